@@ -1,0 +1,105 @@
+"""ctypes loaders for the two in-tree shared libraries.
+
+* ``libonedc_coder.so``  — host entropy coder, C ABI in ``include/onedc_coder.h``
+* ``libonedc_hip.so``    — gfx950 HIP kernels, C ABI in ``include/onedc_hip.h``
+
+There is deliberately no fallback: a missing library raises ``NativeLibraryError``
+so that a product path can never silently run on something else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+CODER_SO = os.path.join(CSRC, "libonedc_coder.so")
+HIP_SO = os.path.join(CSRC, "libonedc_hip.so")
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class Container(C.Structure):
+    _fields_ = [
+        ("height", C.c_uint32), ("width", C.c_uint32),
+        ("pad_height", C.c_uint32), ("pad_width", C.c_uint32),
+        ("len_y", C.c_uint32), ("len_z", C.c_uint32), ("len_caption", C.c_uint32),
+        ("off_y", C.c_int64), ("off_z", C.c_int64), ("off_caption", C.c_int64),
+    ]
+
+
+_coder = None
+_hip = None
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+
+
+def coder():
+    """The host coder library (built by ``onedc_amd.build.build_coder``)."""
+    global _coder
+    if _coder is not None:
+        return _coder
+    if not os.path.exists(CODER_SO):
+        raise NativeLibraryError(
+            f"{CODER_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(CODER_SO)
+    sig = {
+        "onedc_rans_enc_create": (_P, [_I, _I]),
+        "onedc_rans_enc_destroy": (None, [_P]),
+        "onedc_rans_enc_add_cdf": (_I, [_P, _P, _I, _I, _P, _P]),
+        "onedc_rans_enc_empty_cdf_buffer": (_I, [_P]),
+        "onedc_rans_enc_reset": (_I, [_P]),
+        "onedc_rans_enc_encode_with_indexes": (_I, [_P, _P, _P, _L, _I]),
+        "onedc_rans_enc_flush": (_I, [_P]),
+        "onedc_rans_enc_stream_size": (_L, [_P]),
+        "onedc_rans_enc_get_stream": (_I, [_P, _P, _L]),
+        "onedc_rans_dec_create": (_P, [_I]),
+        "onedc_rans_dec_destroy": (None, [_P]),
+        "onedc_rans_dec_add_cdf": (_I, [_P, _P, _I, _I, _P, _P]),
+        "onedc_rans_dec_empty_cdf_buffer": (_I, [_P]),
+        "onedc_rans_dec_set_stream": (_I, [_P, _P, _L]),
+        "onedc_rans_dec_decode_stream": (_I, [_P, _P, _L, _I, _P]),
+        "onedc_rans_dec_decode_batch": (_I, [_P, _I, _P, _L, _I, _P, _I, _P]),
+        "onedc_rans_enc_encode_batch": (_I, [_P, _I, _P, _P, _L, _I, _I]),
+        "onedc_pmf_to_quantized_cdf": (_I, [_P, _I, _I, _P]),
+        "onedc_container_parse": (_I, [_P, _L, _I, _I, C.POINTER(Container)]),
+        "onedc_container_write": (_L, [C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32,
+                                       _P, C.c_uint32, _P, _L]),
+        "onedc_pack_indices": (_L, [_P, _L, _I, _P, _L]),
+        "onedc_unpack_indices": (_I, [_P, _L, _L, _I, _P]),
+        "onedc_coder_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._signatures = sig
+    _coder = lib
+    return lib
+
+
+CODER_SYMBOLS = [
+    "onedc_rans_enc_create", "onedc_rans_enc_destroy", "onedc_rans_enc_add_cdf",
+    "onedc_rans_enc_empty_cdf_buffer", "onedc_rans_enc_reset",
+    "onedc_rans_enc_encode_with_indexes", "onedc_rans_enc_flush", "onedc_rans_enc_stream_size",
+    "onedc_rans_enc_get_stream", "onedc_rans_dec_create", "onedc_rans_dec_destroy",
+    "onedc_rans_dec_add_cdf", "onedc_rans_dec_empty_cdf_buffer", "onedc_rans_dec_set_stream",
+    "onedc_rans_dec_decode_stream", "onedc_rans_dec_decode_batch", "onedc_rans_enc_encode_batch",
+    "onedc_pmf_to_quantized_cdf", "onedc_container_parse", "onedc_container_write",
+    "onedc_pack_indices", "onedc_unpack_indices", "onedc_coder_version",
+]
+
+
+def hip():
+    """The HIP kernel library; signatures are attached by ``onedc_amd.kernels``."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    if not os.path.exists(HIP_SO):
+        raise NativeLibraryError(
+            f"{HIP_SO} is missing: the HIP extension must be built "
+            "(`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+    _hip = C.CDLL(HIP_SO)
+    return _hip

@@ -1,0 +1,72 @@
+"""In-tree builds of the native pieces (no JIT cache: the .so files travel with the repo).
+
+    build_coder()  g++     onedc_amd/csrc/coder.cpp          -> csrc/libonedc_coder.so
+    build_hip()    hipcc   onedc_amd/csrc/*.hip (gfx950)     -> csrc/libonedc_hip.so
+    build_oracle() make -C oracle  (the checkers: C restatement + reference build)
+"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+from . import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_coder(force=False):
+    src = [os.path.join(_native.CSRC, "coder.cpp"), os.path.join(ROOT, "include", "onedc_coder.h")]
+    if force or _stale(_native.CODER_SO, src):
+        _run(["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall",
+              "-o", _native.CODER_SO, src[0]])
+    return _native.CODER_SO
+
+
+def hip_sources():
+    return sorted(glob.glob(os.path.join(_native.CSRC, "*.hip")))
+
+
+def build_hip(force=False, extra_flags=()):
+    srcs = hip_sources()
+    deps = srcs + glob.glob(os.path.join(_native.CSRC, "*.h")) + \
+        [os.path.join(ROOT, "include", "onedc_hip.h")]
+    if not srcs:
+        raise RuntimeError("no HIP sources found")
+    if force or _stale(_native.HIP_SO, deps):
+        objs = []
+        for s in srcs:
+            o = s[:-4] + ".o"
+            if force or _stale(o, [s] + [d for d in deps if d.endswith(".h")]):
+                _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+                      "-Wno-unused-result", *extra_flags, "-o", o, s])
+            objs.append(o)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _native.HIP_SO, *objs])
+    return _native.HIP_SO
+
+
+def build_oracle():
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
+
+
+def build_all(force=False):
+    build_coder(force)
+    build_hip(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
