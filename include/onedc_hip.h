@@ -1,0 +1,159 @@
+/* onedc_hip.h — C ABI of the gfx950 (MI355X / CDNA4) kernel library libonedc_hip.so.
+ *
+ * The reference has no GPU kernels of its own: its device work is stock PyTorch ops issued by
+ * the modules on the decode path.  Each entry point below names the reference computation it
+ * replaces (paths relative to the reference root, `src/` omitted).  The reference-side binding a
+ * maintainer would add is a ctypes stub.
+ *
+ * Conventions
+ *   - raw device pointers, sizes, and a hipStream_t passed as void*; no torch types
+ *   - activations are NHWC ("pixel-major"): element (b, y, x, c) of a tensor with channel stride
+ *     `cs` and channel offset `co` lives at ((b*H + y)*W + x)*cs + co + c.  A (cs, co) pair lets a
+ *     kernel read or write a channel slice of a wider buffer, which is how torch.cat along
+ *     channels is realised without copies
+ *   - bf16 storage unless a field says f32; all accumulation is f32
+ *   - no allocation and no synchronisation inside any entry point (graph-capturable)
+ *   - results are deterministic and batch-invariant: no atomics, no split-K, fixed reduction order
+ *   - return value: 0 ok, <0 argument error, >0 hipError_t of the launch
+ */
+#ifndef ONEDC_HIP_H
+#define ONEDC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogue selector of onedc_conv_gemm: v = act(alpha*acc + bias) [+ residual] */
+enum {
+    ONEDC_EPI_LINEAR = 0,
+    ONEDC_EPI_LEAKY = 1,     /* LeakyReLU(slope)                         dcvc.py:195-197, 246-249 */
+    ONEDC_EPI_SILU = 2,
+    ONEDC_EPI_GLU_LEAKY = 3, /* LeakyReLU(a,.1)+LeakyReLU(b,.01)         ConvFFN3, dcvc.py:353-367 */
+    ONEDC_EPI_GEGLU = 4      /* a * gelu(b)                              diffusers GEGLU (UNet FF) */
+};
+
+/* Implicit-GEMM convolution / linear layer on the matrix cores (v_mfma_f32_16x16x32_bf16).
+ *   y[m, n] = act(alpha * sum_k x[m, k] * w[n, k] + bias[n]) + res[m, n]
+ * m runs over output pixels (b, oy, ox), n over output channels, k over (ky, kx, cin).
+ * Replaces every nn.Conv2d / nn.Linear on the decode path: DepthConvBlock4 1x1s (dcvc.py:242-265,
+ * 353-367), ResidualBlockUpsample (dcvc.py:183-208), ResnetBlock convs (vqgan/blocks.py:28-33),
+ * UNet ResnetBlock2D / Transformer2D projections / up-down samplers (decoder_unet.py:204-299),
+ * VAE decoder convs (model_sd15_with_codec_stage1.py:184-188).
+ * Weights are pre-packed by the host: bf16 [n_rows_padded][KH*KW*Cin], k-contiguous, rows padded
+ * with zeros to a multiple of 128.  For GLU epilogues rows alternate in blocks of 16 (a-block,
+ * b-block); for pixel_shuffle rows are ordered (dy*2+dx)*C' + c. */
+typedef struct onedc_conv_params {
+    const void *x;       /* bf16 input */
+    const void *w;       /* bf16 packed weights */
+    const float *bias;   /* f32 [n] or NULL (GLU: [2][n/2] laid out like the weight rows) */
+    const void *res;     /* bf16 residual on the output pixel grid, or NULL */
+    void *y;             /* bf16 (or f32 when out_f32) output */
+    const void *zeros;   /* >= 256 B of zeros in device memory (source of halo / tail rows) */
+    int32_t B, IH, IW, Cin, x_cs, x_co; /* Cin: channels read, multiple of 64 */
+    int32_t OH, OW, Cout, y_cs, y_co;   /* Cout: GEMM columns (before GLU halving / shuffle) */
+    int32_t r_cs, r_co;
+    int32_t KH, KW, stride, pad, up;    /* up=1: nearest x2 upsample of the input fused in */
+    int32_t epi, out_f32, pixel_shuffle;
+    float alpha, slope;
+    int32_t batch;                      /* >1: batched GEMM over blockIdx.z */
+    int64_t x_bs, w_bs, y_bs, r_bs;     /* element strides between batches */
+} onedc_conv_params;
+int onedc_conv_gemm(const onedc_conv_params *p, void *stream);
+
+/* Small-channel direct convolution (Cin < 64: VAE conv_in / post_quant_conv, HyperDecoder.feat_in
+ * codec_module.py:149-152).  w: f32 [Cout][KH][KW][Cin]; x bf16 or f32 (x_f32). */
+typedef struct onedc_direct_conv_params {
+    const void *x; const float *w; const float *bias; void *y;
+    int32_t B, H, W, Cin, x_cs, x_co, Cout, y_cs, y_co, K, x_f32, out_f32, epi;
+    float slope, in_scale;              /* x is multiplied by in_scale first (1/0.18215 for the VAE) */
+} onedc_direct_conv_params;
+int onedc_direct_conv(const onedc_direct_conv_params *p, void *stream);
+
+/* Depthwise 3x3, pad 1 (DepthConv.depth_conv, dcvc.py:251).  w f32 [3][3][C], bias f32 [C]. */
+int onedc_dwconv3x3(const void *x, const float *w, const float *bias, void *y, int B, int H, int W,
+                    int C, int x_cs, int x_co, int y_cs, int y_co, void *stream);
+
+/* GroupNorm(32 groups) [+ SiLU] as statistics + a per-channel affine:
+ *   onedc_gn_stats        per-chunk partial sums (fixed order) -> per image/group mean, rstd ->
+ *                         ab[b][c] = (rstd*gamma, beta - mean*rstd*gamma), f32 [B][C][2]
+ *   onedc_scale_shift_act y = act(x * a + bb), act = SiLU or identity
+ * Replaces nn.GroupNorm + SiLU in ResnetBlock (vqgan/blocks.py:39-46), reduce_resblock
+ * (decoder_unet.py:19-26), diffusers ResnetBlock2D / Transformer2D.norm / Attention.group_norm.
+ * "Image" is whatever the caller makes it: for the VAE mid-block attention, whose statistics are
+ * per 16x16 window (vae/autoencoders_patch_attn.py:22-28), the windows are the batch.
+ * partial: f32 workspace of B * onedc_gn_chunks(HW) * 64 floats. */
+int onedc_gn_chunks(int HW);
+int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *partial, float *ab, int B,
+                   int HW, int C, int x_cs, int x_co, float eps, void *stream);
+int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
+                          int y_cs, int y_co, int silu, void *stream);
+
+/* LayerNorm over the last dim of [rows][C] bf16 (BasicTransformerBlock norm1-3). */
+int onedc_layernorm(const void *x, const float *gamma, const float *beta, void *y, int64_t rows,
+                    int C, float eps, void *stream);
+
+/* Row softmax of f32 scores [rows][n] -> bf16 probabilities [rows][n_pad] (AttnBlock,
+ * vqgan/blocks.py:95; VAE mid attention).  Columns n..n_pad-1 are written as 0. */
+int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, void *stream);
+
+/* Flash attention for the UNet's multi-head self/cross attention (diffusers Attention with
+ * SDPA; call sites decoder_unet.py:204-293).  q [B][Nq][H*DQ], k [B][Nk][H*DQ] bf16,
+ * vt [B][H*DV][Nk_pad] bf16 (V transposed, keys contiguous), o [B][Nq][H*DV].
+ * DQ in {64, 96, 160}, DV in {48, 80, 160}: head dims 40/80/160 zero-padded by the packed
+ * projection weights.  scale multiplies q.k before the softmax. */
+int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
+                     int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream);
+
+/* ---- elementwise heads ------------------------------------------------------------------- */
+/* FSQ.indices_to_codes, levels [4]*7 (codec_module.py:431): idx int32 [n] -> f32 codes [n][8]
+ * (7 used, channel 7 = 0). */
+int onedc_fsq_codes(const int32_t *idx, float *codes, int64_t n, void *stream);
+
+/* One step k of the four-part prior (compression_model.py:369-407 decode, :303-358 encode).
+ * params: bf16/f32 NHWC [B][H][W][2C] = (scales | means), C = 128.
+ *  - prior_indexes: scale plane of step k -> int16 rANS table indexes [B][C/4][H][W] (NCHW order
+ *    of the reference's flattening; combine_for_writing :296-301 + build_indexes
+ *    entropy_models.py:355-362)
+ *  - prior_update_dec: y_hat += (symbols + means) * mask_k        (:383-385)
+ *  - prior_update_enc: symbols = round((y - means)*mask_k) combined; y_hat += that + means*mask_k
+ *  - prior_update_zonly: y_hat += means * mask_k                  (:410-418)
+ * y_hat is f32 NHWC [B][H][W][C] inside a buffer with channel stride y_cs. */
+int onedc_prior_indexes(const void *params, int params_f32, int16_t *indexes, int B, int H, int W,
+                        int C, int step, void *stream);
+int onedc_prior_update_dec(const void *params, int params_f32, const int16_t *symbols, void *y_hat,
+                           int yhat_f32, int y_cs, int B, int H, int W, int C, int step, void *stream);
+int onedc_prior_update_enc(const void *params, int params_f32, const float *y, int16_t *symbols,
+                           void *y_hat, int yhat_f32, int y_cs, int B, int H, int W, int C, int step,
+                           void *stream);
+int onedc_prior_update_zonly(const void *params, int params_f32, void *y_hat, int yhat_f32, int y_cs,
+                             int B, int H, int W, int C, int step, void *stream);
+
+/* get_x0_from_noise (dmd/utils.py:279-284) in f64 like the reference call site
+ * (model_sd15_with_codec_stage1.py:320-322): x0 = (reduced - sqrt(1-a)*eps)/sqrt(a). f32 in/out. */
+int onedc_x0_from_noise(const float *reduced, const float *eps, float *x0, int64_t n,
+                        double alpha_bar, void *stream);
+
+/* NHWC (bf16/f32) padded picture -> NCHW f32 [B][3][H][W] crop (model...stage1.py:327-329),
+ * optional clamp(-1,1)*0.5+0.5 (inference.py:106). */
+int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
+                    int unit_range, void *stream);
+
+/* generic strided copy / cast between NHWC views (channel concat, padding layouts) */
+int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, int y_f32, int y_cs,
+                        int y_co, int64_t pixels, int C, void *stream);
+/* window partition (B,H,W,C) <-> (B*nwin, win*win, C) for the VAE mid attention */
+int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int win, int reverse,
+                           void *stream);
+/* sinusoidal timestep embedding, flip_sin_to_cos, shift 0 (decoder_unet.py:138): f32 [n][dim] */
+int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *stream);
+/* y = a + b (bf16), used where a residual cannot ride on a GEMM epilogue */
+int onedc_add(const void *a, const void *b, void *y, int64_t n, void *stream);
+
+const char *onedc_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONEDC_HIP_H */

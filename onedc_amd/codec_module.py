@@ -1,0 +1,271 @@
+"""IntraNoAR — the codec module of the decode path on HIP kernels (+ host rANS).
+
+Mirrors reference src/models/sd15_onedc_codec_stage1/codec_module.py: `IntraNoAR.decode` :356-369,
+`_decompress` :418-454, `HyperDecoder` :145-166, `SemanticAdaptor` :169-181, `Decoder` :88-116 and the
+four-part prior of src/modules/entropy/compression_model.py:303-407.  The reference is batch = 1;
+here every call takes a list of bitstreams and runs them as one batch (same arithmetic per image:
+all kernels are batch-invariant), which is what makes the rANS hops and launches amortise.
+
+The analysis transform (`enc`, `hyper_enc`) is out of scope for this round; `encode_latents`
+implements the encode side of the prior + entropy coder from given (z indices, y) so that valid
+bitstreams can be produced and the enc/dec round trip can be tested.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .entropy import rans
+from .entropy.entropy_models import EntropyCoder, GaussianEncoder
+from .entropy.utils import decode_i, encode_i, pack_indices, read_from_file, unpack_indices, write_to_file
+from .kernels import View, new_view
+from .layers import (Conv, DepthConvBlock4, ResidualBlockUpsample, VQAttnBlock, VQResnetBlock, Workspace)
+
+
+class HyperDecoder:
+    def __init__(self, sd, device, p="hyper_dec"):
+        w = sd[f"{p}.feat_in.0.weight"]                        # (128, 7, 1, 1) -> f32 [128][8] (pad cin)
+        wf = torch.zeros(w.shape[0], 8)
+        wf[:, :7] = w[:, :, 0, 0]
+        self.feat_w = wf.contiguous().to(device)
+        self.feat_b = sd[f"{p}.feat_in.0.bias"].float().contiguous().to(device)
+        self.n = w.shape[0]
+        self.b0 = DepthConvBlock4(sd, f"{p}.to_entropy.0", device)
+        self.u1 = ResidualBlockUpsample(sd, f"{p}.to_entropy.1", device)
+        self.b2 = DepthConvBlock4(sd, f"{p}.to_entropy.2", device)
+        self.u3 = ResidualBlockUpsample(sd, f"{p}.to_entropy.3", device)
+        self.b4 = DepthConvBlock4(sd, f"{p}.to_entropy.4", device)
+
+    def __call__(self, codes):
+        """codes: f32 View (B, h, w, 8) -> (params View, z_semantic View)."""
+        z = new_view(codes.B, codes.H, codes.W, self.n, codes.t.device)
+        K.direct_conv(codes, self.feat_w, self.feat_b, z, K=1, epi=K.EPI_LEAKY, slope=0.01)
+        h = self.b4(self.u3(self.b2(self.u1(self.b0(z)))))
+        return h, z
+
+
+class SemanticAdaptor:
+    def __init__(self, sd, device, C=768, p="semantic_adaptor.to_semantic"):
+        self.b0 = DepthConvBlock4(sd, f"{p}.0", device)
+        self.r1 = VQResnetBlock(sd, f"{p}.1", device)
+        self.a2 = VQAttnBlock(sd, f"{p}.2", device, C)
+        self.a3 = VQAttnBlock(sd, f"{p}.3", device, C)
+        self.r4 = VQResnetBlock(sd, f"{p}.4", device)
+        self.a5 = VQAttnBlock(sd, f"{p}.5", device, C)
+        self.a6 = VQAttnBlock(sd, f"{p}.6", device, C)
+        self.b7 = DepthConvBlock4(sd, f"{p}.7", device)
+
+    def __call__(self, z_semantic, ws):
+        x = self.b0(z_semantic)
+        x = self.a3(self.a2(self.r1(x, ws), ws), ws)
+        x = self.a6(self.a5(self.r4(x, ws), ws), ws)
+        return self.b7(x)
+
+
+class Decoder:
+    def __init__(self, sd, device, p="dec"):
+        self.t0 = DepthConvBlock4(sd, f"{p}.trans_coding.0", device)
+        self.t1 = DepthConvBlock4(sd, f"{p}.trans_coding.1", device)
+        self.res_a = [VQResnetBlock(sd, f"{p}.blocks.{i}", device) for i in range(3)]
+        self.up_a = Conv(sd, f"{p}.blocks.3", device, shuffle=True)
+        self.up_b = Conv(sd, f"{p}.blocks.5", device)
+        self.res_b = [VQResnetBlock(sd, f"{p}.blocks.{i}", device) for i in (6, 7, 8)]
+        self.s0 = ResidualBlockUpsample(sd, f"{p}.sem_up.0", device)
+        self.s1 = DepthConvBlock4(sd, f"{p}.sem_up.1", device)
+        self.s2 = ResidualBlockUpsample(sd, f"{p}.sem_up.2", device)
+        self.s3 = DepthConvBlock4(sd, f"{p}.sem_up.3", device)
+        self.s4 = ResidualBlockUpsample(sd, f"{p}.sem_up.4", device)
+        self.conv_out = DepthConvBlock4(sd, f"{p}.conv_out", device)
+
+    def __call__(self, y_hat, sem_hat, ws):
+        dev = y_hat.t.device
+        y = self.t1(self.t0(y_hat))
+        for r in self.res_a:
+            y = r(y, ws)
+        y = self.up_b(self.up_a(y))
+        # torch.cat([y, sem], dim=1) without a copy: both branches write their last layer into
+        # channel slices of one buffer
+        cat = new_view(y.B, y.H, y.W, 2 * y.C, dev)
+        for i, r in enumerate(self.res_b):
+            y = r(y, ws, cat.slice(0, y.C) if i == 2 else None)
+        s = self.s3(self.s2(self.s1(self.s0(sem_hat))))
+        self.s4(s, cat.slice(y.C, y.C))
+        return self.conv_out(cat)
+
+
+class IntraNoAR:
+    def __init__(self, sd, device, bottleneck_ch=128, semantic_ch=768, z_fsq_levels=(4,) * 7, host_threads=None):
+        self.device = device
+        self.N = N = bottleneck_ch
+        self.hyper_dec = HyperDecoder(sd, device)
+        self.y_prior_fusion = [DepthConvBlock4(sd, f"y_prior_fusion.{i}", device) for i in range(2)]
+        self.y_spatial_prior_reduction = Conv(sd, "y_spatial_prior_reduction", device)
+        self.y_spatial_prior_adaptor = [DepthConvBlock4(sd, f"y_spatial_prior_adaptor_{i}", device) for i in (1, 2, 3)]
+        self.y_spatial_prior = [DepthConvBlock4(sd, f"y_spatial_prior.{i}", device) for i in range(3)]
+        self.semantic_adaptor = SemanticAdaptor(sd, device, semantic_ch)
+        self.dec = Decoder(sd, device)
+        self.z_fsq_levels = list(z_fsq_levels)
+        self.index_unit_length = int(round(np.log2(np.prod(self.z_fsq_levels))))   # 14
+        self.ds = 64
+        self.cond_ds = 8
+        self.debug = False
+        self.ws = Workspace(device)
+        self.host_threads = host_threads or min(16, os.cpu_count() or 1)
+        self.gaussian_encoder = GaussianEncoder()
+        self.entropy_coder = None
+        self._tables = None
+
+    # reference CompressionModel.update (compression_model.py:169-171)
+    def update(self, force=False):
+        self.entropy_coder = EntropyCoder(False, 1)
+        self.gaussian_encoder.update(force=force, entropy_coder=self.entropy_coder)
+        self._tables = self.gaussian_encoder.get_cdf_info()
+
+    # ------------------------------------------------------------------ prior nets
+    def _params_from_indices(self, indices):
+        """indices: int32 device tensor (B, h, w) -> (fused params f32 View (B,4h,4w,2N), z_semantic)."""
+        B, h, w = indices.shape
+        codes = View(torch.empty(B * h * w * 8, dtype=torch.float32, device=self.device), B, h, w, 8)
+        K.fsq_codes(indices.contiguous(), codes.t)
+        params, z_semantic = self.hyper_dec(codes)
+        fused = self.y_prior_fusion[0](params)
+        fused = self.y_prior_fusion[1](fused, out_f32=True)
+        return fused, z_semantic
+
+    def _next_params(self, k, y_hat, common_cat):
+        """(scales, means) of step k >= 1 from y_hat_so_far and the reduced common params."""
+        K.copy_channels(y_hat, common_cat.slice(0, self.N))               # f32 -> bf16 into the cat buffer
+        a = self.y_spatial_prior_adaptor[k - 1](common_cat)
+        a = self.y_spatial_prior[0](a)
+        a = self.y_spatial_prior[1](a)
+        return self.y_spatial_prior[2](a, out_f32=True)
+
+    def _prior_setup(self, fused):
+        B, H, W, N = fused.B, fused.H, fused.W, self.N
+        fused_bf = new_view(B, H, W, 2 * N, self.device)
+        K.copy_channels(fused, fused_bf)
+        common_cat = new_view(B, H, W, 2 * N, self.device)                 # [y_hat_so_far | common]
+        self.y_spatial_prior_reduction(fused_bf, common_cat.slice(N, N))
+        y_hat = new_view(B, H, W, N, self.device, torch.float32)
+        return common_cat, y_hat
+
+    # ------------------------------------------------------------------ decode
+    @torch.no_grad()
+    def decompress(self, streams_y, indices):
+        """decompress_four_part_prior (compression_model.py:369-407) for a batch.
+        streams_y: list of B rANS byte strings; indices: int32 (B,h,w) device tensor."""
+        B = len(streams_y)
+        fused, z_semantic = self._params_from_indices(indices)
+        common_cat, y_hat = self._prior_setup(fused)
+        H, W, N = fused.H, fused.W, self.N
+        n = (N // 4) * H * W
+        decoders = []
+        for s in streams_y:
+            d = rans.RansDecoder(1)
+            d.add_cdf(*self._tables)
+            d.set_stream(s)
+            decoders.append(d)
+        idx_dev = torch.empty(B * n, dtype=torch.int16, device=self.device)
+        sym_dev = torch.empty(B * n, dtype=torch.int16, device=self.device)
+        idx_host = torch.empty(B, n, dtype=torch.int16).pin_memory()
+        sym_host = torch.empty(B, n, dtype=torch.int16).pin_memory()
+        params = fused
+        for k in range(4):
+            if k > 0:
+                params = self._next_params(k, y_hat, common_cat)
+            K.prior_indexes(params, idx_dev, B, H, W, N, k)
+            idx_host.copy_(idx_dev.view(B, n), non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            sym_host.numpy()[...] = rans.decode_batch(decoders, idx_host.numpy(), 0, self.host_threads)
+            sym_dev.view(B, n).copy_(sym_host, non_blocking=True)
+            K.prior_update_dec(params, sym_dev, y_hat, k)
+        return y_hat, z_semantic
+
+    @torch.no_grad()
+    def recon_with_z(self, indices):
+        """z-only model: forward_four_part_prior_recon_with_z (compression_model.py:421-465)."""
+        fused, z_semantic = self._params_from_indices(indices)
+        common_cat, y_hat = self._prior_setup(fused)
+        params = fused
+        for k in range(4):
+            if k > 0:
+                params = self._next_params(k, y_hat, common_cat)
+            K.prior_update_zonly(params, y_hat, k)
+        return y_hat, z_semantic
+
+    @torch.no_grad()
+    def synthesis(self, y_hat, z_semantic):
+        """codec_module.py:452-453: y_semantic = semantic_adaptor(z_semantic); x_hat = dec(y_hat, y_semantic)."""
+        y_bf = new_view(y_hat.B, y_hat.H, y_hat.W, self.N, self.device)
+        K.copy_channels(y_hat, y_bf)
+        y_semantic = self.semantic_adaptor(z_semantic, self.ws)
+        x_hat = self.dec(y_bf, y_semantic, self.ws)
+        return x_hat, y_semantic
+
+    @torch.no_grad()
+    def decode(self, fp=None, stream=None):
+        """Reference signature (codec_module.py:356-369), one stream or a list of streams."""
+        assert fp or stream
+        blobs = stream if stream else [read_from_file(f) for f in ([fp] if isinstance(fp, str) else fp)]
+        if isinstance(blobs, (bytes, bytearray)):
+            blobs = [blobs]
+        infos = [decode_i(b, self.index_unit_length, self.ds) for b in blobs]
+        hw = {(d["pad_height"], d["pad_width"]) for d in infos}
+        if len(hw) != 1:
+            raise ValueError("a batch must share one padded picture size")
+        pad_h, pad_w = hw.pop()
+        zh, zw = pad_h // self.ds, pad_w // self.ds
+        idx = np.stack([unpack_indices(d["bit_stream_z"], zh * zw, self.index_unit_length) for d in infos])
+        indices = torch.from_numpy(idx.reshape(len(blobs), zh, zw)).to(self.device)
+        y_hat, z_semantic = self.decompress([d["bit_stream_y"] for d in infos], indices)
+        x_hat, y_semantic = self.synthesis(y_hat, z_semantic)
+        orig_hw = [(d["height"], d["width"]) for d in infos]
+        return x_hat, y_semantic, orig_hw, (pad_h, pad_w), infos[0]["pad_tuple"]
+
+    # ------------------------------------------------------------------ encode side of the prior
+    @torch.no_grad()
+    def encode_latents(self, indices, y=None, noise_seed=0, heights=None, widths=None):
+        """compress_four_part_prior + entropy encode (codec_module.py:372-415 minus the analysis
+        transform): indices int32 (B,h,w); y f32 NHWC (B,4h,4w,N) device tensor, or None to draw a
+        synthetic latent step by step as means + clamp(scales, .11, 8) * N(0,1).
+        Returns (list of container bytes, y_hat View)."""
+        B, zh, zw = indices.shape
+        fused, _ = self._params_from_indices(indices)
+        common_cat, y_hat = self._prior_setup(fused)
+        H, W, N = fused.H, fused.W, self.N
+        n = (N // 4) * H * W
+        encoders = []
+        for _ in range(B):
+            e = rans.RansEncoder(False, 1)
+            e.add_cdf(*self._tables)
+            encoders.append(e)
+        idx_dev = torch.empty(B * n, dtype=torch.int16, device=self.device)
+        sym_dev = torch.empty(B * n, dtype=torch.int16, device=self.device)
+        gen = torch.Generator(device=self.device).manual_seed(noise_seed)
+        params = fused
+        for k in range(4):
+            if k > 0:
+                params = self._next_params(k, y_hat, common_cat)
+            if y is None:      # synthetic latent for this step's positions (bench / test input only)
+                pv = params.t[:B * H * W * 2 * N].view(B, H, W, 2 * N)
+                y_k = pv[..., N:] + pv[..., :N].clamp(0.11, 8.0) * torch.randn(
+                    (B, H, W, N), generator=gen, device=self.device)
+                y_k = y_k.contiguous()
+            else:
+                y_k = y
+            K.prior_indexes(params, idx_dev, B, H, W, N, k)
+            K.prior_update_enc(params, y_k, sym_dev, y_hat, k)
+            torch.cuda.current_stream().synchronize()
+            rans.encode_batch(encoders, sym_dev.view(B, n).cpu().numpy(), idx_dev.view(B, n).cpu().numpy(), 0,
+                              self.host_threads)
+        blobs = []
+        idx_host = indices.cpu().numpy()
+        for b, e in enumerate(encoders):
+            e.flush()
+            ybytes = e.get_encoded_stream().tobytes()
+            zbytes = pack_indices(idx_host[b].reshape(-1), self.index_unit_length)
+            hh = heights[b] if heights else zh * self.ds
+            ww = widths[b] if widths else zw * self.ds
+            blobs.append(encode_i(hh, ww, ybytes, zbytes, b"", 0))
+        return blobs, y_hat

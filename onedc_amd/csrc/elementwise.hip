@@ -1,0 +1,388 @@
+// elementwise.hip — the small HBM-bound heads of the decode path: depthwise 3x3, small-channel
+// direct convolution, FSQ code book, the four-part-prior bookkeeping (masks, combine_for_writing,
+// build_indexes, y_hat update), the epsilon -> x0 formula, output crop/convert, strided copies.
+#include "common.h"
+
+namespace {
+
+// ---- four-part prior helpers (reference modules/entropy/compression_model.py:241-301) ------------
+// step k assigns channel group g (C/4 channels each) the 2x2 phase PHASE[k][g];
+// phases 0..3 = (y&1, x&1) = (0,0),(0,1),(1,0),(1,1)
+__device__ __constant__ int PHASE[4][4] = {{0, 1, 2, 3}, {3, 2, 1, 0}, {2, 3, 0, 1}, {1, 0, 3, 2}};
+
+__device__ __forceinline__ int active_group(int step, int y, int x) {
+    const int ph = ((y & 1) << 1) | (x & 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (PHASE[step][g] == ph) return g;
+    return 0;
+}
+
+template <bool F32>
+__device__ __forceinline__ float ldp(const void *p, int64_t i) {
+    if (F32) return ((const float *)p)[i];
+    return bf2f(((const bf16_t *)p)[i]);
+}
+template <bool F32>
+__device__ __forceinline__ void stp(void *p, int64_t i, float v) {
+    if (F32) ((float *)p)[i] = v;
+    else ((bf16_t *)p)[i] = f2bf(v);
+}
+
+constexpr float LOG_SCALE_MIN = -2.2072749131897207f;           // ln 0.11
+constexpr float LOG_SCALE_STEP = 0.024971781017814617f;          // (ln 64 - ln 0.11) / 255
+
+// indexes[b][c4][y][x] (NCHW, the reference's flatten order) from the scale plane of `step`.
+// combine_for_writing sums the four masked channel groups: exactly one is non-zero per position.
+template <bool F32>
+__global__ void prior_indexes_kernel(const void *params, int16_t *idx, int B, int H, int W, int C, int step) {
+    const int q = C >> 2;
+    const int64_t total = (int64_t)B * q * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        int64_t r = i / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c4 = (int)(r % q);
+        const int b = (int)(r / q);
+        const int g = active_group(step, y, x);
+        const int64_t pix = ((int64_t)b * H + y) * W + x;
+        float s = ldp<F32>(params, pix * (2 * C) + g * q + c4);     // scales = first C channels
+        // the reference adds the three masked-out groups as +0.0f: a -0.0 scale becomes +0.0, harmless
+        s = fmaxf(s, 1e-5f);
+        float fi = (logf(s) - LOG_SCALE_MIN) / LOG_SCALE_STEP;
+        fi = fminf(fmaxf(fi, 0.f), 255.f);
+        idx[i] = (int16_t)(int)fi;
+    }
+}
+
+// mode 0 decode: y_hat += (sym + mean)*mask ; mode 1 encode: sym = round((y-mean)*mask), same update;
+// mode 2 z-only: y_hat += mean*mask.  step 0 initialises y_hat (masked-out positions become 0).
+template <bool PF32, bool YF32, int MODE>
+__global__ void prior_update_kernel(const void *params, const float *yin, int16_t *sym, void *y_hat, int y_cs,
+                                    int B, int H, int W, int C, int step) {
+    const int q = C >> 2;
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int b = (int)(pix / ((int64_t)W * H));
+        const int g = c / q;
+        const bool on = active_group(step, y, x) == g;
+        float cur = 0.f;
+        if (on) {
+            const float mean = ldp<PF32>(params, pix * (2 * C) + C + c);
+            const int64_t si = (((int64_t)b * q + (c - g * q)) * H + y) * W + x;
+            if (MODE == 0) {
+                cur = (float)sym[si] + mean;
+            } else if (MODE == 1) {
+                const float v = rintf(yin[pix * C + c] - mean);          // torch.round: half to even
+                const float cl = fminf(fmaxf(v, -30000.f), 30000.f);      // entropy_models.py:67
+                sym[si] = (int16_t)cl;
+                cur = v + mean;
+            } else {
+                cur = mean;
+            }
+        }
+        const int64_t yo = pix * y_cs + c;
+        if (step == 0) {
+            stp<YF32>(y_hat, yo, cur);
+        } else if (on) {
+            stp<YF32>(y_hat, yo, ldp<YF32>(y_hat, yo) + cur);
+        }
+    }
+}
+
+__global__ void fsq_codes_kernel(const int32_t *idx, float *codes, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i & 7);
+        const int v = idx[i >> 3];
+        codes[i] = d < 7 ? (float)(((v >> (2 * d)) & 3) - 2) * 0.5f : 0.f;
+    }
+}
+
+__global__ void x0_kernel(const float *reduced, const float *eps, float *x0, int64_t n, double sa, double sb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        x0[i] = (float)(((double)reduced[i] - sb * (double)eps[i]) / sa);
+}
+
+template <bool F32>
+__global__ void image_out_kernel(const void *x, int x_cs, float *out, int B, int PH, int PW, int H, int W,
+                                 int unit) {
+    const int64_t total = (int64_t)B * 3 * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        int64_t r = i / W;
+        const int yy = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % 3);
+        const int b = (int)(r / 3);
+        float v = ldp<F32>(x, (((int64_t)b * PH + yy) * PW + xx) * x_cs + c);
+        if (unit) v = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
+        out[i] = v;
+    }
+}
+
+template <bool XF, bool YF>
+__global__ void copy_channels_kernel(const void *x, int x_cs, int x_co, void *y, int y_cs, int y_co,
+                                     int64_t pixels, int C) {
+    const int64_t total = pixels * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / C;
+        const int c = (int)(i - pix * C);
+        stp<YF>(y, pix * y_cs + y_co + c, ldp<XF>(x, pix * x_cs + x_co + c));
+    }
+}
+
+// (B,H,W,C) <-> (B*nwin, win*win, C), 8 channels per lane
+__global__ void window_partition_kernel(const bf16_t *x, bf16_t *y, int B, int H, int W, int C, int win,
+                                        int reverse) {
+    const int CC = C >> 3;
+    const int nwx = W / win, nwy = H / win;
+    const int64_t total = (int64_t)B * H * W * CC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % CC);
+        const int64_t wp = i / CC;                       // index in window-major order
+        const int pin = (int)(wp % (win * win));
+        int64_t r = wp / (win * win);
+        const int wx = (int)(r % nwx);
+        r /= nwx;
+        const int wy = (int)(r % nwy);
+        const int b = (int)(r / nwy);
+        const int64_t pix = ((int64_t)b * H + wy * win + pin / win) * W + wx * win + pin % win;
+        if (!reverse)
+            ((uint4 *)y)[wp * CC + cc] = ((const uint4 *)x)[pix * CC + cc];
+        else
+            ((uint4 *)y)[pix * CC + cc] = ((const uint4 *)x)[wp * CC + cc];
+    }
+}
+
+__global__ void timestep_embedding_kernel(const float *t, float *emb, int n, int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * half) return;
+    const int row = i / half, k = i - row * half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);   // ln 10000
+    const float a = t[row] * freq;
+    emb[row * dim + k] = cosf(a);                 // flip_sin_to_cos: cos half first
+    emb[row * dim + half + k] = sinf(a);
+}
+
+__global__ void add_kernel(const bf16_t *a, const bf16_t *b, bf16_t *y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 va = ((const uint4 *)a)[i], vb = ((const uint4 *)b)[i];
+        const uint32_t *pa = (const uint32_t *)&va, *pb = (const uint32_t *)&vb;
+        uint4 o;
+        uint32_t *po = (uint32_t *)&o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            po[e] = pack_bf2(bf2f((bf16_t)(pa[e] & 0xffff)) + bf2f((bf16_t)(pb[e] & 0xffff)),
+                             bf2f((bf16_t)(pa[e] >> 16)) + bf2f((bf16_t)(pb[e] >> 16)));
+        ((uint4 *)y)[i] = o;
+    }
+}
+
+// depthwise 3x3 pad 1: 8 channels per lane, weights f32 [9][C]
+__global__ void dwconv3x3_kernel(const bf16_t *__restrict__ x, const float *__restrict__ w,
+                                 const float *__restrict__ bias, bf16_t *__restrict__ y, int B, int H, int W,
+                                 int C, int x_cs, int x_co, int y_cs, int y_co) {
+    const int CC = C >> 3;
+    const int64_t total = (int64_t)B * H * W * CC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % CC);
+        const int64_t pix = i / CC;
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        const int64_t b = pix / ((int64_t)W * H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[cc * 8 + e] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = yy + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = xx + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const uint4 v = *(const uint4 *)(x + ((b * H + iy) * W + ix) * x_cs + x_co + cc * 8);
+                const uint32_t *pv = (const uint32_t *)&v;
+                const float *wp = w + (ky * 3 + kx) * C + cc * 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += bf2f((bf16_t)(pv[e] & 0xffff)) * wp[2 * e];
+                    acc[2 * e + 1] += bf2f((bf16_t)(pv[e] >> 16)) * wp[2 * e + 1];
+                }
+            }
+        }
+        *(uint4 *)(y + pix * y_cs + y_co + cc * 8) =
+            make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]),
+                       pack_bf2(acc[6], acc[7]));
+    }
+}
+
+// direct conv for Cin < 64: one thread per (pixel, cout); w f32 [Cout][K][K][Cin]
+template <bool XF>
+__global__ void direct_conv_kernel(const onedc_direct_conv_params p) {
+    const int64_t total = (int64_t)p.B * p.H * p.W * p.Cout;
+    const int pad = p.K / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % p.Cout);
+        const int64_t pix = i / p.Cout;
+        const int xx = (int)(pix % p.W);
+        const int yy = (int)((pix / p.W) % p.H);
+        const int64_t b = pix / ((int64_t)p.W * p.H);
+        float acc = 0.f;
+        for (int ky = 0; ky < p.K; ++ky) {
+            const int iy = yy + ky - pad;
+            if (iy < 0 || iy >= p.H) continue;
+            for (int kx = 0; kx < p.K; ++kx) {
+                const int ix = xx + kx - pad;
+                if (ix < 0 || ix >= p.W) continue;
+                const int64_t xo = ((b * p.H + iy) * p.W + ix) * p.x_cs + p.x_co;
+                const float *wp = p.w + ((int64_t)(n * p.K + ky) * p.K + kx) * p.Cin;
+                for (int c = 0; c < p.Cin; ++c) acc += ldp<XF>(p.x, xo + c) * p.in_scale * wp[c];
+            }
+        }
+        if (p.bias) acc += p.bias[n];
+        if (p.epi == ONEDC_EPI_LEAKY) acc = leaky(acc, p.slope);
+        const int64_t yo = pix * p.y_cs + p.y_co + n;
+        if (p.out_f32) ((float *)p.y)[yo] = acc;
+        else ((bf16_t *)p.y)[yo] = f2bf(acc);
+    }
+}
+
+inline int grid_for(int64_t n, int per = 256) { return (int)min((int64_t)16384, (n + per - 1) / per); }
+
+}  // namespace
+
+#define LAUNCH(kern, n, ...)                                                                     \
+    do {                                                                                         \
+        if ((n) > 0) hipLaunchKernelGGL(kern, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), \
+                                        __VA_ARGS__);                                            \
+        ONEDC_LAUNCH_CHECK();                                                                    \
+    } while (0)
+
+extern "C" {
+
+const char *onedc_hip_version(void) { return "onedc-hip 0.1 (gfx950)"; }
+
+int onedc_fsq_codes(const int32_t *idx, float *codes, int64_t n, void *stream) {
+    if (!idx || !codes) return -1;
+    LAUNCH(fsq_codes_kernel, n * 8, idx, codes, n);
+    return 0;
+}
+
+int onedc_prior_indexes(const void *params, int params_f32, int16_t *indexes, int B, int H, int W, int C,
+                        int step, void *stream) {
+    if (!params || !indexes || (C & 3) || step < 0 || step > 3) return -1;
+    const int64_t n = (int64_t)B * (C / 4) * H * W;
+    if (params_f32) LAUNCH(prior_indexes_kernel<true>, n, params, indexes, B, H, W, C, step);
+    else LAUNCH(prior_indexes_kernel<false>, n, params, indexes, B, H, W, C, step);
+    return 0;
+}
+
+#define PRIOR_DISPATCH(MODE, yin, sym)                                                                          \
+    do {                                                                                                        \
+        const int64_t n = (int64_t)B * H * W * C;                                                               \
+        if (params_f32 && yhat_f32) LAUNCH((prior_update_kernel<true, true, MODE>), n, params, yin, sym, y_hat, y_cs, B, H, W, C, step); \
+        else if (params_f32) LAUNCH((prior_update_kernel<true, false, MODE>), n, params, yin, sym, y_hat, y_cs, B, H, W, C, step);       \
+        else if (yhat_f32) LAUNCH((prior_update_kernel<false, true, MODE>), n, params, yin, sym, y_hat, y_cs, B, H, W, C, step);        \
+        else LAUNCH((prior_update_kernel<false, false, MODE>), n, params, yin, sym, y_hat, y_cs, B, H, W, C, step);                     \
+    } while (0)
+
+int onedc_prior_update_dec(const void *params, int params_f32, const int16_t *symbols, void *y_hat,
+                           int yhat_f32, int y_cs, int B, int H, int W, int C, int step, void *stream) {
+    if (!params || !symbols || !y_hat || (C & 3) || step < 0 || step > 3) return -1;
+    PRIOR_DISPATCH(0, (const float *)nullptr, (int16_t *)symbols);
+    return 0;
+}
+int onedc_prior_update_enc(const void *params, int params_f32, const float *y, int16_t *symbols, void *y_hat,
+                           int yhat_f32, int y_cs, int B, int H, int W, int C, int step, void *stream) {
+    if (!params || !y || !symbols || !y_hat || (C & 3) || step < 0 || step > 3) return -1;
+    PRIOR_DISPATCH(1, y, symbols);
+    return 0;
+}
+int onedc_prior_update_zonly(const void *params, int params_f32, void *y_hat, int yhat_f32, int y_cs, int B,
+                             int H, int W, int C, int step, void *stream) {
+    if (!params || !y_hat || (C & 3) || step < 0 || step > 3) return -1;
+    PRIOR_DISPATCH(2, (const float *)nullptr, (int16_t *)nullptr);
+    return 0;
+}
+
+int onedc_x0_from_noise(const float *reduced, const float *eps, float *x0, int64_t n, double alpha_bar,
+                        void *stream) {
+    if (!reduced || !eps || !x0 || !(alpha_bar > 0.0 && alpha_bar < 1.0)) return -1;
+    LAUNCH(x0_kernel, n, reduced, eps, x0, n, sqrt(alpha_bar), sqrt(1.0 - alpha_bar));
+    return 0;
+}
+
+int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
+                    int unit_range, void *stream) {
+    if (!x || !out || H > PH || W > PW) return -1;
+    const int64_t n = (int64_t)B * 3 * H * W;
+    if (x_f32) LAUNCH(image_out_kernel<true>, n, x, x_cs, out, B, PH, PW, H, W, unit_range);
+    else LAUNCH(image_out_kernel<false>, n, x, x_cs, out, B, PH, PW, H, W, unit_range);
+    return 0;
+}
+
+int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, int y_f32, int y_cs, int y_co,
+                        int64_t pixels, int C, void *stream) {
+    if (!x || !y) return -1;
+    const int64_t n = pixels * C;
+    if (x_f32 && y_f32) LAUNCH((copy_channels_kernel<true, true>), n, x, x_cs, x_co, y, y_cs, y_co, pixels, C);
+    else if (x_f32) LAUNCH((copy_channels_kernel<true, false>), n, x, x_cs, x_co, y, y_cs, y_co, pixels, C);
+    else if (y_f32) LAUNCH((copy_channels_kernel<false, true>), n, x, x_cs, x_co, y, y_cs, y_co, pixels, C);
+    else LAUNCH((copy_channels_kernel<false, false>), n, x, x_cs, x_co, y, y_cs, y_co, pixels, C);
+    return 0;
+}
+
+int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int win, int reverse,
+                           void *stream) {
+    if (!x || !y || win < 1 || H % win || W % win || (C & 7)) return -1;
+    const int64_t n = (int64_t)B * H * W * (C / 8);
+    LAUNCH(window_partition_kernel, n, (const bf16_t *)x, (bf16_t *)y, B, H, W, C, win, reverse);
+    return 0;
+}
+
+int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *stream) {
+    if (!t || !emb || (dim & 1)) return -1;
+    LAUNCH(timestep_embedding_kernel, (int64_t)n * (dim / 2), t, emb, n, dim);
+    return 0;
+}
+
+int onedc_add(const void *a, const void *b, void *y, int64_t n, void *stream) {
+    if (!a || !b || !y || (n & 7)) return -1;
+    LAUNCH(add_kernel, n / 8, (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)y, n / 8);
+    return 0;
+}
+
+int onedc_dwconv3x3(const void *x, const float *w, const float *bias, void *y, int B, int H, int W, int C,
+                    int x_cs, int x_co, int y_cs, int y_co, void *stream) {
+    if (!x || !w || !y || (C & 7) || (x_cs & 7) || (x_co & 7) || (y_cs & 7) || (y_co & 7)) return -1;
+    const int64_t n = (int64_t)B * H * W * (C / 8);
+    LAUNCH(dwconv3x3_kernel, n, (const bf16_t *)x, w, bias, (bf16_t *)y, B, H, W, C, x_cs, x_co, y_cs, y_co);
+    return 0;
+}
+
+int onedc_direct_conv(const onedc_direct_conv_params *pp, void *stream) {
+    if (!pp || !pp->x || !pp->w || !pp->y || pp->Cin < 1 || pp->Cin > 64 || (pp->K != 1 && pp->K != 3)) return -1;
+    const int64_t n = (int64_t)pp->B * pp->H * pp->W * pp->Cout;
+    if (pp->x_f32) LAUNCH(direct_conv_kernel<true>, n, *pp);
+    else LAUNCH(direct_conv_kernel<false>, n, *pp);
+    return 0;
+}
+
+}  // extern "C"

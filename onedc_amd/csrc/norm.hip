@@ -1,0 +1,273 @@
+// norm.hip — GroupNorm statistics / apply, LayerNorm, row softmax.  All HBM-bound streaming
+// kernels: 16-byte (8 x bf16) accesses per lane, fp32 math, fixed-order reductions (no atomics) so
+// results do not depend on batch size or scheduling.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_GROUPS = 32;
+constexpr int GN_PPC = 1024;  // pixels per partial-sum chunk
+
+__device__ __forceinline__ void unpack8(const uint4 &v, float *f) {
+    f[0] = bf2f((bf16_t)(v.x & 0xffff)); f[1] = bf2f((bf16_t)(v.x >> 16));
+    f[2] = bf2f((bf16_t)(v.y & 0xffff)); f[3] = bf2f((bf16_t)(v.y >> 16));
+    f[4] = bf2f((bf16_t)(v.z & 0xffff)); f[5] = bf2f((bf16_t)(v.z >> 16));
+    f[6] = bf2f((bf16_t)(v.w & 0xffff)); f[7] = bf2f((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float *f) {
+    return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+
+// stage 1: block (chunk, b) sums x and x^2 per group over GN_PPC pixels.
+// threads = CC * PL with CC = C/8 channel chunks and PL pixel lanes.
+__global__ void gn_partial_kernel(const bf16_t *__restrict__ x, float *__restrict__ part, int HW, int C,
+                                  int cs, int co, int CC, int PL, int nchunk) {
+    extern __shared__ float lds[];  // [PL][C][2]
+    const int t = threadIdx.x;
+    const int cc = t % CC, pl = t / CC;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int p0 = chunk * GN_PPC;
+    const int p1 = min(p0 + GN_PPC, HW);
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    const bf16_t *base = x + ((int64_t)b * HW) * cs + co + cc * 8;
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const uint4 v = *(const uint4 *)(base + (int64_t)p * cs);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[e] += f[e];
+            q[e] += f[e] * f[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        lds[(pl * C + cc * 8 + e) * 2 + 0] = s[e];
+        lds[(pl * C + cc * 8 + e) * 2 + 1] = q[e];
+    }
+    __syncthreads();
+    if (t < GN_GROUPS) {
+        const int cpg = C / GN_GROUPS;
+        float ss = 0.f, qq = 0.f;
+        for (int l = 0; l < PL; ++l)
+            for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
+                ss += lds[(l * C + c) * 2 + 0];
+                qq += lds[(l * C + c) * 2 + 1];
+            }
+        float *o = part + (((int64_t)b * nchunk + chunk) * GN_GROUPS + t) * 2;
+        o[0] = ss;
+        o[1] = qq;
+    }
+}
+
+// stage 2: one block per image: reduce chunks (fp64), emit per-channel (scale, shift):
+//   y = x * a + bb with a = rstd*gamma, bb = beta - mean*rstd*gamma
+__global__ void gn_finalize_kernel(const float *__restrict__ part, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float2 *__restrict__ ab, int HW, int C,
+                                   int nchunk, float eps) {
+    __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int cpg = C / GN_GROUPS;
+    if (t < GN_GROUPS) {
+        double ss = 0.0, qq = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const float *o = part + (((int64_t)b * nchunk + k) * GN_GROUPS + t) * 2;
+            ss += (double)o[0];
+            qq += (double)o[1];
+        }
+        const double n = (double)HW * cpg;
+        const double mean = ss / n;
+        double var = qq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[t] = (float)mean;
+        rstd_s[t] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float a = rstd_s[g] * gamma[c];
+        ab[(int64_t)b * C + c] = make_float2(a, beta[c] - mean_s[g] * a);
+    }
+}
+
+// y = act(x * a + bb), 8 channels per lane
+__global__ void scale_shift_act_kernel(const bf16_t *__restrict__ x, const float2 *__restrict__ ab,
+                                       bf16_t *__restrict__ y, int64_t items, int HW, int C, int CC, int x_cs,
+                                       int x_co, int y_cs, int y_co, int silu) {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = it / CC;
+        const int cc = (int)(it - pix * CC);
+        const int b = (int)(pix / HW);
+        const uint4 v = *(const uint4 *)(x + pix * x_cs + x_co + cc * 8);
+        float f[8];
+        unpack8(v, f);
+        const float4 *abp = (const float4 *)(ab + (int64_t)b * C + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float4 t = abp[e];
+            float v0 = f[2 * e] * t.x + t.y, v1 = f[2 * e + 1] * t.z + t.w;
+            if (silu) {
+                v0 = silu_f(v0);
+                v1 = silu_f(v1);
+            }
+            f[2 * e] = v0;
+            f[2 * e + 1] = v1;
+        }
+        *(uint4 *)(y + pix * y_cs + y_co + cc * 8) = pack8(f);
+    }
+}
+
+// LayerNorm: one wave per row, row cached in registers (C <= 8*64*NCH)
+template <int NCH>
+__global__ void layernorm_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma,
+                                 const float *__restrict__ beta, bf16_t *__restrict__ y, int64_t rows, int C,
+                                 float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int CC = C >> 3;
+    float f[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < CC) {
+            unpack8(*(const uint4 *)(x + row * C + cc * 8), f[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[i][e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < CC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = f[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / C + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < CC) {
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o8[e] = (f[i][e] - mean) * rstd * gamma[cc * 8 + e] + beta[cc * 8 + e];
+            *(uint4 *)(y + row * C + cc * 8) = pack8(o8);
+        }
+    }
+}
+
+// softmax over f32 rows (n <= 64*NV), bf16 out with zero padding up to n_pad
+template <int NV>
+__global__ void softmax_rows_kernel(const float *__restrict__ s, bf16_t *__restrict__ p, int64_t rows, int n,
+                                    int n_pad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NV];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < n ? s[row * n + c] : -3.0e38f;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < n ? __expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < n_pad) p[row * n_pad + c] = f2bf(v[i] * inv);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int onedc_gn_chunks(int HW) { return (HW + GN_PPC - 1) / GN_PPC; }
+
+int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *partial, float *ab, int B,
+                   int HW, int C, int x_cs, int x_co, float eps, void *stream) {
+    if (!x || !gamma || !beta || !partial || !ab) return -1;
+    if (C % 32 || C % 8 || (x_cs & 7) || (x_co & 7) || C > 4096) return -2;
+    const int CC = C / 8;
+    const int PL = CC >= 256 ? 1 : 256 / CC;
+    const int threads = CC * PL;
+    if (threads > 1024) return -3;
+    const int nchunk = onedc_gn_chunks(HW);
+    const size_t lds = (size_t)PL * C * 2 * sizeof(float);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(threads), lds, as_stream(stream),
+                       (const bf16_t *)x, partial, HW, C, x_cs, x_co, CC, PL, nchunk);
+    ONEDC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, as_stream(stream), partial, gamma, beta,
+                       (float2 *)ab, HW, C, nchunk, eps);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
+                          int y_cs, int y_co, int silu, void *stream) {
+    if (!x || !ab || !y) return -1;
+    if ((C & 7) || (x_cs & 7) || (x_co & 7) || (y_cs & 7) || (y_co & 7)) return -2;
+    const int CC = C / 8;
+    const int64_t items = (int64_t)B * HW * CC;
+    const int blocks = (int)min((int64_t)8192, (items + 255) / 256);
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       (const bf16_t *)x, (const float2 *)ab, (bf16_t *)y, items, HW, C, CC, x_cs, x_co, y_cs,
+                       y_co, silu);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+int onedc_layernorm(const void *x, const float *gamma, const float *beta, void *y, int64_t rows, int C,
+                    float eps, void *stream) {
+    if (!x || !gamma || !beta || !y || (C & 7) || C > 1536) return -1;
+    const int blocks = (int)((rows + 3) / 4);
+    if (C <= 512)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                           (const bf16_t *)x, gamma, beta, (bf16_t *)y, rows, C, eps);
+    else if (C <= 1024)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                           (const bf16_t *)x, gamma, beta, (bf16_t *)y, rows, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                           (const bf16_t *)x, gamma, beta, (bf16_t *)y, rows, C, eps);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, void *stream) {
+    if (!s || !p || n < 1 || n_pad < n || n_pad > 256) return -1;
+    const int blocks = (int)((rows + 3) / 4);
+    hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
+                       rows, n, n_pad);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

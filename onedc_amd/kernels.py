@@ -1,0 +1,292 @@
+"""ctypes signatures of libonedc_hip.so + thin torch-tensor wrappers.
+
+PyTorch is plumbing here: device memory (`tensor.data_ptr()`), the current HIP stream and
+nothing else.  Every wrapper launches on torch's current stream and raises on a non-zero status.
+There is no CPU or eager fallback: without the built library `_native.hip()` raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native
+
+EPI_LINEAR, EPI_LEAKY, EPI_SILU, EPI_GLU_LEAKY, EPI_GEGLU = range(5)
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("x", _P), ("w", _P), ("bias", _P), ("res", _P), ("y", _P), ("zeros", _P),
+        ("B", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("Cin", C.c_int32),
+        ("x_cs", C.c_int32), ("x_co", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("y_cs", C.c_int32), ("y_co", C.c_int32),
+        ("r_cs", C.c_int32), ("r_co", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32),
+        ("epi", C.c_int32), ("out_f32", C.c_int32), ("pixel_shuffle", C.c_int32),
+        ("alpha", _F), ("slope", _F),
+        ("batch", C.c_int32),
+        ("x_bs", _L), ("w_bs", _L), ("y_bs", _L), ("r_bs", _L),
+    ]
+
+
+class DirectConvParams(C.Structure):
+    _fields_ = [
+        ("x", _P), ("w", _P), ("bias", _P), ("y", _P),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("x_cs", C.c_int32),
+        ("x_co", C.c_int32), ("Cout", C.c_int32), ("y_cs", C.c_int32), ("y_co", C.c_int32), ("K", C.c_int32),
+        ("x_f32", C.c_int32), ("out_f32", C.c_int32), ("epi", C.c_int32),
+        ("slope", _F), ("in_scale", _F),
+    ]
+
+
+SIGNATURES = {
+    "onedc_conv_gemm": (_I, [C.POINTER(ConvParams), _P]),
+    "onedc_direct_conv": (_I, [C.POINTER(DirectConvParams), _P]),
+    "onedc_dwconv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_gn_chunks": (_I, [_I]),
+    "onedc_gn_stats": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_scale_shift_act": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
+    "onedc_softmax_rows": (_I, [_P, _P, _L, _I, _I, _P]),
+    "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_fsq_codes": (_I, [_P, _P, _L, _P]),
+    "onedc_prior_indexes": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "onedc_prior_update_dec": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_prior_update_enc": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_prior_update_zonly": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_x0_from_noise": (_I, [_P, _P, _P, _L, _D, _P]),
+    "onedc_image_out": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_copy_channels": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
+    "onedc_window_partition": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
+    "onedc_add": (_I, [_P, _P, _P, _L, _P]),
+    "onedc_hip_version": (C.c_char_p, []),
+}
+HIP_SYMBOLS = list(SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = _native.hip()
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def _ok(rc, name):
+    if rc != 0:
+        raise KernelError(f"{name} failed with status {rc}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_zeros = {}
+
+
+def zeros_page(device):
+    key = str(device)
+    if key not in _zeros:
+        _zeros[key] = torch.zeros(1024, dtype=torch.uint8, device=device)
+    return _zeros[key]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class View:
+    """A channel slice [co, co+C) of an NHWC buffer with `cs` channels per pixel."""
+    __slots__ = ("t", "B", "H", "W", "C", "cs", "co")
+
+    def __init__(self, t, B, H, W, C, cs=None, co=0):
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+        self.cs = C if cs is None else cs
+        self.co = co
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    @property
+    def f32(self):
+        return self.t.dtype == torch.float32
+
+    def slice(self, co, C):
+        return View(self.t, self.B, self.H, self.W, C, self.cs, self.co + co)
+
+    def torch_nchw(self):
+        """fp32 NCHW copy, for tests."""
+        n = self.B * self.H * self.W * self.cs
+        v = self.t[:n].view(self.B, self.H, self.W, self.cs)[..., self.co:self.co + self.C]
+        return v.permute(0, 3, 1, 2).float().contiguous()
+
+
+SLACK_ROWS = 128   # a GEMM may read (never use) up to one tile of rows past its "weight" operand
+
+
+def new_view(B, H, W, C, device, dtype=torch.bfloat16, cs=None):
+    cs = C if cs is None else cs
+    return View(torch.empty((B * H * W + SLACK_ROWS) * cs, dtype=dtype, device=device), B, H, W, C, cs, 0)
+
+
+def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
+    """torch NCHW tensor -> NHWC View (optionally zero-padded to `pad_to` channels)."""
+    B, Cc, H, W = x.shape
+    Cp = pad_to or Cc
+    cs = cs or Cp
+    t = torch.zeros(B * H * W + SLACK_ROWS, cs, dtype=dtype, device=x.device)
+    t[:B * H * W].view(B, H, W, cs)[..., :Cc] = x.permute(0, 2, 3, 1).to(dtype)
+    return View(t.reshape(-1), B, H, W, Cp, cs, 0)
+
+
+def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
+              pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0):
+    """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None."""
+    p = ConvParams()
+    p.x, p.w, p.bias, p.res, p.y = x.ptr, w.data_ptr(), _ptr(bias), (res.ptr if res is not None else None), y.ptr
+    p.zeros = zeros_page(x.t.device).data_ptr()
+    p.B, p.IH, p.IW = x.B, x.H, x.W
+    p.Cin = Cin if Cin is not None else x.C
+    p.x_cs, p.x_co = x.cs, x.co
+    if pixel_shuffle:
+        p.OH, p.OW = y.H // 2, y.W // 2
+    else:
+        p.OH, p.OW = y.H, y.W
+    glu = epi in (EPI_GLU_LEAKY, EPI_GEGLU)
+    p.Cout = Cout if Cout is not None else (y.C * 2 if glu else (y.C * 4 if pixel_shuffle else y.C))
+    p.y_cs, p.y_co = y.cs, y.co
+    if res is not None:
+        p.r_cs, p.r_co = res.cs, res.co
+    p.KH = p.KW = KH
+    p.stride, p.pad, p.up = stride, KH // 2, up
+    p.epi, p.out_f32, p.pixel_shuffle = epi, int(y.f32), pixel_shuffle
+    p.alpha, p.slope = alpha, slope
+    p.batch, p.x_bs, p.w_bs, p.y_bs, p.r_bs = batch, x_bs, w_bs, y_bs, r_bs
+    _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
+    return y
+
+
+def direct_conv(x, w, bias, y, *, K, epi=EPI_LINEAR, slope=0.01, in_scale=1.0):
+    p = DirectConvParams()
+    p.x, p.w, p.bias, p.y = x.ptr, w.data_ptr(), _ptr(bias), y.ptr
+    p.B, p.H, p.W, p.Cin, p.x_cs, p.x_co = x.B, x.H, x.W, x.C, x.cs, x.co
+    p.Cout, p.y_cs, p.y_co, p.K = y.C, y.cs, y.co, K
+    p.x_f32, p.out_f32, p.epi, p.slope, p.in_scale = int(x.f32), int(y.f32), epi, slope, in_scale
+    _ok(lib().onedc_direct_conv(C.byref(p), stream()), "onedc_direct_conv")
+    return y
+
+
+def dwconv3x3(x, w, bias, y):
+    _ok(lib().onedc_dwconv3x3(x.ptr, w.data_ptr(), _ptr(bias), y.ptr, x.B, x.H, x.W, x.C, x.cs, x.co,
+                              y.cs, y.co, stream()), "onedc_dwconv3x3")
+    return y
+
+
+def gn_chunks(HW):
+    return lib().onedc_gn_chunks(HW)
+
+
+def group_norm(x, gamma, beta, y, eps, silu, ws):
+    """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors."""
+    HW = x.H * x.W
+    need = x.B * gn_chunks(HW) * 64
+    part, ab = ws.f32("gn_partial", need), ws.f32("gn_ab", x.B * x.C * 2)
+    _ok(lib().onedc_gn_stats(x.ptr, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), ab.data_ptr(),
+                             x.B, HW, x.C, x.cs, x.co, eps, stream()), "onedc_gn_stats")
+    _ok(lib().onedc_scale_shift_act(x.ptr, ab.data_ptr(), y.ptr, x.B, HW, x.C, x.cs, x.co, y.cs, y.co,
+                                    int(silu), stream()), "onedc_scale_shift_act")
+    return y
+
+
+def layernorm(x, gamma, beta, y, rows, Cc, eps=1e-5):
+    _ok(lib().onedc_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, Cc, eps,
+                              stream()), "onedc_layernorm")
+    return y
+
+
+def softmax_rows(s, p, rows, n, n_pad):
+    _ok(lib().onedc_softmax_rows(s.data_ptr(), p.data_ptr(), rows, n, n_pad, stream()), "onedc_softmax_rows")
+    return p
+
+
+def flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale):
+    _ok(lib().onedc_flash_attn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, Nq, Nk, Nk_pad,
+                               DQ, DV, scale, stream()), "onedc_flash_attn")
+    return o
+
+
+def fsq_codes(idx, codes):
+    _ok(lib().onedc_fsq_codes(idx.data_ptr(), codes.data_ptr(), idx.numel(), stream()), "onedc_fsq_codes")
+    return codes
+
+
+def prior_indexes(params, indexes, B, H, W, Cc, step):
+    _ok(lib().onedc_prior_indexes(params.ptr, int(params.f32), indexes.data_ptr(), B, H, W, Cc, step,
+                                  stream()), "onedc_prior_indexes")
+    return indexes
+
+
+def prior_update_dec(params, symbols, y_hat, step):
+    _ok(lib().onedc_prior_update_dec(params.ptr, int(params.f32), symbols.data_ptr(), y_hat.ptr, int(y_hat.f32),
+                                     y_hat.cs, y_hat.B, y_hat.H, y_hat.W, y_hat.C, step, stream()),
+        "onedc_prior_update_dec")
+
+
+def prior_update_enc(params, y, symbols, y_hat, step):
+    _ok(lib().onedc_prior_update_enc(params.ptr, int(params.f32), y.data_ptr(), symbols.data_ptr(), y_hat.ptr,
+                                     int(y_hat.f32), y_hat.cs, y_hat.B, y_hat.H, y_hat.W, y_hat.C, step,
+                                     stream()), "onedc_prior_update_enc")
+
+
+def prior_update_zonly(params, y_hat, step):
+    _ok(lib().onedc_prior_update_zonly(params.ptr, int(params.f32), y_hat.ptr, int(y_hat.f32), y_hat.cs,
+                                       y_hat.B, y_hat.H, y_hat.W, y_hat.C, step, stream()),
+        "onedc_prior_update_zonly")
+
+
+def x0_from_noise(reduced, eps, x0, alpha_bar):
+    _ok(lib().onedc_x0_from_noise(reduced.data_ptr(), eps.data_ptr(), x0.data_ptr(), x0.numel(),
+                                  float(alpha_bar), stream()), "onedc_x0_from_noise")
+    return x0
+
+
+def image_out(x, out, H, W, unit_range=False):
+    _ok(lib().onedc_image_out(x.ptr, int(x.f32), x.cs, out.data_ptr(), x.B, x.H, x.W, H, W, int(unit_range),
+                              stream()), "onedc_image_out")
+    return out
+
+
+def copy_channels(x, y):
+    _ok(lib().onedc_copy_channels(x.ptr, int(x.f32), x.cs, x.co, y.ptr, int(y.f32), y.cs, y.co,
+                                  x.B * x.H * x.W, x.C, stream()), "onedc_copy_channels")
+    return y
+
+
+def window_partition(x, y, B, H, W, Cc, win, reverse=False):
+    _ok(lib().onedc_window_partition(x.data_ptr(), y.data_ptr(), B, H, W, Cc, win, int(reverse), stream()),
+        "onedc_window_partition")
+    return y
+
+
+def timestep_embedding(t, emb):
+    _ok(lib().onedc_timestep_embedding(t.data_ptr(), emb.data_ptr(), t.numel(), emb.shape[-1], stream()),
+        "onedc_timestep_embedding")
+    return emb
+
+
+def add(a, b, y):
+    _ok(lib().onedc_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), y.numel(), stream()), "onedc_add")
+    return y

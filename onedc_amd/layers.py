@@ -1,0 +1,286 @@
+"""Device-side building blocks of the decode path, expressed as sequences of HIP kernel launches.
+
+Each class is built from checkpoint-named tensors (`sd`, a flat state dict with LoRA already
+folded) and keeps only packed device weights.  Names follow the reference modules they stand for:
+
+    DepthConvBlock4, ResidualBlockUpsample   reference src/modules/dcvc.py:424-433, 183-208
+    VQResnetBlock, VQAttnBlock               src/modules/vqgan/blocks.py:15-52, 55-106
+    ResnetBlock2D, Transformer2D             diffusers blocks used by decoder_unet.py:204-299 and
+                                             by AutoencoderKL.decode (third-party, restated)
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from . import pack
+from .kernels import EPI_GEGLU, EPI_GLU_LEAKY, EPI_LEAKY, EPI_LINEAR, View, new_view
+
+
+class Workspace:
+    """Named scratch tensors that only ever grow (stable addresses -> graph friendly)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._t = {}
+
+    def _get(self, name, n, dtype):
+        t = self._t.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._t[name] = t
+        return t
+
+    def f32(self, name, n):
+        return self._get(name, n, torch.float32)
+
+    def bf16(self, name, n):
+        return self._get(name, n, torch.bfloat16)
+
+
+class Conv:
+    """nn.Conv2d / nn.Linear as one implicit-GEMM launch."""
+
+    def __init__(self, sd, name, device, *, perm=None, glu=False, shuffle=False, weight=None, bias=None):
+        w = sd[f"{name}.weight"] if weight is None else weight
+        b = sd.get(f"{name}.bias") if bias is None and weight is None else bias
+        self.k = w.shape[2] if w.dim() == 4 else 1
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        m = pack.conv_matrix(w)
+        if glu:
+            perm = pack.glu_perm(self.cout // 2)
+        elif shuffle:
+            perm = pack.shuffle_perm(self.cout)
+        self.w = pack.pack_matrix(m, device, perm)
+        self.b = pack.f32(b, device, perm)
+        self.glu, self.shuffle = glu, shuffle
+
+    def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
+                 alpha=1.0):
+        if y is None:
+            oh, ow = x.H, x.W
+            if stride == 2:
+                oh, ow = (x.H + 1) // 2, (x.W + 1) // 2
+            if up:
+                oh, ow = 2 * x.H, 2 * x.W
+            c = self.cout
+            if self.glu:
+                c //= 2
+            if self.shuffle:
+                c //= 4
+                oh, ow = 2 * oh, 2 * ow
+            y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if out_f32 else torch.bfloat16)
+        return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
+                           alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
+                           Cout=self.cout)
+
+
+class GroupNorm:
+    def __init__(self, sd, name, device, eps):
+        self.g = pack.f32(sd[f"{name}.weight"], device)
+        self.b = pack.f32(sd[f"{name}.bias"], device)
+        self.eps = eps
+
+    def __call__(self, x, ws, silu, y=None):
+        if y is None:
+            y = new_view(x.B, x.H, x.W, x.C, x.t.device)
+        return K.group_norm(x, self.g, self.b, y, self.eps, silu, ws)
+
+
+class DepthConvBlock4:
+    def __init__(self, sd, p, device):
+        self.conv1 = Conv(sd, f"{p}.block.0.conv1.0", device)
+        w = sd[f"{p}.block.0.depth_conv.weight"]                       # (C,1,3,3) -> [9][C]
+        self.dw_w = w[:, 0].permute(1, 2, 0).reshape(9, -1).float().contiguous().to(device)
+        self.dw_b = pack.f32(sd[f"{p}.block.0.depth_conv.bias"], device)
+        self.conv2 = Conv(sd, f"{p}.block.0.conv2", device)
+        self.adaptor = Conv(sd, f"{p}.block.0.adaptor", device) if f"{p}.block.0.adaptor.weight" in sd else None
+        self.ffn_in = Conv(sd, f"{p}.block.1.conv", device, glu=True)
+        self.ffn_out = Conv(sd, f"{p}.block.1.conv_out", device)
+
+    def __call__(self, x, y=None, out_f32=False):
+        identity = self.adaptor(x) if self.adaptor is not None else x
+        t = self.conv1(x, epi=EPI_LEAKY, slope=0.01)
+        t2 = K.dwconv3x3(t, self.dw_w, self.dw_b, new_view(t.B, t.H, t.W, t.C, t.t.device))
+        h = self.conv2(t2, res=identity)
+        u = self.ffn_in(h, epi=EPI_GLU_LEAKY)
+        return self.ffn_out(u, y, res=h, out_f32=out_f32)
+
+
+class ResidualBlockUpsample:
+    def __init__(self, sd, p, device):
+        self.subpel = Conv(sd, f"{p}.subpel_conv.0", device, shuffle=True)
+        self.conv = Conv(sd, f"{p}.conv", device)
+        self.upsample = Conv(sd, f"{p}.upsample.0", device, shuffle=True)
+
+    def __call__(self, x, y=None):
+        t = self.subpel(x, epi=EPI_LEAKY, slope=0.01)
+        identity = self.upsample(x)
+        return self.conv(t, y, epi=EPI_LEAKY, slope=0.1, res=identity)
+
+
+class VQResnetBlock:
+    def __init__(self, sd, p, device):
+        self.n1 = GroupNorm(sd, f"{p}.norm1", device, 1e-6)
+        self.c1 = Conv(sd, f"{p}.conv1", device)
+        self.n2 = GroupNorm(sd, f"{p}.norm2", device, 1e-6)
+        self.c2 = Conv(sd, f"{p}.conv2", device)
+
+    def __call__(self, x, ws, y=None):
+        h = self.c1(self.n1(x, ws, True))
+        return self.c2(self.n2(h, ws, True), y, res=x)
+
+
+class SingleHeadAttention:
+    """softmax(q k^T / sqrt(C)) v over `n` tokens per group, unfused (scores in f32):
+    VQ AttnBlock (1x1-conv projections) and the VAE mid-block Attention (Linear projections)."""
+
+    def __init__(self, sd, names, device, C):
+        qn, kn, vn, on = names
+        self.C = C
+        self.q = Conv(sd, qn, device)
+        self.k = Conv(sd, kn, device)
+        wv = sd[f"{vn}.weight"].reshape(C, C)
+        self.wv = View(pack.pack_matrix(wv, device), 1, 1, C, C)       # V^T = Wv . h^T: Wv is the "pixel" operand
+        # rows of softmax sum to 1, so the v bias rides on the output: P (V + 1 bv^T) = P V + bv
+        self.bv = pack.f32(sd[f"{vn}.bias"], device)
+        self.o = Conv(sd, on, device)
+
+    def __call__(self, hn, res, n, y=None):
+        """hn: normalised tokens View with B groups of n = H*W tokens; res: residual View."""
+        dev, C, G = hn.t.device, self.C, hn.B
+        n_pad = (n + 63) // 64 * 64
+        rows = G * n
+        q = self.q(hn)
+        k = self.k(hn)
+        kbuf = k.t
+        # V^T per group: [C][n_pad], zero padded keys
+        vt = torch.zeros(G * C * n_pad, dtype=torch.bfloat16, device=dev)
+        hn_flat = hn
+        K.conv_gemm(self.wv, hn_flat.t, None, View(vt, 1, 1, C, n, n_pad), Cin=C, Cout=n, batch=G,
+                    x_bs=0, w_bs=n * C, y_bs=C * n_pad)
+        s = torch.empty(rows * n, dtype=torch.float32, device=dev)
+        K.conv_gemm(View(q.t, 1, 1, n, C), kbuf, None, View(s, 1, 1, n, n), Cin=C, Cout=n, batch=G,
+                    x_bs=n * C, w_bs=n * C, y_bs=n * n, alpha=C ** -0.5)
+        p = torch.empty(rows * n_pad, dtype=torch.bfloat16, device=dev)
+        K.softmax_rows(s, p, rows, n, n_pad)
+        a = torch.empty(rows * C, dtype=torch.bfloat16, device=dev)
+        K.conv_gemm(View(p, 1, 1, n, n_pad), vt, self.bv, View(a, 1, 1, n, C), Cin=n_pad, Cout=C, batch=G,
+                    x_bs=n * n_pad, w_bs=C * n_pad, y_bs=n * C)
+        return self.o(View(a, hn.B, hn.H, hn.W, C), y, res=res)
+
+
+class VQAttnBlock:
+    def __init__(self, sd, p, device, C):
+        self.norm = GroupNorm(sd, f"{p}.norm", device, 1e-6)
+        self.attn = SingleHeadAttention(sd, (f"{p}.q", f"{p}.k", f"{p}.v", f"{p}.proj_out"), device, C)
+
+    def __call__(self, x, ws, y=None):
+        return self.attn(self.norm(x, ws, False), x, x.H * x.W, y)
+
+
+class ResnetBlock2D:
+    """diffusers ResnetBlock2D; `temb` (B-independent, timestep is a constant of the codec) is
+    folded into conv1's bias by `set_temb`."""
+
+    def __init__(self, sd, p, device, eps):
+        self.p, self.device = p, device
+        cin = sd[f"{p}.norm1.weight"].shape[0]
+        self.n1 = GroupNorm(sd, f"{p}.norm1", device, eps)
+        self.c1 = Conv(sd, f"{p}.conv1", device)
+        self.n2 = GroupNorm(sd, f"{p}.norm2", device, eps)
+        self.c2 = Conv(sd, f"{p}.conv2", device)
+        self.short = Conv(sd, f"{p}.conv_shortcut", device) if f"{p}.conv_shortcut.weight" in sd else None
+        self.cin = cin
+        self._c1_bias = sd[f"{p}.conv1.bias"].float()
+        if f"{p}.time_emb_proj.weight" in sd:
+            self._tw, self._tb = sd[f"{p}.time_emb_proj.weight"].float(), sd[f"{p}.time_emb_proj.bias"].float()
+        else:
+            self._tw = None
+
+    def set_temb(self, temb_act):
+        """temb_act = SiLU(time_embedding(t)) as a CPU f32 vector [1280]."""
+        if self._tw is not None:
+            self.c1.b = (self._c1_bias + self._tw @ temb_act + self._tb).contiguous().to(self.device)
+
+    def __call__(self, x, ws, y=None):
+        h = self.c1(self.n1(x, ws, True))
+        h = self.n2(h, ws, True)
+        res = self.short(x) if self.short is not None else x
+        return self.c2(h, y, res=res)
+
+
+class MultiHeadAttention:
+    """diffusers Attention (8 heads) on flash attention; projections zero-pad the head dim."""
+
+    def __init__(self, sd, p, device, C, ctx_dim, heads=8):
+        d = C // heads
+        self.H, self.d = heads, d
+        self.DQ, self.DV = pack.HEAD_PAD[d]
+        self.C, self.ctx_dim = C, ctx_dim
+        self.q = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_q.weight"], heads, d, self.DQ))
+        self.k = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_k.weight"], heads, d, self.DQ))
+        wv = pack.pad_heads_rows(sd[f"{p}.to_v.weight"], heads, d, self.DV)
+        self.wv = View(pack.pack_matrix(wv, device), 1, 1, heads * self.DV, ctx_dim)
+        self.o = Conv(sd, "", device, weight=pack.pad_heads_cols(sd[f"{p}.to_out.0.weight"], heads, d, self.DV),
+                      bias=sd[f"{p}.to_out.0.bias"])
+
+    def __call__(self, x, ctx, res, y=None):
+        """x: query tokens View (B, H, W, C); ctx: key/value tokens View; res: residual."""
+        dev = x.t.device
+        B, Nq, Nk = x.B, x.H * x.W, ctx.H * ctx.W
+        Nk_pad = (Nk + 63) // 64 * 64
+        q = self.q(x)
+        k = self.k(ctx)
+        vt = torch.zeros(B * self.H * self.DV * Nk_pad, dtype=torch.bfloat16, device=dev)
+        K.conv_gemm(self.wv, ctx.t, None, View(vt, 1, 1, self.H * self.DV, Nk, Nk_pad), Cin=self.ctx_dim,
+                    Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=self.H * self.DV * Nk_pad)
+        o = new_view(x.B, x.H, x.W, self.H * self.DV, dev)
+        K.flash_attn(q.t, k.t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, self.DQ, self.DV, self.d ** -0.5)
+        return self.o(o, y, res=res)
+
+
+class LayerNorm:
+    def __init__(self, sd, name, device):
+        self.g = pack.f32(sd[f"{name}.weight"], device)
+        self.b = pack.f32(sd[f"{name}.bias"], device)
+
+    def __call__(self, x):
+        y = new_view(x.B, x.H, x.W, x.C, x.t.device)
+        K.layernorm(x.t, self.g, self.b, y.t, x.B * x.H * x.W, x.C)
+        return y
+
+
+class Transformer2D:
+    """diffusers Transformer2DModel (conv projections) with one BasicTransformerBlock (GEGLU FF)."""
+
+    def __init__(self, sd, p, device, C, ctx_dim=768):
+        t = f"{p}.transformer_blocks.0"
+        self.norm = GroupNorm(sd, f"{p}.norm", device, 1e-6)
+        self.proj_in = Conv(sd, f"{p}.proj_in", device)
+        self.n1, self.n2, self.n3 = (LayerNorm(sd, f"{t}.norm{i}", device) for i in (1, 2, 3))
+        self.attn1 = MultiHeadAttention(sd, f"{t}.attn1", device, C, C)
+        self.attn2 = MultiHeadAttention(sd, f"{t}.attn2", device, C, ctx_dim)
+        self.ff1 = Conv(sd, f"{t}.ff.net.0.proj", device, glu=True)
+        self.ff2 = Conv(sd, f"{t}.ff.net.2", device)
+        self.proj_out = Conv(sd, f"{p}.proj_out", device)
+
+    def __call__(self, x, ctx, ws, y=None):
+        h = self.proj_in(self.norm(x, ws, False))
+        n = self.n1(h)
+        h = self.attn1(n, n, h)
+        h = self.attn2(self.n2(h), ctx, h)
+        f = self.ff1(self.n3(h), epi=EPI_GEGLU)
+        h = self.ff2(f, res=h)
+        return self.proj_out(h, y, res=x)
+
+
+def silu_cpu(v):
+    return v * torch.sigmoid(v)
+
+
+def timestep_embedding_cpu(t, dim=320):
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half
+    emb = torch.tensor([float(t)], dtype=torch.float32)[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)[0]

@@ -1,0 +1,162 @@
+"""SD15_1step_codec_stage1 — drop-in decoder with the reference's model surface.
+
+Mirrors reference src/models/sd15_onedc_codec_stage1/model_sd15_with_codec_stage1.py:
+`decode(fp=None, stream=None)` :295-330, `vae_decode_image` :184-188, the DDIM alphas_cumprod of
+:103-106 and the epsilon -> x0 step :320-322, plus `eval()` / `prepare()` and the
+`codec_model.update(force=True)` call sequence of src/inference.py:69-74.  Differences, all
+additive: `decode` also accepts lists (a batch of bitstreams of one padded size), and the SD-2.1
+VAE weights come from a local file or state dict because the reference downloads them from the
+HF hub (:43-45) which does not exist offline.
+"""
+import os
+from types import SimpleNamespace
+
+import torch
+
+from . import kernels as K
+from . import synth
+from .codec_module import IntraNoAR
+from .decoder_unet import UNet
+from .kernels import View, new_view
+from .vae import VAEDecoder
+
+
+def load_safetensor(path, map_location="cpu"):
+    """reference src/utils.py:25-33"""
+    if path.endswith("safetensors"):
+        from safetensors import safe_open
+        tensors = {}
+        with safe_open(path, framework="pt", device=map_location) as f:
+            for k in f.keys():
+                tensors[k] = f.get_tensor(k)
+        return tensors
+    return torch.load(path, map_location=map_location)
+
+
+def ddim_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+    """DDIMScheduler('scaled_linear') of runwayml/stable-diffusion-v1-5 (:103-106)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def _get(args, name, default=None):
+    if isinstance(args, dict):
+        return args.get(name, default)
+    return getattr(args, name, default)
+
+
+class SD15_1step_codec_stage1:
+    def __init__(self, args, accelerator=None, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("onedc_amd needs a ROCm device: the decode path has no CPU implementation")
+        if device is None:
+            device = getattr(accelerator, "device", None) or torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.args = args
+        self.accelerator = accelerator
+        self.use_fp16 = _get(args, "use_fp16", True)
+        self.vae_attn_patch = _get(args, "vae_attn_patch", 16)
+        self.lora_config = _get(args, "lora_config", {"lora_rank": 64, "lora_alpha": 8.0})
+        self.conditioning_timestep = _get(args, "conditioning_timestep", 999)
+        self.num_train_timesteps = _get(args, "num_train_timesteps", 1000)
+        self.alphas_cumprod = ddim_alphas_cumprod(self.num_train_timesteps)
+        self.feedforward_model = None
+        self.codec_model = None
+        self.vae_large = None
+
+    # -- weights -------------------------------------------------------------------------------
+    def load_state_dicts(self, feedforward_sd, codec_sd, vae_sd):
+        lc = self.lora_config or {}
+        rank = _get(lc, "lora_rank", 64)
+        alpha = _get(lc, "lora_alpha", 8.0)
+        with torch.cuda.device(self.device):
+            self.feedforward_model = UNet(feedforward_sd, self.device, rank, alpha)
+            self.codec_model = IntraNoAR(codec_sd, self.device)
+            self.vae_large = VAEDecoder(vae_sd, self.device, self.vae_attn_patch)
+        return self
+
+    def load(self, checkpoint_path, vae_path=None):
+        """inference.py:87-93 + the VAE file the reference fetches from the hub."""
+        ff = load_safetensor(os.path.join(checkpoint_path, "model.safetensors"))
+        codec = load_safetensor(os.path.join(checkpoint_path, "model_1.safetensors"))
+        vae_path = vae_path or os.path.join(checkpoint_path, "vae", "diffusion_pytorch_model.safetensors")
+        vae = load_safetensor(vae_path)
+        check_state_dicts(ff, codec, vae)
+        return self.load_state_dicts(ff, codec, vae)
+
+    def load_synthetic(self, seed=0):
+        """Deterministic random-init weights of the real architecture (no checkpoints offline)."""
+        return self.load_state_dicts(synth.unet_state_dict(seed), synth.codec_state_dict(seed),
+                                     synth.vae_state_dict(seed))
+
+    def prepare(self):
+        return self
+
+    def eval(self):
+        return self
+
+    # -- decode ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_latents(self, h_detail_hat, y_semantic):
+        """model...stage1.py:303-324 after the codec: UNet step, x0, VAE decode. Returns dict of Views."""
+        ctx = y_semantic                                            # 'b c h w -> b (h w) c' is the NHWC layout itself
+        eps, reduced = self.feedforward_model(h_detail_hat, self.conditioning_timestep, ctx)
+        x0 = new_view(eps.B, eps.H, eps.W, 4, self.device, torch.float32)
+        n = eps.B * eps.H * eps.W * 4
+        K.x0_from_noise(reduced.t[:n], eps.t[:n], x0.t[:n], float(self.alphas_cumprod[self.conditioning_timestep].double()))
+        image = self.vae_large.decode(x0)
+        return {"eps": eps, "reduced": reduced, "x0": x0, "image": image}
+
+    @torch.no_grad()
+    def decode(self, fp=None, stream=None, unit_range=False):
+        """-> f32 tensor [B,3,H,W] (B = 1 for a single path/bytes, as in the reference)."""
+        assert fp or stream
+        with torch.cuda.device(self.device):
+            h_detail_hat, y_semantic, orig_hw, pad_hw, pad_size = self.codec_model.decode(fp=fp, stream=stream)
+            out = self.decode_latents(h_detail_hat, y_semantic)
+            image = out["image"]
+            H, W = orig_hw[0]
+            if any(hw != (H, W) for hw in orig_hw):
+                H, W = pad_hw                                        # mixed crops: return the padded frame
+            res = torch.empty(image.B, 3, H, W, dtype=torch.float32, device=self.device)
+            K.image_out(image, res, H, W, unit_range)
+        return res
+
+    @torch.no_grad()
+    def decode_z_only(self, indices):
+        """sd15_onedc_codec_z_only forward path from FSQ indices alone
+        (models/sd15_onedc_codec_z_only/model_sd15_with_codec_stage1.py:198-218)."""
+        with torch.cuda.device(self.device):
+            y_hat, z_semantic = self.codec_model.recon_with_z(indices.to(self.device, torch.int32))
+            h_detail_hat, y_semantic = self.codec_model.synthesis(y_hat, z_semantic)
+            out = self.decode_latents(h_detail_hat, y_semantic)
+            image = out["image"]
+            res = torch.empty(image.B, 3, image.H, image.W, dtype=torch.float32, device=self.device)
+            K.image_out(image, res, image.H, image.W, False)
+        return res
+
+
+def check_state_dicts(ff, codec, vae):
+    """The strict-load contract of inference.py:87-93, against arch.py's key/shape tables."""
+    from . import arch
+    problems = []
+    for name, sd, spec, ignore in (("model.safetensors", ff, arch.unet_spec(True), ()),
+                                   ("model_1.safetensors", codec, arch.codec_decode_spec(), arch.CODEC_IGNORED_PREFIXES),
+                                   ("vae", vae, arch.vae_decoder_spec(), ("encoder.", "quant_conv."))):
+        for k, shape in spec.items():
+            alt = None
+            if name == "vae":
+                for old, new in arch.VAE_LEGACY_ATTN.items():
+                    if f".{new}." in k:
+                        alt = k.replace(f".{new}.", f".{old}.")
+            t = sd.get(k, sd.get(alt) if alt else None)
+            if t is None:
+                problems.append(f"{name}: missing {k}")
+            elif tuple(t.shape) != tuple(shape) and t.numel() != int(torch.tensor(shape).prod()):
+                problems.append(f"{name}: {k} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+        known = set(spec)
+        for k in sd:
+            if k not in known and not k.startswith(ignore) and name != "vae":
+                problems.append(f"{name}: unexpected {k}")
+    if problems:
+        raise RuntimeError("Error(s) in loading state_dict:\n  " + "\n  ".join(problems[:20]))

@@ -1,0 +1,95 @@
+"""Host-side weight preparation: checkpoint tensors -> the layouts the HIP kernels read.
+
+* conv / linear weights -> bf16 [rows padded to 128][KH*KW*Cin], k-contiguous with k = (ky, kx, cin)
+* GLU layers (ConvFFN3, GEGLU): rows interleaved in blocks of 16 (value block, gate block)
+* sub-pixel convs: rows ordered (dy*2+dx)*C' + c so the pixel-shuffle store is channel-contiguous
+* attention projections: heads zero-padded from d to DQ / DV (40->64/48, 80->96/80, 160->160)
+* peft LoRA: W += (alpha/r) * B @ A   (reference decoder_unet.py:360-367; config_inference.yaml:19-22)
+"""
+import torch
+
+ROW_PAD = 128
+
+
+def fold_lora(sd, rank=64, alpha=8.0):
+    out = {}
+    scale = alpha / rank
+    for k, v in sd.items():
+        if ".lora_A." in k or ".lora_B." in k:
+            continue
+        if ".base_layer." in k:
+            name, leaf = k.split(".base_layer.")
+            if leaf == "weight":
+                A = sd[f"{name}.lora_A.default.weight"].double()
+                B = sd[f"{name}.lora_B.default.weight"].double()
+                delta = (B.reshape(B.shape[0], -1) @ A.reshape(A.shape[0], -1)).reshape(v.shape)
+                v = (v.double() + scale * delta).float()
+            out[f"{name}.{leaf}"] = v
+        else:
+            out[k] = v
+    return out
+
+
+def _pad_rows(m):
+    rows = m.shape[0]
+    pad = (-rows) % ROW_PAD
+    if pad:
+        m = torch.cat([m, m.new_zeros(pad, m.shape[1])], dim=0)
+    return m
+
+
+def pack_matrix(w2d, device, row_perm=None):
+    """[rows][K] f32 -> padded bf16 on `device`."""
+    if row_perm is not None:
+        w2d = w2d[row_perm]
+    return _pad_rows(w2d.contiguous()).to(torch.bfloat16).to(device).contiguous()
+
+
+def conv_matrix(w):
+    """(Cout, Cin, KH, KW) or (Cout, Cin) -> [Cout][KH*KW*Cin] with k = (ky, kx, cin)."""
+    if w.dim() == 2:
+        return w
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def glu_perm(n_half):
+    """Row order for GLU epilogues: [v0..v15, g0..g15, v16..v31, g16..g31, ...]."""
+    assert n_half % 16 == 0
+    idx = []
+    for t in range(n_half // 16):
+        idx += list(range(16 * t, 16 * t + 16)) + list(range(n_half + 16 * t, n_half + 16 * t + 16))
+    return torch.tensor(idx, dtype=torch.long)
+
+
+def shuffle_perm(c_out):
+    """Row order for a conv followed by PixelShuffle(2): new row s*C' + c <- old row c*4 + s."""
+    assert c_out % 4 == 0
+    cq = c_out // 4
+    return torch.tensor([c * 4 + s for s in range(4) for c in range(cq)], dtype=torch.long)
+
+
+def pad_heads_rows(w, heads, d, d_pad):
+    """(heads*d, K) -> (heads*d_pad, K) with zero rows after each head."""
+    K = w.shape[1]
+    out = w.new_zeros(heads, d_pad, K)
+    out[:, :d] = w.view(heads, d, K)
+    return out.reshape(heads * d_pad, K)
+
+
+def pad_heads_cols(w, heads, d, d_pad):
+    """(N, heads*d) -> (N, heads*d_pad) with zero columns after each head."""
+    N = w.shape[0]
+    out = w.new_zeros(N, heads, d_pad)
+    out[:, :, :d] = w.view(N, heads, d)
+    return out.reshape(N, heads * d_pad)
+
+
+def f32(t, device, perm=None):
+    if t is None:
+        return None
+    if perm is not None:
+        t = t[perm]
+    return t.float().contiguous().to(device)
+
+
+HEAD_PAD = {40: (64, 48), 80: (96, 80), 160: (160, 160)}   # head dim -> (DQ, DV)

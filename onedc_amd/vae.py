@@ -1,0 +1,80 @@
+"""SD-2.1 VAE decoder with windowed mid-block attention, on HIP kernels.
+
+Mirrors reference `vae_decode_image` (src/models/sd15_onedc_codec_stage1/
+model_sd15_with_codec_stage1.py:184-188) -> diffusers `AutoencoderKL.decode` as patched by
+src/modules/vae/autoencoders_patch_attn.py:9-80 (attention, including its GroupNorm, runs per
+`attn_patch` x `attn_patch` window; here all windows of the batch go through one set of batched
+launches instead of a Python double loop).  The decoder body is third-party and restated.
+"""
+import torch
+
+from . import arch
+from . import kernels as K
+from .kernels import View, new_view
+from .layers import Conv, GroupNorm, ResnetBlock2D, SingleHeadAttention, Workspace
+
+
+class VAEDecoder:
+    def __init__(self, sd, device, attn_patch=16, scaling_factor=0.18215):
+        sd = dict(sd)
+        a = "decoder.mid_block.attentions.0"
+        for old, new in arch.VAE_LEGACY_ATTN.items():      # pre-0.15 diffusers attention names
+            for leaf in ("weight", "bias"):
+                if f"{a}.{old}.{leaf}" in sd:
+                    sd[f"{a}.{new}.{leaf}"] = sd.pop(f"{a}.{old}.{leaf}").reshape(512, -1).squeeze(-1)
+        self.device = device
+        self.attn_patch = attn_patch
+        self.scaling_factor = scaling_factor
+        self.ws = Workspace(device)
+        # post_quant_conv (1x1, 4->4) and conv_in (3x3, 4->512): tiny-channel direct kernels in f32
+        self.pq_w = sd["post_quant_conv.weight"].permute(0, 2, 3, 1).reshape(4, -1).float().contiguous().to(device)
+        self.pq_b = sd["post_quant_conv.bias"].float().contiguous().to(device)
+        self.ci_w = sd["decoder.conv_in.weight"].permute(0, 2, 3, 1).reshape(512, -1).float().contiguous().to(device)
+        self.ci_b = sd["decoder.conv_in.bias"].float().contiguous().to(device)
+        self.mid_res = [ResnetBlock2D(sd, f"decoder.mid_block.resnets.{j}", device, 1e-6) for j in range(2)]
+        self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6)
+        self.attn = SingleHeadAttention(sd, (f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{a}.to_out.0"), device, 512)
+        self.up = []
+        for i, (cin, cout) in enumerate(arch.VAE_UP):
+            blk = {"res": [ResnetBlock2D(sd, f"decoder.up_blocks.{i}.resnets.{j}", device, 1e-6) for j in range(3)]}
+            blk["up"] = Conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", device) if i < 3 else None
+            self.up.append(blk)
+        self.norm_out = GroupNorm(sd, "decoder.conv_norm_out", device, 1e-6)
+        self.conv_out = Conv(sd, "decoder.conv_out", device)
+
+    def set_attn_patch(self, attn_patch):
+        assert attn_patch > 0, "attn_patch must be greater than 0"
+        self.attn_patch = attn_patch
+
+    def _windowed_attention(self, x):
+        B, H, W, C = x.B, x.H, x.W, x.C
+        win = min(self.attn_patch, H, W)
+        if H % win or W % win:
+            raise ValueError("latent size must be a multiple of the attention window")
+        nwin = (H // win) * (W // win)
+        xw = new_view(B * nwin, win, win, C, self.device)
+        K.window_partition(x.t, xw.t, B, H, W, C, win)
+        hn = self.attn_norm(xw, self.ws, False)                       # statistics per window
+        ow = self.attn(hn, xw, win * win)
+        out = new_view(B, H, W, C, self.device)
+        K.window_partition(ow.t, out.t, B, H, W, C, win, reverse=True)
+        return out
+
+    @torch.no_grad()
+    def decode(self, latents):
+        """latents: f32 View (B,h,w,4) -> f32 View (B,8h,8w,3) picture in [-1,1] (unclamped)."""
+        ws, dev = self.ws, self.device
+        z = new_view(latents.B, latents.H, latents.W, 4, dev, torch.float32)
+        K.direct_conv(latents, self.pq_w, self.pq_b, z, K=1, in_scale=1.0 / self.scaling_factor)
+        h = new_view(latents.B, latents.H, latents.W, 512, dev)
+        K.direct_conv(z, self.ci_w, self.ci_b, h, K=3)
+        h = self.mid_res[0](h, ws)
+        h = self._windowed_attention(h)
+        h = self.mid_res[1](h, ws)
+        for blk in self.up:
+            for r in blk["res"]:
+                h = r(h, ws)
+            if blk["up"] is not None:
+                h = blk["up"](h, up=1)
+        h = self.norm_out(h, ws, True)
+        return self.conv_out(h, out_f32=True)

@@ -1,0 +1,58 @@
+"""The two C-ABI libraries load on a CPU-only box and export every symbol their headers declare
+(no compute calls here: those need a GPU and live in the -m gpu tests)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from onedc_amd import _native, build, kernels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(onedc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_coder_library_exports_header_symbols():
+    build.build_coder()
+    lib = ctypes.CDLL(_native.CODER_SO)
+    names = declared("onedc_coder.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in onedc_coder.h but not exported"
+    assert set(names) == set(_native.CODER_SYMBOLS)
+    assert _native.coder().onedc_coder_version().startswith(b"onedc-coder")
+
+
+def test_hip_library_exports_header_symbols():
+    """hipcc cross-compiles for gfx950 without a GPU; dlopen works because the HIP runtime
+    initialises lazily."""
+    build.build_hip()
+    lib = ctypes.CDLL(_native.HIP_SO)
+    names = declared("onedc_hip.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in onedc_hip.h but not exported"
+    assert set(names) == set(kernels.HIP_SYMBOLS)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_native, "_hip", None)
+    monkeypatch.setattr(_native, "HIP_SO", "/nonexistent/libonedc_hip.so")
+    with pytest.raises(_native.NativeLibraryError):
+        _native.hip()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "onedc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(f)
+    assert not bad, f"product modules import the oracle: {bad}"

@@ -1,0 +1,265 @@
+"""Kernel-level numerics on a real MI355X: every HIP kernel (called through the C ABI) against a
+plain PyTorch fp32 reference of the same op.  Inputs and weights are rounded to bf16 first, so the
+only differences left are accumulation order (fp32 MFMA) and the final bf16 store.
+
+Tolerances (written here, checked by `close`): relative RMS error <= 4e-3 (bf16 has 8 significant
+bits: a rounded output carries ~2e-3 relative error) and max abs error <= 2.5e-2 * max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from onedc_amd import kernels as K
+from onedc_amd import pack
+from onedc_amd.kernels import View, from_nchw, new_view
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+
+
+def close(got, ref, rms=4e-3, mx=2.5e-2, what=""):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = got - ref
+    scale = ref.abs().max().clamp_min(1e-6)
+    rel_rms = float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-9))
+    rel_max = float(err.abs().max() / scale)
+    assert rel_rms <= rms and rel_max <= mx, f"{what}: rel_rms={rel_rms:.2e} rel_max={rel_max:.2e}"
+
+
+def packed(w, perm=None):
+    return pack.pack_matrix(pack.conv_matrix(w), DEV, perm)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (2, 16, 16, 128, 128, 3),     # VAE-style 3x3, 128x128 tile
+    (1, 24, 20, 64, 320, 3),      # Cout=320 -> 64-wide channel tile, ragged M
+    (2, 12, 12, 256, 256, 1),     # 1x1
+    (1, 9, 7, 192, 128, 3),       # odd spatial size: halo + tail rows
+    (3, 8, 8, 1280, 640, 1),      # long K
+])
+def test_conv_gemm_plain(B, H, W, Cin, Cout, k):
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5), rnd(Cout, seed=3)
+    y = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=k)
+    close(y.torch_nchw(), F.conv2d(x, w, b, padding=k // 2), what="conv")
+
+
+def test_conv_gemm_stride2_and_upsample():
+    x, w, b = rnd(2, 128, 16, 12, seed=4), rnd(192, 128, 3, 3, seed=5, scale=1 / 34), rnd(192, seed=6)
+    xv = from_nchw(x.to(DEV))
+    y = new_view(2, 8, 6, 192, DEV)
+    K.conv_gemm(xv, packed(w), b.to(DEV), y, KH=3, stride=2)
+    close(y.torch_nchw(), F.conv2d(x, w, b, stride=2, padding=1), what="stride2")
+    y = new_view(2, 32, 24, 192, DEV)
+    K.conv_gemm(xv, packed(w), b.to(DEV), y, KH=3, up=1)
+    close(y.torch_nchw(), F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1), what="up")
+
+
+def test_conv_gemm_epilogues_residual_slices():
+    B, H, W, Cin, Cout = 2, 10, 10, 128, 128
+    x, w, b = rnd(B, Cin, H, W, seed=7), rnd(Cout, Cin, 1, 1, seed=8, scale=Cin ** -0.5), rnd(Cout, seed=9)
+    r = rnd(B, Cout, H, W, seed=10)
+    # input read from a channel slice, output + residual in slices of wider buffers
+    xbuf = from_nchw(torch.cat([rnd(B, 64, H, W, seed=11), x], 1).to(DEV))
+    rbuf = from_nchw(torch.cat([r, rnd(B, 8, H, W, seed=12)], 1).to(DEV))
+    ybuf = new_view(B, H, W, Cout + 64, DEV)
+    ybuf.t.zero_()
+    K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), ybuf.slice(64, Cout), KH=1, epi=K.EPI_LEAKY,
+                slope=0.1, res=rbuf.slice(0, Cout))
+    close(ybuf.slice(64, Cout).torch_nchw(), F.leaky_relu(F.conv2d(x, w, b), 0.1) + r, what="leaky+res")
+    assert float(ybuf.slice(0, 64).torch_nchw().abs().max()) == 0.0       # neighbours untouched
+    y = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=1, epi=K.EPI_SILU, alpha=0.5)
+    close(y.torch_nchw(), F.silu(0.5 * F.conv2d(x, w) + b.view(1, -1, 1, 1)), what="silu/alpha")
+
+
+@pytest.mark.parametrize("epi", ["glu_leaky", "geglu"])
+def test_conv_gemm_glu(epi):
+    B, H, W, Cin, Ch = 1, 12, 12, 128, 256
+    x, w, b = rnd(B, Cin, H, W, seed=13), rnd(2 * Ch, Cin, 1, 1, seed=14, scale=Cin ** -0.5), rnd(2 * Ch, seed=15)
+    perm = pack.glu_perm(Ch)
+    y = new_view(B, H, W, Ch, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w, perm), b[perm].to(DEV), y, KH=1,
+                epi=K.EPI_GLU_LEAKY if epi == "glu_leaky" else K.EPI_GEGLU)
+    a, g = F.conv2d(x, w, b).chunk(2, 1)
+    ref = F.leaky_relu(a, 0.1) + F.leaky_relu(g, 0.01) if epi == "glu_leaky" else a * F.gelu(g)
+    close(y.torch_nchw(), ref, what=epi)
+
+
+def test_conv_gemm_pixel_shuffle():
+    B, H, W, Cin, Cq = 2, 6, 5, 128, 64
+    x, w, b = rnd(B, Cin, H, W, seed=16), rnd(4 * Cq, Cin, 1, 1, seed=17, scale=Cin ** -0.5), rnd(4 * Cq, seed=18)
+    perm = pack.shuffle_perm(4 * Cq)
+    y = new_view(B, 2 * H, 2 * W, Cq, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w, perm), b[perm].to(DEV), y, KH=1, pixel_shuffle=1)
+    close(y.torch_nchw(), F.pixel_shuffle(F.conv2d(x, w, b), 2), what="pixel_shuffle")
+
+
+@pytest.mark.parametrize("Cout", [3, 4])
+def test_conv_gemm_tiny_cout_f32(Cout):
+    """conv_out of the VAE (128->3) and the UNet (320->4): 16-channel tile, f32 output."""
+    B, H, W, Cin = 1, 20, 24, 128
+    x, w, b = rnd(B, Cin, H, W, seed=19), rnd(Cout, Cin, 3, 3, seed=20, scale=1 / 34), rnd(Cout, seed=21)
+    y = new_view(B, H, W, Cout, DEV, torch.float32)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=3)
+    close(y.torch_nchw(), F.conv2d(x, w, b, padding=1), rms=1e-4, mx=1e-4, what="tiny cout f32")
+
+
+def test_conv_gemm_batched_nt():
+    """Batched activation x activation product (QK^T of the single-head attention)."""
+    G, n, Cc = 5, 144, 128
+    q, k = rnd(G, n, Cc, seed=22), rnd(G, n, Cc, seed=23)
+    qd = torch.zeros(G * n + 128, Cc, dtype=torch.bfloat16, device=DEV)
+    kd = torch.zeros(G * n + 128, Cc, dtype=torch.bfloat16, device=DEV)
+    qd[:G * n] = q.view(-1, Cc).to(DEV)
+    kd[:G * n] = k.view(-1, Cc).to(DEV)
+    s = torch.empty(G * n * n, dtype=torch.float32, device=DEV)
+    K.conv_gemm(View(qd, 1, 1, n, Cc), kd, None, View(s, 1, 1, n, n), Cin=Cc, Cout=n, batch=G, x_bs=n * Cc,
+                w_bs=n * Cc, y_bs=n * n, alpha=0.25)
+    close(s.view(G, n, n), 0.25 * q @ k.transpose(1, 2), rms=1e-4, mx=1e-4, what="batched nt")
+
+
+def test_conv_gemm_batch_invariant():
+    """Same image alone or inside a batch -> bit-identical output (determinism requirement)."""
+    x, w = rnd(4, 128, 12, 12, seed=24), rnd(256, 128, 3, 3, seed=25, scale=1 / 34)
+    pw = packed(w)
+    y4 = new_view(4, 12, 12, 256, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), pw, None, y4, KH=3)
+    y1 = new_view(1, 12, 12, 256, DEV)
+    K.conv_gemm(from_nchw(x[2:3].to(DEV)), pw, None, y1, KH=3)
+    assert torch.equal(y4.torch_nchw()[2:3], y1.torch_nchw())
+
+
+def test_conv_gemm_rejects_bad_arguments():
+    y = new_view(1, 4, 4, 128, DEV)
+    with pytest.raises(K.KernelError):
+        K.conv_gemm(new_view(1, 4, 4, 100, DEV), torch.zeros(128, 100, dtype=torch.bfloat16, device=DEV), None, y)
+
+
+class _WS:
+    def __init__(self):
+        self.t = {}
+
+    def f32(self, name, n):
+        if name not in self.t or self.t[name].numel() < n:
+            self.t[name] = torch.empty(n, dtype=torch.float32, device=DEV)
+        return self.t[name]
+
+
+@pytest.mark.parametrize("B,C,H,W,silu", [(2, 128, 40, 36, True), (1, 320, 9, 9, False), (2, 1920, 6, 6, True),
+                                          (1, 2560, 4, 4, True), (3, 512, 16, 16, False)])
+def test_group_norm(B, C, H, W, silu):
+    x, g, b = rnd(B, C, H, W, seed=26) * 2 + 0.5, rnd(C, seed=27), rnd(C, seed=28)
+    x = x.to(torch.bfloat16).float()
+    y = new_view(B, H, W, C, DEV)
+    K.group_norm(from_nchw(x.to(DEV)), g.to(DEV), b.to(DEV), y, 1e-6, silu, _WS())
+    ref = F.group_norm(x, 32, g, b, 1e-6)
+    close(y.torch_nchw(), F.silu(ref) if silu else ref, what="group_norm")
+
+
+def test_group_norm_large_map_many_chunks():
+    x, g, b = rnd(1, 128, 96, 128, seed=29), rnd(128, seed=30), rnd(128, seed=31)
+    y = new_view(1, 96, 128, 128, DEV)
+    K.group_norm(from_nchw(x.to(DEV)), g.to(DEV), b.to(DEV), y, 1e-5, True, _WS())
+    close(y.torch_nchw(), F.silu(F.group_norm(x, 32, g, b, 1e-5)), what="group_norm chunks")
+
+
+@pytest.mark.parametrize("C", [320, 640, 1280])
+def test_layernorm(C):
+    x, g, b = rnd(300, C, seed=32) * 3, rnd(C, seed=33), rnd(C, seed=34)
+    y = torch.empty(300, C, dtype=torch.bfloat16, device=DEV)
+    K.layernorm(x.to(torch.bfloat16).to(DEV), g.to(DEV), b.to(DEV), y, 300, C)
+    close(y.float(), F.layer_norm(x, (C,), g, b, 1e-5), what="layernorm")
+
+
+@pytest.mark.parametrize("n,n_pad", [(144, 192), (256, 256), (16, 64)])
+def test_softmax_rows(n, n_pad):
+    s = torch.randn(77, n, generator=torch.Generator().manual_seed(35)) * 4
+    p = torch.empty(77, n_pad, dtype=torch.bfloat16, device=DEV)
+    K.softmax_rows(s.to(DEV), p, 77, n, n_pad)
+    close(p[:, :n].float(), torch.softmax(s, -1), what="softmax")
+    assert float(p[:, n:].float().abs().max() if n_pad > n else 0.0) == 0.0
+
+
+def test_dwconv3x3():
+    B, C, H, W = 2, 256, 11, 13
+    x, w, b = rnd(B, C, H, W, seed=36), torch.randn(C, 1, 3, 3, generator=torch.Generator().manual_seed(37)), rnd(C, seed=38)
+    y = new_view(B, H, W, C, DEV)
+    K.dwconv3x3(from_nchw(x.to(DEV)), w[:, 0].permute(1, 2, 0).reshape(9, C).contiguous().to(DEV), b.to(DEV), y)
+    close(y.torch_nchw(), F.conv2d(x, w, b, padding=1, groups=C), what="dwconv")
+
+
+def test_direct_conv_small_cin():
+    x = torch.randn(2, 4, 12, 12, generator=torch.Generator().manual_seed(39))
+    w, b = torch.randn(512, 4, 3, 3, generator=torch.Generator().manual_seed(40)) * 0.2, rnd(512, seed=41)
+    xv = View(x.permute(0, 2, 3, 1).contiguous().to(DEV).reshape(-1), 2, 12, 12, 4)
+    y = new_view(2, 12, 12, 512, DEV)
+    K.direct_conv(xv, w.permute(0, 2, 3, 1).reshape(512, -1).contiguous().to(DEV), b.to(DEV), y, K=3, in_scale=1 / 0.18215)
+    close(y.torch_nchw(), F.conv2d(x / 0.18215, w, b, padding=1), what="direct conv")
+
+
+@pytest.mark.parametrize("d,Nq,Nk", [(40, 300, 300), (40, 200, 144), (80, 576, 576), (160, 144, 144), (160, 130, 77)])
+def test_flash_attention(d, Nq, Nk):
+    B, Hh = 2, 8
+    DQ, DV = pack.HEAD_PAD[d]
+    g = torch.Generator().manual_seed(42)
+    q, k, v = (torch.randn(B, Hh, n, d, generator=g).to(torch.bfloat16).float() for n in (Nq, Nk, Nk))
+    Nk_pad = (Nk + 63) // 64 * 64
+
+    def padded(t, dp):                      # (B,H,N,d) -> (B,N,H*dp) bf16 with zero padding
+        out = torch.zeros(B, t.shape[2], Hh, dp)
+        out[..., :d] = t.permute(0, 2, 1, 3)
+        return out.reshape(B, t.shape[2], Hh * dp).to(torch.bfloat16).to(DEV).contiguous()
+
+    vt = torch.zeros(B, Hh, DV, Nk_pad)
+    vt[:, :, :d, :Nk] = v.transpose(2, 3)
+    o = torch.empty(B, Nq, Hh * DV, dtype=torch.bfloat16, device=DEV)
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk_pad).to(torch.bfloat16).to(DEV).contiguous(),
+                 o, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v               # (B,H,Nq,d)
+    got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
+    close(got, ref, rms=6e-3, mx=3e-2, what="flash attention")
+    assert float(o.float().cpu().view(B, Nq, Hh, DV)[..., d:].abs().max() if DV > d else 0.0) == 0.0
+
+
+def test_x0_and_image_out_and_fsq():
+    g = torch.Generator().manual_seed(43)
+    red, eps = torch.randn(2 * 6 * 5 * 4, generator=g), torch.randn(2 * 6 * 5 * 4, generator=g)
+    x0 = torch.empty_like(red, device=DEV)
+    a = 0.004660095
+    K.x0_from_noise(red.to(DEV), eps.to(DEV), x0, a)
+    ref = ((red.double() - (1 - a) ** 0.5 * eps.double()) / a ** 0.5).float()
+    assert torch.equal(x0.cpu(), ref)
+    img = torch.randn(2, 3, 16, 24, generator=g) * 1.5
+    v = View(img.permute(0, 2, 3, 1).contiguous().to(DEV).reshape(-1), 2, 16, 24, 3)
+    out = torch.empty(2, 3, 13, 20, device=DEV)
+    K.image_out(v, out, 13, 20, True)
+    assert torch.equal(out.cpu(), img[:, :, :13, :20].clamp(-1, 1) * 0.5 + 0.5)
+    idx = torch.arange(16384, dtype=torch.int32)
+    codes = torch.empty(16384 * 8, device=DEV)
+    K.fsq_codes(idx.to(DEV), codes)
+    c = codes.cpu().view(-1, 8)
+    want = torch.stack([((idx // 4 ** dd) % 4 - 2).float() / 2 for dd in range(7)], 1)
+    assert torch.equal(c[:, :7], want) and float(c[:, 7].abs().max()) == 0.0
+
+
+def test_window_partition_round_trip():
+    x = rnd(2, 64, 32, 48, seed=44)
+    v = from_nchw(x.to(DEV))
+    w = torch.empty_like(v.t)
+    K.window_partition(v.t, w, 2, 32, 48, 64, 16)
+    back = torch.zeros_like(v.t)
+    K.window_partition(w, back, 2, 32, 48, 64, 16, reverse=True)
+    n = 2 * 32 * 48 * 64
+    assert torch.equal(back[:n], v.t[:n])
+    ref = x.view(2, 64, 2, 16, 3, 16).permute(0, 2, 4, 3, 5, 1).reshape(12, 256, 64)   # (b wy wx) (iy ix) c
+    assert torch.equal(w[:n].view(12, 256, 64).float().cpu(), ref)

@@ -1,0 +1,211 @@
+"""Parity of the HIP decode path (through the C ABI) with the fp32 oracle (oracle/torch_ref.py,
+itself pinned to the reference by tests/test_oracle_codec.py), stage by stage and end to end, with
+the deterministic synthetic weights of onedc_amd.synth.
+
+Floating-point tolerances are written at each check.  The product computes in bf16 with fp32
+accumulation (BASELINE config "bf16"); the oracle is fp32, so per-stage relative RMS errors of a
+few 1e-3 per layer are the expected bf16 rounding noise, not bugs.  Integer/byte results (symbols,
+bitstreams, round trips) are checked bit-exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import golden
+from onedc_amd import kernels as K
+from onedc_amd import synth
+from onedc_amd.codec_module import IntraNoAR
+from onedc_amd.decoder_unet import UNet
+from onedc_amd.kernels import View, from_nchw, new_view
+from onedc_amd.layers import (DepthConvBlock4, ResidualBlockUpsample, VQAttnBlock, VQResnetBlock, Workspace)
+from onedc_amd.model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+from onedc_amd.vae import VAEDecoder
+from oracle import rans_port
+from oracle import torch_ref as R
+
+DEV = "cuda:0"
+
+
+def rel_rms(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
+
+
+def check(got, ref, tol, what):
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    e = rel_rms(got, ref)
+    print(f"[parity] {what}: rel_rms = {e:.3e} (tol {tol:.1e})")
+    assert e <= tol, f"{what}: rel_rms {e:.3e} > {tol:.1e}"
+
+
+@pytest.fixture(scope="module")
+def codec_sd():
+    return synth.codec_state_dict(0)
+
+
+@pytest.fixture(scope="module")
+def codec(codec_sd):
+    m = IntraNoAR(codec_sd, DEV)
+    m.update(force=True)
+    return m
+
+
+def test_codec_blocks(codec_sd):
+    """DCB4 / RBU / ResnetBlock / AttnBlock on the golden block inputs. tol: 1e-2 rel. RMS."""
+    g = golden("g5_blocks.npz")
+    ws = Workspace(DEV)
+    x128 = torch.from_numpy(g["x128"]).to(torch.bfloat16).float()
+    x768 = torch.from_numpy(g["x768"]).to(torch.bfloat16).float()
+    with torch.no_grad():
+        y = DepthConvBlock4(codec_sd, "hyper_dec.to_entropy.0", DEV)(from_nchw(x128.to(DEV)))
+        check(y.torch_nchw(), R.depth_conv_block4(codec_sd, "hyper_dec.to_entropy.0", x128), 1e-2, "DCB4 128->128")
+        y = DepthConvBlock4(codec_sd, "y_prior_fusion.0", DEV)(from_nchw(x128.to(DEV)))
+        check(y.torch_nchw(), R.depth_conv_block4(codec_sd, "y_prior_fusion.0", x128), 1e-2, "DCB4 128->256")
+        y = ResidualBlockUpsample(codec_sd, "hyper_dec.to_entropy.1", DEV)(from_nchw(x128.to(DEV)))
+        check(y.torch_nchw(), R.residual_block_upsample(codec_sd, "hyper_dec.to_entropy.1", x128), 1e-2, "RBU")
+        y = VQResnetBlock(codec_sd, "semantic_adaptor.to_semantic.1", DEV)(from_nchw(x768.to(DEV)), ws)
+        check(y.torch_nchw(), R.vq_resnet_block(codec_sd, "semantic_adaptor.to_semantic.1", x768), 1e-2, "ResnetBlock")
+        y = VQAttnBlock(codec_sd, "semantic_adaptor.to_semantic.2", DEV, 768)(from_nchw(x768.to(DEV)), ws)
+        check(y.torch_nchw(), R.vq_attn_block(codec_sd, "semantic_adaptor.to_semantic.2", x768), 1e-2, "AttnBlock")
+
+
+def test_hyper_decoder_and_prior_params(codec, codec_sd):
+    """FSQ codes -> HyperDecoder -> y_prior_fusion against the oracle AND the reference-made golden."""
+    g = golden("g5_codec_path.npz")
+    idx = torch.from_numpy(g["indices"]).to(DEV)
+    fused, z_sem = codec._params_from_indices(idx)
+    check(z_sem.torch_nchw(), torch.from_numpy(g["z_semantic"]), 4e-3, "z_semantic vs reference golden")
+    check(fused.torch_nchw(), torch.from_numpy(g["fused"]), 2e-2, "prior params vs reference golden")
+    with torch.no_grad():
+        ref, _ = R.z_indices_to_params(codec_sd, torch.from_numpy(g["indices"]))
+    check(fused.torch_nchw(), ref, 2e-2, "prior params vs oracle")
+
+
+def test_entropy_round_trip_and_oracle_agreement(codec, codec_sd, gaussian_tables):
+    """encode_latents -> container -> decode: y_hat must come back BIT-EXACT (integer path), for
+    a ragged batch size, and the symbols must agree with the fp32 oracle up to rare rounding flips
+    (tol: <= 2 % of symbols differ, |delta| <= 1, because means come from bf16 matrix products)."""
+    g = golden("g5_codec_path.npz")
+    B = 3
+    rng = np.random.default_rng(5)
+    idx = torch.from_numpy(rng.integers(0, 16384, (B, 2, 3)).astype(np.int32)).to(DEV)
+    fused, _ = codec._params_from_indices(idx)
+    H, W = fused.H, fused.W
+    y = (fused.torch_nchw()[:, 128:] + 3.0 * torch.randn(B, 128, H, W, generator=torch.Generator().manual_seed(6)))
+    y_nhwc = y.permute(0, 2, 3, 1).contiguous().to(DEV)
+    blobs, y_hat_enc = codec.encode_latents(idx, y_nhwc, heights=[128, 100, 128], widths=[192, 192, 131])
+    x_hat, y_sem, orig_hw, pad_hw, pad = codec.decode(stream=blobs)
+    assert orig_hw == [(128, 192), (100, 192), (128, 131)] and pad_hw == (128, 192)
+    # decode again, recovering y_hat, and compare with the encoder's
+    from onedc_amd.entropy.utils import decode_i, unpack_indices
+    infos = [decode_i(b, 14, 64) for b in blobs]
+    y_hat_dec, _ = codec.decompress([d["bit_stream_y"] for d in infos], idx)
+    n = B * H * W * 128
+    assert torch.equal(y_hat_dec.t[:n], y_hat_enc.t[:n]), "decoder did not reproduce the encoder's y_hat"
+    assert np.array_equal(np.stack([unpack_indices(d["bit_stream_z"], 6, 14) for d in infos]).reshape(B, 2, 3),
+                          idx.cpu().numpy())
+    # batch invariance of the whole entropy path: image 1 alone gives the same bytes
+    blob1, _ = codec.encode_latents(idx[1:2], y_nhwc[1:2].contiguous(), heights=[100], widths=[192])
+    assert blob1[0] == blobs[1]
+
+    # oracle on the same inputs
+    with torch.no_grad():
+        fused_ref, _ = R.z_indices_to_params(codec_sd, idx.cpu())
+        y_q_w, s_w, y_hat_ref = R.compress_four_part_prior(codec_sd, y, fused_ref)
+    sym_ref = torch.stack(y_q_w, 1).to(torch.int16).numpy()                # (B,4,32,H,W)
+    # product symbols: decode our own streams with the ORACLE coder and the oracle's index planes is not
+    # possible when indexes differ, so compare y_hat instead: y_hat = round(y - mu) + mu
+    diff = (y_hat_dec.torch_nchw() - y_hat_ref).abs()
+    frac = float((diff > 0.5).float().mean())
+    print(f"[parity] y_hat rounding flips vs oracle: {frac:.4%}, max |delta| = {float(diff.max()):.3f}")
+    assert frac <= 0.02 and float(diff.max()) <= 1.25
+    bits_ref = sum(len(rans_port.encode(sym_ref[b].reshape(-1),
+                                        torch.stack([R.build_indexes(s[b:b + 1]) for s in s_w]).to(torch.int16).numpy().reshape(-1),
+                                        rans_port.Tables(*gaussian_tables))) for b in range(B))
+    bits_got = sum(len(d["bit_stream_y"]) for d in infos)
+    print(f"[parity] y stream bytes: product {bits_got}, oracle {bits_ref} ({bits_got / bits_ref - 1:+.3%})")
+    assert abs(bits_got / bits_ref - 1) <= 0.02
+
+
+def test_z_only_prior(codec, codec_sd):
+    g = golden("g5_codec_path.npz")
+    idx = torch.from_numpy(g["indices"])
+    y_hat, _ = codec.recon_with_z(idx.to(DEV))
+    with torch.no_grad():
+        fused_ref, _ = R.z_indices_to_params(codec_sd, idx)
+        ref = R.recon_with_z_four_part_prior(codec_sd, fused_ref)
+    check(y_hat.torch_nchw(), ref, 3e-2, "z-only y_hat vs oracle")
+    check(y_hat.torch_nchw(), torch.from_numpy(g["y_hat_zonly"]), 3e-2, "z-only y_hat vs reference golden")
+
+
+def test_semantic_adaptor_and_synthesis(codec, codec_sd):
+    g = golden("g5_codec_path.npz")
+    y_hat = torch.from_numpy(g["y_hat"])
+    z_sem = torch.from_numpy(g["z_semantic"])
+    yv = View(y_hat.permute(0, 2, 3, 1).contiguous().to(DEV).reshape(-1), 1, y_hat.shape[2], y_hat.shape[3], 128)
+    x_hat, y_sem = codec.synthesis(yv, from_nchw(z_sem.to(DEV)))
+    with torch.no_grad():
+        ys_ref = R.semantic_adaptor(codec_sd, z_sem)
+        xh_ref = R.codec_decoder(codec_sd, y_hat, ys_ref)
+    check(y_sem.torch_nchw(), ys_ref, 2e-2, "semantic adaptor")
+    check(x_hat.torch_nchw(), xh_ref, 3e-2, "codec synthesis (h_detail_hat)")
+    flat = x_hat.torch_nchw().reshape(-1).cpu()
+    gi = torch.from_numpy(g["x_hat.idx"])
+    assert rel_rms(flat[gi], torch.from_numpy(g["x_hat.val"])) <= 3e-2       # vs the reference-made golden
+
+
+@pytest.fixture(scope="module")
+def unet_pair():
+    sd = synth.unet_state_dict(0)
+    return UNet(sd, DEV), R.fold_lora(sd)
+
+
+def test_unet_step(unet_pair):
+    """One UNet step at 16x24 latents (128x192 picture) vs the oracle: eps and reduced.
+    tol: 3e-2 rel. RMS over ~60 bf16 layers."""
+    unet, sd = unet_pair
+    g = torch.Generator().manual_seed(7)
+    sample = torch.randn(2, 320, 16, 24, generator=g).to(torch.bfloat16).float()
+    ctx = torch.randn(2, 768, 2, 3, generator=g).to(torch.bfloat16).float()
+    eps, reduced = unet(from_nchw(sample.to(DEV)), 999, from_nchw(ctx.to(DEV)))
+    with torch.no_grad():
+        eps_ref, red_ref = R.unet_forward(sd, sample, torch.tensor([999, 999]), ctx.permute(0, 2, 3, 1).reshape(2, 6, 768))
+    check(reduced.torch_nchw(), red_ref, 1e-2, "vae_reduction")
+    check(eps.torch_nchw(), eps_ref, 3e-2, "UNet eps")
+
+
+def test_vae_decoder_windowed():
+    """VAE decoder on a 32x48 latent (six 16x16 attention windows) vs the oracle. tol 3e-2."""
+    sd = synth.vae_state_dict(0)
+    vae = VAEDecoder(sd, DEV, attn_patch=16)
+    lat = torch.randn(1, 4, 32, 48, generator=torch.Generator().manual_seed(8)) * 0.18215
+    lv = View(lat.permute(0, 2, 3, 1).contiguous().to(DEV).reshape(-1), 1, 32, 48, 4)
+    img = vae.decode(lv)
+    with torch.no_grad():
+        ref = R.vae_decode(sd, lat, 16)
+    check(img.torch_nchw(), ref, 3e-2, "VAE decoder")
+
+
+def test_end_to_end_decode_psnr(gaussian_tables):
+    """Whole decode of two 128x192 streams (made by the product's own encoder side) against the
+    oracle run from the same decoded latents.  Reported: PSNR(product, oracle) on [0,1] pictures
+    (reference metric, test_quality.py:234-235).  tol: >= 30 dB (bf16 UNet + x14.65 eps->x0 gain)."""
+    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0)
+    model.codec_model.update(force=True)
+    rng = np.random.default_rng(9)
+    idx = torch.from_numpy(rng.integers(0, 16384, (2, 2, 3)).astype(np.int32)).to(DEV)
+    blobs, y_hat = model.codec_model.encode_latents(idx, None, noise_seed=1)
+    img = model.decode(stream=blobs, unit_range=True)
+    assert img.shape == (2, 3, 128, 192)
+    # oracle from the same y_hat / z indices (the entropy path is integer-exact, checked above)
+    codec_sd, unet_sd, vae_sd = synth.codec_state_dict(0), R.fold_lora(synth.unet_state_dict(0)), synth.vae_state_dict(0)
+    with torch.no_grad():
+        _, z_sem = R.z_indices_to_params(codec_sd, idx.cpu())
+        out = R.decode_from_latents(codec_sd, unet_sd, vae_sd, y_hat.torch_nchw().cpu(), z_sem)
+    ref = R.to_unit_range(out["image"])
+    p = R.psnr(img.cpu(), ref)
+    print(f"[parity] end-to-end PSNR(product, oracle) = {p:.2f} dB")
+    assert p >= 30.0
