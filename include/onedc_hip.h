@@ -143,9 +143,11 @@ int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int P
 /* generic strided copy / cast between NHWC views (channel concat, padding layouts) */
 int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, int y_f32, int y_cs,
                         int y_co, int64_t pixels, int C, void *stream);
-/* window partition (B,H,W,C) <-> (B*nwin, win*win, C) for the VAE mid attention */
-int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int win, int reverse,
-                           void *stream);
+/* window partition for the VAE mid attention (vae/autoencoders_patch_attn.py:22-28): the region
+ * [y0,y0+RH) x [x0,x0+RW) of a (B,H,W,C) map <-> (B*nwin, wh*ww, C) windows.  The reference's slicing
+ * leaves ragged windows at the right/bottom edge; the caller covers them as extra regions. */
+int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int y0, int x0, int RH,
+                           int RW, int wh, int ww, int reverse, void *stream);
 /* sinusoidal timestep embedding, flip_sin_to_cos, shift 0 (decoder_unet.py:138): f32 [n][dim] */
 int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *stream);
 /* y = a + b (bf16), used where a residual cannot ride on a GEMM epilogue */

@@ -142,23 +142,23 @@ __global__ void copy_channels_kernel(const void *x, int x_cs, int x_co, void *y,
     }
 }
 
-// (B,H,W,C) <-> (B*nwin, win*win, C), 8 channels per lane
-__global__ void window_partition_kernel(const bf16_t *x, bf16_t *y, int B, int H, int W, int C, int win,
-                                        int reverse) {
+// region [y0,y0+RH) x [x0,x0+RW) of (B,H,W,C) <-> (B*nwin, wh*ww, C) windows, 8 channels per lane
+__global__ void window_partition_kernel(const bf16_t *x, bf16_t *y, int B, int H, int W, int C, int y0, int x0,
+                                        int RH, int RW, int wh, int ww, int reverse) {
     const int CC = C >> 3;
-    const int nwx = W / win, nwy = H / win;
-    const int64_t total = (int64_t)B * H * W * CC;
+    const int nwx = RW / ww, nwy = RH / wh;
+    const int64_t total = (int64_t)B * RH * RW * CC;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int cc = (int)(i % CC);
         const int64_t wp = i / CC;                       // index in window-major order
-        const int pin = (int)(wp % (win * win));
-        int64_t r = wp / (win * win);
+        const int pin = (int)(wp % (wh * ww));
+        int64_t r = wp / (wh * ww);
         const int wx = (int)(r % nwx);
         r /= nwx;
         const int wy = (int)(r % nwy);
         const int b = (int)(r / nwy);
-        const int64_t pix = ((int64_t)b * H + wy * win + pin / win) * W + wx * win + pin % win;
+        const int64_t pix = ((int64_t)b * H + y0 + wy * wh + pin / ww) * W + x0 + wx * ww + pin % ww;
         if (!reverse)
             ((uint4 *)y)[wp * CC + cc] = ((const uint4 *)x)[pix * CC + cc];
         else
@@ -349,11 +349,12 @@ int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, i
     return 0;
 }
 
-int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int win, int reverse,
-                           void *stream) {
-    if (!x || !y || win < 1 || H % win || W % win || (C & 7)) return -1;
-    const int64_t n = (int64_t)B * H * W * (C / 8);
-    LAUNCH(window_partition_kernel, n, (const bf16_t *)x, (bf16_t *)y, B, H, W, C, win, reverse);
+int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int y0, int x0, int RH, int RW,
+                           int wh, int ww, int reverse, void *stream) {
+    if (!x || !y || wh < 1 || ww < 1 || RH % wh || RW % ww || (C & 7)) return -1;
+    if (y0 < 0 || x0 < 0 || y0 + RH > H || x0 + RW > W) return -2;
+    const int64_t n = (int64_t)B * RH * RW * (C / 8);
+    LAUNCH(window_partition_kernel, n, (const bf16_t *)x, (bf16_t *)y, B, H, W, C, y0, x0, RH, RW, wh, ww, reverse);
     return 0;
 }
 

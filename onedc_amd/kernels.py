@@ -58,7 +58,7 @@ SIGNATURES = {
     "onedc_x0_from_noise": (_I, [_P, _P, _P, _L, _D, _P]),
     "onedc_image_out": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_copy_channels": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
-    "onedc_window_partition": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_window_partition": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
     "onedc_hip_version": (C.c_char_p, []),
@@ -275,9 +275,12 @@ def copy_channels(x, y):
     return y
 
 
-def window_partition(x, y, B, H, W, Cc, win, reverse=False):
-    _ok(lib().onedc_window_partition(x.data_ptr(), y.data_ptr(), B, H, W, Cc, win, int(reverse), stream()),
-        "onedc_window_partition")
+def window_partition(x, y, B, H, W, Cc, win, reverse=False, region=None, win_hw=None):
+    """region = (y0, x0, RH, RW) (default: whole map); win_hw = (wh, ww) (default: win x win)."""
+    y0, x0, RH, RW = region or (0, 0, H, W)
+    wh, ww = win_hw or (win, win)
+    _ok(lib().onedc_window_partition(x.data_ptr(), y.data_ptr(), B, H, W, Cc, y0, x0, RH, RW, wh, ww,
+                                     int(reverse), stream()), "onedc_window_partition")
     return y
 
 

@@ -263,3 +263,8 @@ def test_window_partition_round_trip():
     assert torch.equal(back[:n], v.t[:n])
     ref = x.view(2, 64, 2, 16, 3, 16).permute(0, 2, 4, 3, 5, 1).reshape(12, 256, 64)   # (b wy wx) (iy ix) c
     assert torch.equal(w[:n].view(12, 256, 64).float().cpu(), ref)
+    # ragged edge region: rows 16..31, cols 32..47 as 16x8 windows
+    e = torch.zeros_like(v.t)
+    K.window_partition(v.t, e, 2, 32, 48, 64, 16, region=(16, 32, 16, 16), win_hw=(16, 8))
+    ref = x[:, :, 16:32, 32:48].reshape(2, 64, 1, 16, 2, 8).permute(0, 2, 4, 3, 5, 1).reshape(4, 128, 64)
+    assert torch.equal(e[:4 * 128 * 64].view(4, 128, 64).float().cpu(), ref)
