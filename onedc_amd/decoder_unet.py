@@ -77,7 +77,7 @@ class UNet:
         if self._timestep == t:
             return
         w1, b1, w2, b2 = self._te
-        emb = timestep_embedding_cpu(t, arch.UNET_CH[0])
+        emb = timestep_embedding_cpu(t, arch.UNET_CH[0]).to(w1.device)
         emb = w2 @ silu_cpu(w1 @ emb + b1) + b2
         act = silu_cpu(emb)
         for r in self._all_resnets():

@@ -1,0 +1,95 @@
+"""Command-line harness with the reference's surface (src/inference.py:138-164).
+
+    python -m onedc_amd.inference --config_path src/config_inference.yaml --checkpoint_path CKPT \
+        --decoder_only --decoder_bin_path a.bin --decoder_out_path a.png [--vae_path vae.safetensors]
+
+Same flags, same YAML keys (config_inference.yaml), CLI values override the file
+(inference.py:149-152; OmegaConf is replaced by PyYAML + a dict merge), LOCAL_RANK override
+(:154-156), checkpoint directory = model.safetensors + model_1.safetensors loaded strictly (:87-93).
+Additions: --vae_path (the reference downloads the SD-2.1 VAE from the HF hub), and
+--decoder_bin_path may be a directory: all *.bin files of one padded size are decoded as batches.
+The encode half of `evaluate()` (analysis transform) is SURVEY 8(f) and not built yet.
+"""
+import argparse
+import glob
+import os
+
+import numpy as np
+import torch
+import yaml
+
+
+def save_image(img, path):
+    """torchvision.utils.save_image for one [3,H,W] tensor in [0,1] (x255 + 0.5, clamp, uint8)."""
+    from PIL import Image
+    arr = img.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+    Image.fromarray(arr).save(path)
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config_path", type=str, required=True)
+    parser.add_argument("--checkpoint_path", type=str, required=True)
+    parser.add_argument("--output_path", type=str, required=False)
+    parser.add_argument("--eval_image_path", type=str, required=False)
+    parser.add_argument("--decoder_only", action="store_true")
+    parser.add_argument("--decoder_bin_path", type=str, default="", required=False)
+    parser.add_argument("--decoder_out_path", type=str, default="", required=False)
+    parser.add_argument("--vae_path", type=str, default=None, required=False)
+    parser.add_argument("--batch_size", type=int, default=16, required=False)
+    cli = vars(parser.parse_args(argv))
+    with open(cli["config_path"]) as f:
+        config = yaml.safe_load(f) or {}
+    config.update(cli)                                   # CLI over file, like OmegaConf.merge(config, args)
+    env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
+    if env_local_rank != -1 and env_local_rank != config.get("local_rank"):
+        config["local_rank"] = env_local_rank
+    config["unet_ckpt"] = None
+    return config
+
+
+class Evaluator:
+    def __init__(self, args):
+        from .model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+        self.args = args
+        rank = args.get("local_rank", -1)
+        device = torch.device("cuda", rank if rank is not None and rank >= 0 else 0)
+        self.model = SD15_1step_codec_stage1(args, device=device)
+        self.model.load(args["checkpoint_path"], args.get("vae_path"))
+        self.model.prepare()
+        self.model.codec_model.update(force=True)
+        self.model.codec_model.debug = False
+
+    @torch.no_grad()
+    def evaluate(self):
+        args = self.args
+        self.model.eval()
+        if not args["decoder_only"]:
+            raise NotImplementedError(
+                "encode (analysis transform) is not part of this build yet; use --decoder_only")
+        src, dst = args["decoder_bin_path"], args["decoder_out_path"]
+        if os.path.isdir(src):
+            os.makedirs(dst, exist_ok=True)
+            files = sorted(glob.glob(os.path.join(src, "*.bin")))
+            by_size = {}
+            from .entropy.utils import decode_i, read_from_file
+            for f in files:
+                d = decode_i(read_from_file(f), 14, 64)
+                by_size.setdefault((d["pad_height"], d["pad_width"], d["height"], d["width"]), []).append(f)
+            for group in by_size.values():
+                for i in range(0, len(group), args["batch_size"]):
+                    chunk = group[i:i + args["batch_size"]]
+                    recon = self.model.decode(fp=chunk, unit_range=True)
+                    for f, img in zip(chunk, recon):
+                        save_image(img, os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png"))
+            return
+        recon = self.model.decode(fp=src, unit_range=True)      # clamp(-1,1)*0.5+0.5, inference.py:106
+        save_image(recon[0], dst)
+
+
+def main(argv=None):
+    Evaluator(parse_args(argv)).evaluate()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,8 +152,20 @@ def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
     return View(t.reshape(-1), B, H, W, Cp, cs, 0)
 
 
+PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then bracketed by HIP events
+
+
+def conv_tile(cout, glu):
+    """The tile instantiation onedc_conv_gemm picks (mirrors the dispatcher in gemm_conv.hip)."""
+    if cout <= 16 and not glu:
+        return "16x256"
+    if cout % 128 != 0 and cout % 128 <= 64:
+        return "64x128"
+    return "128x128"
+
+
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
-              pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0):
+              pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0):
     """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None."""
     p = ConvParams()
     p.x, p.w, p.bias, p.res, p.y = x.ptr, w.data_ptr(), _ptr(bias), (res.ptr if res is not None else None), y.ptr
@@ -175,7 +187,15 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     p.epi, p.out_f32, p.pixel_shuffle = epi, int(y.f32), pixel_shuffle
     p.alpha, p.slope = alpha, slope
     p.batch, p.x_bs, p.w_bs, p.y_bs, p.r_bs = batch, x_bs, w_bs, y_bs, r_bs
+    if PROFILE is None:
+        _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
+        return y
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
+    e1.record()
+    flops = 2.0 * p.B * p.OH * p.OW * p.Cout * (p.KH * p.KW * p.Cin) * max(batch, 1) * flop_scale
+    PROFILE.append((conv_tile(p.Cout, glu), flops, e0, e1))
     return y
 
 

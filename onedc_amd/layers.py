@@ -41,7 +41,9 @@ class Workspace:
 class Conv:
     """nn.Conv2d / nn.Linear as one implicit-GEMM launch."""
 
-    def __init__(self, sd, name, device, *, perm=None, glu=False, shuffle=False, weight=None, bias=None):
+    def __init__(self, sd, name, device, *, perm=None, glu=False, shuffle=False, weight=None, bias=None,
+                 flop_scale=1.0):
+        self.flop_scale = flop_scale          # < 1 when rows/cols are zero padding (padded heads)
         w = sd[f"{name}.weight"] if weight is None else weight
         b = sd.get(f"{name}.bias") if bias is None and weight is None else bias
         self.k = w.shape[2] if w.dim() == 4 else 1
@@ -72,7 +74,7 @@ class Conv:
             y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if out_f32 else torch.bfloat16)
         return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
                            alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
-                           Cout=self.cout)
+                           Cout=self.cout, flop_scale=self.flop_scale)
 
 
 class GroupNorm:
@@ -201,7 +203,7 @@ class ResnetBlock2D:
     def set_temb(self, temb_act):
         """temb_act = SiLU(time_embedding(t)) as a CPU f32 vector [1280]."""
         if self._tw is not None:
-            self.c1.b = (self._c1_bias + self._tw @ temb_act + self._tb).contiguous().to(self.device)
+            self.c1.b = (self._c1_bias + self._tw @ temb_act.to(self._tw.device) + self._tb).contiguous().to(self.device)
 
     def __call__(self, x, ws, y=None):
         h = self.c1(self.n1(x, ws, True))
@@ -218,12 +220,14 @@ class MultiHeadAttention:
         self.H, self.d = heads, d
         self.DQ, self.DV = pack.HEAD_PAD[d]
         self.C, self.ctx_dim = C, ctx_dim
-        self.q = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_q.weight"], heads, d, self.DQ))
-        self.k = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_k.weight"], heads, d, self.DQ))
+        self.q = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_q.weight"], heads, d, self.DQ),
+                      flop_scale=d / self.DQ)
+        self.k = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_k.weight"], heads, d, self.DQ),
+                      flop_scale=d / self.DQ)
         wv = pack.pad_heads_rows(sd[f"{p}.to_v.weight"], heads, d, self.DV)
         self.wv = View(pack.pack_matrix(wv, device), 1, 1, heads * self.DV, ctx_dim)
         self.o = Conv(sd, "", device, weight=pack.pad_heads_cols(sd[f"{p}.to_out.0.weight"], heads, d, self.DV),
-                      bias=sd[f"{p}.to_out.0.bias"])
+                      bias=sd[f"{p}.to_out.0.bias"], flop_scale=d / self.DV)
 
     def __call__(self, x, ctx, res, y=None):
         """x: query tokens View (B, H, W, C); ctx: key/value tokens View; res: residual."""
@@ -234,7 +238,8 @@ class MultiHeadAttention:
         k = self.k(ctx)
         vt = torch.zeros(B * self.H * self.DV * Nk_pad, dtype=torch.bfloat16, device=dev)
         K.conv_gemm(self.wv, ctx.t, None, View(vt, 1, 1, self.H * self.DV, Nk, Nk_pad), Cin=self.ctx_dim,
-                    Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=self.H * self.DV * Nk_pad)
+                    Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=self.H * self.DV * Nk_pad,
+                    flop_scale=self.d / self.DV)
         o = new_view(x.B, x.H, x.W, self.H * self.DV, dev)
         K.flash_attn(q.t, k.t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, self.DQ, self.DV, self.d ** -0.5)
         return self.o(o, y, res=res)
