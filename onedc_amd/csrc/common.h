@@ -15,18 +15,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
         if (e__ != hipSuccess) return (int)e__;      \
     } while (0)
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even f32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// f32 -> bf16, round to nearest even, NaN stays NaN: one v_cvt_pk_bf16_f32 per pair
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
