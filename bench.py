@@ -15,7 +15,7 @@ parallel, one process per GPU, weak scaling, one RCCL broadcast of the weights, 
 collective.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      for the dominant kernel (the 128x128 implicit-GEMM instantiation): achieved =
+  roofline      for the dominant kernel (the implicit-GEMM instantiation with the most device time): achieved =
                 algorithmic FLOPs of its launches / their summed duration, measured live with HIP
                 events on the launch stream during the timed region; peak = dense bf16 MFMA.
   cpu_baseline  the fp32 oracle (oracle/torch_ref.py, "port") timed on the host cores of this box
@@ -191,7 +191,11 @@ def main():
                        "timed": "container parse + host rANS + H2D/D2H + all device kernels + crop"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": f"conv_gemm_kernel<Tile<{dom.replace('x', ',')},2,2>>",
+                         "kernel": ("conv_gemm256_kernel" if dom == "256x256" else
+                                    f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
+                                    + (" f32" if dom.startswith("f32") else "")),
+                         "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.steps * 1e3, 2),
+                                           "launches_per_step": v[2] // args.steps} for k, v in sorted(by_tile.items())},
                          "launches_per_step": launches // args.steps,
                          "avg_launch_us": round(secs / launches * 1e6, 2),
                          "algorithmic_gflop_per_step": round(flops / args.steps / 1e9, 1),

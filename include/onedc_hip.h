@@ -58,6 +58,10 @@ typedef struct onedc_conv_params {
     int32_t epi, out_f32, pixel_shuffle;
     float alpha, slope;
     int32_t batch;                      /* >1: batched GEMM over blockIdx.z */
+    int32_t tile;                       /* 0: pick the tile automatically; 128 / 256: force that channel-tile
+                                           family (tests, benchmarks) */
+    int32_t in_f32;                     /* 1: x, w, res are f32 (exact f32 MFMA; Cin multiple of 32, out_f32
+                                           required): the prior networks, whose outputs feed integer decisions */
     int64_t x_bs, w_bs, y_bs, r_bs;     /* element strides between batches */
 } onedc_conv_params;
 int onedc_conv_gemm(const onedc_conv_params *p, void *stream);
@@ -74,6 +78,9 @@ int onedc_direct_conv(const onedc_direct_conv_params *p, void *stream);
 /* Depthwise 3x3, pad 1 (DepthConv.depth_conv, dcvc.py:251).  w f32 [3][3][C], bias f32 [C]. */
 int onedc_dwconv3x3(const void *x, const float *w, const float *bias, void *y, int B, int H, int W,
                     int C, int x_cs, int x_co, int y_cs, int y_co, void *stream);
+/* the same on f32 activations (prior networks) */
+int onedc_dwconv3x3_f32(const float *x, const float *w, const float *bias, float *y, int B, int H, int W,
+                        int C, int x_cs, int x_co, int y_cs, int y_co, void *stream);
 
 /* GroupNorm(32 groups) [+ SiLU] as statistics + a per-channel affine:
  *   onedc_gn_stats        per-chunk partial sums (fixed order) -> per image/group mean, rstd ->

@@ -24,24 +24,28 @@ from .layers import (Conv, DepthConvBlock4, ResidualBlockUpsample, VQAttnBlock, 
 
 
 class HyperDecoder:
-    def __init__(self, sd, device, p="hyper_dec"):
+    def __init__(self, sd, device, p="hyper_dec", f32=False):
+        self.f32 = f32
         w = sd[f"{p}.feat_in.0.weight"]                        # (128, 7, 1, 1) -> f32 [128][8] (pad cin)
         wf = torch.zeros(w.shape[0], 8)
         wf[:, :7] = w[:, :, 0, 0]
         self.feat_w = wf.contiguous().to(device)
         self.feat_b = sd[f"{p}.feat_in.0.bias"].float().contiguous().to(device)
         self.n = w.shape[0]
-        self.b0 = DepthConvBlock4(sd, f"{p}.to_entropy.0", device)
-        self.u1 = ResidualBlockUpsample(sd, f"{p}.to_entropy.1", device)
-        self.b2 = DepthConvBlock4(sd, f"{p}.to_entropy.2", device)
-        self.u3 = ResidualBlockUpsample(sd, f"{p}.to_entropy.3", device)
-        self.b4 = DepthConvBlock4(sd, f"{p}.to_entropy.4", device)
+        self.b0 = DepthConvBlock4(sd, f"{p}.to_entropy.0", device, f32)
+        self.u1 = ResidualBlockUpsample(sd, f"{p}.to_entropy.1", device, f32)
+        self.b2 = DepthConvBlock4(sd, f"{p}.to_entropy.2", device, f32)
+        self.u3 = ResidualBlockUpsample(sd, f"{p}.to_entropy.3", device, f32)
+        self.b4 = DepthConvBlock4(sd, f"{p}.to_entropy.4", device, f32)
 
     def __call__(self, codes):
-        """codes: f32 View (B, h, w, 8) -> (params View, z_semantic View)."""
-        z = new_view(codes.B, codes.H, codes.W, self.n, codes.t.device)
+        """codes: f32 View (B, h, w, 8) -> (params View, z_semantic View (bf16: it feeds the synthesis))."""
+        dev = codes.t.device
+        z = new_view(codes.B, codes.H, codes.W, self.n, dev, torch.float32 if self.f32 else torch.bfloat16)
         K.direct_conv(codes, self.feat_w, self.feat_b, z, K=1, epi=K.EPI_LEAKY, slope=0.01)
         h = self.b4(self.u3(self.b2(self.u1(self.b0(z)))))
+        if self.f32:
+            z = K.copy_channels(z, new_view(z.B, z.H, z.W, z.C, dev))
         return h, z
 
 
@@ -95,14 +99,21 @@ class Decoder:
 
 
 class IntraNoAR:
-    def __init__(self, sd, device, bottleneck_ch=128, semantic_ch=768, z_fsq_levels=(4,) * 7, host_threads=None):
+    def __init__(self, sd, device, bottleneck_ch=128, semantic_ch=768, z_fsq_levels=(4,) * 7, host_threads=None,
+                 prior_f32=True):
+        """prior_f32: run everything that feeds the integer decisions of the entropy coder (hyper
+        decoder, prior fusion, the four-part prior's nets: 36 GFLOP of the 8047 per 768x768 picture)
+        in exact f32 on the f32 matrix-core path, like the reference's CPU path; False = bf16 MFMA
+        like the reference under GPU autocast (SURVEY hard part 2)."""
         self.device = device
         self.N = N = bottleneck_ch
-        self.hyper_dec = HyperDecoder(sd, device)
-        self.y_prior_fusion = [DepthConvBlock4(sd, f"y_prior_fusion.{i}", device) for i in range(2)]
-        self.y_spatial_prior_reduction = Conv(sd, "y_spatial_prior_reduction", device)
-        self.y_spatial_prior_adaptor = [DepthConvBlock4(sd, f"y_spatial_prior_adaptor_{i}", device) for i in (1, 2, 3)]
-        self.y_spatial_prior = [DepthConvBlock4(sd, f"y_spatial_prior.{i}", device) for i in range(3)]
+        self.prior_f32 = f32 = bool(prior_f32)
+        self.hyper_dec = HyperDecoder(sd, device, f32=f32)
+        self.y_prior_fusion = [DepthConvBlock4(sd, f"y_prior_fusion.{i}", device, f32) for i in range(2)]
+        self.y_spatial_prior_reduction = Conv(sd, "y_spatial_prior_reduction", device, f32=f32)
+        self.y_spatial_prior_adaptor = [DepthConvBlock4(sd, f"y_spatial_prior_adaptor_{i}", device, f32)
+                                        for i in (1, 2, 3)]
+        self.y_spatial_prior = [DepthConvBlock4(sd, f"y_spatial_prior.{i}", device, f32) for i in range(3)]
         self.semantic_adaptor = SemanticAdaptor(sd, device, semantic_ch)
         self.dec = Decoder(sd, device)
         self.z_fsq_levels = list(z_fsq_levels)
@@ -135,7 +146,8 @@ class IntraNoAR:
 
     def _next_params(self, k, y_hat, common_cat):
         """(scales, means) of step k >= 1 from y_hat_so_far and the reduced common params."""
-        K.copy_channels(y_hat, common_cat.slice(0, self.N))               # f32 -> bf16 into the cat buffer
+        if not self.prior_f32:
+            K.copy_channels(y_hat, common_cat.slice(0, self.N))           # f32 -> bf16 into the cat buffer
         a = self.y_spatial_prior_adaptor[k - 1](common_cat)
         a = self.y_spatial_prior[0](a)
         a = self.y_spatial_prior[1](a)
@@ -143,6 +155,13 @@ class IntraNoAR:
 
     def _prior_setup(self, fused):
         B, H, W, N = fused.B, fused.H, fused.W, self.N
+        if self.prior_f32:
+            # [y_hat_so_far | common] is ONE f32 buffer: y_hat is its first channel slice, so
+            # torch.cat((y_hat_so_far, common_params)) (compression_model.py:387) costs nothing
+            common_cat = new_view(B, H, W, 2 * N, self.device, torch.float32)
+            self.y_spatial_prior_reduction(fused, common_cat.slice(N, N))
+            y_hat = common_cat.slice(0, N)            # step 0 of the prior update initialises it
+            return common_cat, y_hat
         fused_bf = new_view(B, H, W, 2 * N, self.device)
         K.copy_channels(fused, fused_bf)
         common_cat = new_view(B, H, W, 2 * N, self.device)                 # [y_hat_so_far | common]

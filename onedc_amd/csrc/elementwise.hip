@@ -30,7 +30,7 @@ __device__ __forceinline__ void stp(void *p, int64_t i, float v) {
 }
 
 constexpr float LOG_SCALE_MIN = -2.2072749131897207f;           // ln 0.11
-constexpr float LOG_SCALE_STEP = 0.024971781017814617f;          // (ln 64 - ln 0.11) / 255
+constexpr float LOG_SCALE_STEP = 0.02496532547666428f;           // (ln 64 - ln 0.11) / 255
 
 // indexes[b][c4][y][x] (NCHW, the reference's flatten order) from the scale plane of `step`.
 // combine_for_writing sums the four masked channel groups: exactly one is non-zero per position.
@@ -232,6 +232,40 @@ __global__ void dwconv3x3_kernel(const bf16_t *__restrict__ x, const float *__re
     }
 }
 
+// f32 variant (prior networks): 4 channels per lane, 16-byte accesses
+__global__ void dwconv3x3_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                     const float *__restrict__ bias, float *__restrict__ y, int B, int H, int W,
+                                     int C, int x_cs, int x_co, int y_cs, int y_co) {
+    const int CC = C >> 2;
+    const int64_t total = (int64_t)B * H * W * CC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % CC);
+        const int64_t pix = i / CC;
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        const int64_t b = pix / ((int64_t)W * H);
+        float4 acc = bias ? *(const float4 *)(bias + cc * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = yy + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = xx + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = *(const float4 *)(x + ((b * H + iy) * W + ix) * x_cs + x_co + cc * 4);
+                const float4 wv = *(const float4 *)(w + (ky * 3 + kx) * C + cc * 4);
+                acc.x = __builtin_fmaf(v.x, wv.x, acc.x);
+                acc.y = __builtin_fmaf(v.y, wv.y, acc.y);
+                acc.z = __builtin_fmaf(v.z, wv.z, acc.z);
+                acc.w = __builtin_fmaf(v.w, wv.w, acc.w);
+            }
+        }
+        *(float4 *)(y + pix * y_cs + y_co + cc * 4) = acc;
+    }
+}
+
 // direct conv for Cin < 64: one thread per (pixel, cout); w f32 [Cout][K][K][Cin]
 template <bool XF>
 __global__ void direct_conv_kernel(const onedc_direct_conv_params p) {
@@ -367,6 +401,14 @@ int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *s
 int onedc_add(const void *a, const void *b, void *y, int64_t n, void *stream) {
     if (!a || !b || !y || (n & 7)) return -1;
     LAUNCH(add_kernel, n / 8, (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)y, n / 8);
+    return 0;
+}
+
+int onedc_dwconv3x3_f32(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int C,
+                        int x_cs, int x_co, int y_cs, int y_co, void *stream) {
+    if (!x || !w || !y || (C & 3) || (x_cs & 3) || (x_co & 3) || (y_cs & 3) || (y_co & 3)) return -1;
+    const int64_t n = (int64_t)B * H * W * (C / 4);
+    LAUNCH(dwconv3x3_f32_kernel, n, x, w, bias, y, B, H, W, C, x_cs, x_co, y_cs, y_co);
     return 0;
 }
 

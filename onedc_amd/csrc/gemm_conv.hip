@@ -14,7 +14,7 @@
 // up with 4 consecutive channels of one pixel -> 8-byte NHWC stores and lane-local epilogues.
 //
 // Replaces nn.Conv2d / nn.Linear everywhere on the reference decode path (see onedc_hip.h).
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -31,31 +31,30 @@ struct Tile {
     static_assert(WN * WM == 4 && TM % 32 == 0 && TN % 8 == 0, "tile shape");
 };
 
-__device__ __forceinline__ void glds16(const char *src, char *lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
-}
-
-template <class T>
+// F32 = true: the same tile machinery on f32 activations and weights (exact f32 products,
+// v_mfma_f32_16x16x4_f32).  A 128-byte LDS row then holds 32 channels instead of 64; each lane's
+// 16-byte fragment chunk feeds four k=4 MFMAs (element e of every lane's chunk is one k-slice, the
+// same permutation on both operands).  Used for the prior networks, whose outputs feed integer
+// decisions (SURVEY hard part 2).
+template <class T, bool F32>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_params p, int tiles_n,
                                                            int tiles_m, int M, int Ktot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TN = T::TN, TM = T::TM;
+    constexpr int ES = F32 ? 4 : 2;                // bytes per element
+    constexpr int KSH = F32 ? 5 : 6;               // log2(channels per 128-byte row)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % T::WN, wm = wave / T::WN;
 
     // ---- tile of this workgroup; consecutive logical tiles share an XCD (and its L2) -------------
-    const int nblk = tiles_n * tiles_m;
-    const int bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_m);
     const int n0 = (logical % tiles_n) * TN;
     const int m0 = (logical / tiles_n) * TM;
 
-    const char *xb = (const char *)p.x + (int64_t)blockIdx.z * p.x_bs * 2;
-    const char *wb = (const char *)p.w + (int64_t)blockIdx.z * p.w_bs * 2;
+    const char *xb = (const char *)p.x + (int64_t)blockIdx.z * p.x_bs * ES;
+    const char *wb = (const char *)p.w + (int64_t)blockIdx.z * p.w_bs * ES;
     const char *zeros = (const char *)p.zeros;
 
     // ---- per-lane DMA sources -----------------------------------------------------------------
@@ -65,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
 #pragma unroll
     for (int i = 0; i < T::NWI; ++i) {
         const int row = (wave + 4 * i) * 8 + lrow;
-        wsrc[i] = wb + ((int64_t)(n0 + row) * Ktot) * 2 + chunk * 16;
+        wsrc[i] = wb + ((int64_t)(n0 + row) * Ktot) * ES + chunk * 16;
     }
     int pb[T::NPI], pyx[T::NPI];                   // image index, packed (oy << 16 | ox); oy = -1: no pixel
 #pragma unroll
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     }
     const char *psrc[T::NPI];
     unsigned pok = 0;                              // bit i: pixel row i of this lane is inside the image
-    const int nc = p.Cin >> 6;                     // 64-channel steps per tap
+    const int nc = p.Cin >> KSH;                   // 128-byte steps per tap
     const int steps = p.KH * p.KW * nc;
 
     auto tap_sources = [&](int tap) {
@@ -104,13 +103,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
                 ok = ok && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW;
             }
             const int64_t pix = ((int64_t)pb[i] * p.IH + iy) * p.IW + ix;
-            psrc[i] = xb + (pix * p.x_cs + p.x_co) * 2 + chunk * 16;
+            psrc[i] = xb + (pix * p.x_cs + p.x_co) * ES + chunk * 16;
             pok |= ok ? (1u << i) : 0u;
         }
     };
 
     auto issue = [&](int step, int tap, int ci, char *buf) {
-        const int64_t kbyte = ((int64_t)tap * p.Cin + ci * 64) * 2;
+        const int64_t kbyte = (int64_t)tap * p.Cin * ES + ci * 128;
 #pragma unroll
         for (int i = 0; i < T::NWI; ++i) {
             const int blk = wave + 4 * i;          // wave-uniform
@@ -157,18 +156,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[T::FI], b[T::FJ];
+            if constexpr (F32) {
+                f32x4 a[T::FI], b[T::FJ];
 #pragma unroll
-            for (int i = 0; i < T::FI; ++i)
-                a[i] = *(const bf16x8 *)(cur + a_base + i * 2048 + foff[ks]);
-#pragma unroll
-            for (int j = 0; j < T::FJ; ++j)
-                b[j] = *(const bf16x8 *)(cur + b_base + j * 2048 + foff[ks]);
-#pragma unroll
-            for (int i = 0; i < T::FI; ++i)
+                for (int i = 0; i < T::FI; ++i)
+                    a[i] = *(const f32x4 *)(cur + a_base + i * 2048 + foff[ks]);
 #pragma unroll
                 for (int j = 0; j < T::FJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    b[j] = *(const f32x4 *)(cur + b_base + j * 2048 + foff[ks]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < T::FI; ++i)
+#pragma unroll
+                        for (int j = 0; j < T::FJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            } else {
+                bf16x8 a[T::FI], b[T::FJ];
+#pragma unroll
+                for (int i = 0; i < T::FI; ++i)
+                    a[i] = *(const bf16x8 *)(cur + a_base + i * 2048 + foff[ks]);
+#pragma unroll
+                for (int j = 0; j < T::FJ; ++j)
+                    b[j] = *(const bf16x8 *)(cur + b_base + j * 2048 + foff[ks]);
+#pragma unroll
+                for (int i = 0; i < T::FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::FJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 
@@ -176,100 +192,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     const int cout_store = glu ? p.Cout / 2 : p.Cout;
     char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
-    const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
+    const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * ES : nullptr;
     const int nw = n0 + wn * T::WTN;               // first packed row of this wave
 
 #pragma unroll
     for (int j = 0; j < T::FJ; ++j) {
         const int m = m0 + wm * T::WTM + j * 16 + frow;
         if (m >= M) continue;
-        int64_t opix = m;                          // output pixel index on the y grid
-        int c_shift = 0;                           // pixel-shuffle: sub-position selects the pixel
-        int ob = 0, ooy = 0, oox = 0;
-        if (p.pixel_shuffle) {
-            const int ohw = p.OH * p.OW;
-            ob = m / ohw;
-            const int rem = m - ob * ohw;
-            ooy = rem / p.OW;
-            oox = rem - ooy * p.OW;
-        }
+        const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
         for (int i = 0; i < T::FI; ++i) {
-            if (glu && (i & 1)) continue;          // odd tiles are the gate halves, consumed below
-            const int nrow = nw + i * 16 + fq * 4; // packed weight row of element 0
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = acc[i][j][e] * p.alpha;
-                if (p.bias) t += p.bias[nrow + e];
-                v[e] = t;
-            }
-            int n_out = nrow;
-            if (glu) {
-                if constexpr (T::FI >= 2) {
-                    const int i2 = (i + 1 < T::FI) ? i + 1 : i;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float g = acc[i2][j][e] * p.alpha;
-                        if (p.bias) g += p.bias[nrow + 16 + e];
-                        v[e] = p.epi == ONEDC_EPI_GLU_LEAKY ? leaky(v[e], 0.1f) + leaky(g, 0.01f)
-                                                            : v[e] * gelu_f(g);
-                    }
-                }
-                n_out = (nw + i * 16) / 2 + fq * 4;
-            } else if (p.epi == ONEDC_EPI_LEAKY) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], p.slope);
-            } else if (p.epi == ONEDC_EPI_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            }
-            if (n_out >= cout_store) continue;
-            if (p.pixel_shuffle) {
-                const int cq = p.Cout >> 2;        // channels after the shuffle
-                const int sub = n_out / cq;
-                c_shift = n_out - sub * cq;
-                opix = ((int64_t)ob * (2 * p.OH) + 2 * ooy + (sub >> 1)) * (2 * p.OW) + 2 * oox + (sub & 1);
-                n_out = c_shift;
-            }
-            if (rb) {
-                const bf16_t *rp = (const bf16_t *)rb + opix * p.r_cs + p.r_co + n_out;
-                if (n_out + 3 < cout_store || p.pixel_shuffle) {
-                    const uint2 rv = *(const uint2 *)rp;
-                    v[0] += bf2f((bf16_t)(rv.x & 0xffff));
-                    v[1] += bf2f((bf16_t)(rv.x >> 16));
-                    v[2] += bf2f((bf16_t)(rv.y & 0xffff));
-                    v[3] += bf2f((bf16_t)(rv.y >> 16));
-                } else {
-                    for (int e = 0; e < 4 && n_out + e < cout_store; ++e) v[e] += bf2f(rp[e]);
-                }
-            }
-            const int64_t yo = opix * p.y_cs + p.y_co + n_out;
-            const bool full = p.pixel_shuffle || n_out + 3 < cout_store;
-            if (p.out_f32) {
-                float *yp = (float *)yb + yo;
-                if (full && ((p.y_cs | p.y_co) & 3) == 0) {
-                    *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int e = 0; e < 4 && n_out + e < cout_store; ++e) yp[e] = v[e];
-                }
-            } else {
-                bf16_t *yp = (bf16_t *)yb + yo;
-                if (full && ((p.y_cs | p.y_co) & 3) == 0) {
-                    *(uint2 *)yp = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                } else {
-                    for (int e = 0; e < 4 && n_out + e < cout_store; ++e) yp[e] = f2bf(v[e]);
-                }
-            }
+            if (glu && (i & 1)) continue;          // odd tiles are the gate halves, consumed with their value tile
+            const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
+            conv_epilogue_tile<F32>(p, yb, rb, glu, cout_store, acc[i][j], acc[i2][j], nw + i * 16, fq, op);
         }
     }
 }
 
-template <class T>
+template <class T, bool F32 = false>
 int launch(const onedc_conv_params &p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipFuncSetAttribute((const void *)conv_gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void *)conv_gemm_kernel<T, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * T::BUF);
         configured = true;
     }
@@ -280,26 +224,36 @@ int launch(const onedc_conv_params &p, hipStream_t st) {
     const int tiles_m = (M + T::TM - 1) / T::TM;
     const int Ktot = p.KH * p.KW * p.Cin;
     dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
-    hipLaunchKernelGGL(conv_gemm_kernel<T>, grid, dim3(256), 2 * T::BUF, st, p, tiles_n, tiles_m, M, Ktot);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, F32>), grid, dim3(256), 2 * T::BUF, st, p, tiles_n, tiles_m, M, Ktot);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
+int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st);   // gemm_conv256.hip
+
 extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (!pp) return -1;
     const onedc_conv_params &p = *pp;
     if (!p.x || !p.w || !p.y || !p.zeros) return -1;
-    if (p.Cin <= 0 || (p.Cin & 63) || p.Cout <= 0) return -2;
-    if ((p.x_cs & 7) || (p.x_co & 7)) return -3;          // 16-byte aligned source chunks
-    if (p.res && ((p.r_cs | p.r_co) & 3)) return -8;       // 8-byte aligned residual reads
+    if (p.Cin <= 0 || (p.Cin & (p.in_f32 ? 31 : 63)) || p.Cout <= 0) return -2;
+    if ((p.x_cs | p.x_co) & (p.in_f32 ? 3 : 7)) return -3; // 16-byte aligned source chunks
+    if (p.res && ((p.r_cs | p.r_co) & 3)) return -8;       // 8-byte (bf16) / 16-byte (f32) aligned residual reads
+    if (p.in_f32 && !p.out_f32) return -9;                 // the f32 path stays f32
     if (p.KH < 1 || p.KW < 1 || p.stride < 1 || p.OH < 1 || p.OW < 1 || p.B < 1) return -4;
     if (p.OW > 0xffff || p.OH > 0x7fff) return -5;
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     if (glu && (p.Cout & 31)) return -6;
     if (p.pixel_shuffle && ((p.Cout & 15) || glu)) return -7;
     hipStream_t st = as_stream(stream);
+    if (p.in_f32) return launch<Tile<128, 128, 2, 2>, true>(p, st);
+    // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
+    const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
+    const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
+    const int ktiles = p.KH * p.KW * (p.Cin >> 6);         // short K: prologue + epilogue of the one resident block dominate
+    if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 8) || p.tile == 256))
+        return onedc_conv_gemm256_launch(p, st);
     if (p.Cout <= 16 && !glu) return launch<Tile<16, 256, 1, 4>>(p, st);
     if ((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) return launch<Tile<64, 128, 2, 2>>(p, st);
     return launch<Tile<128, 128, 2, 2>>(p, st);

@@ -1,0 +1,290 @@
+// gemm_conv256.hip — the large-tile implicit-GEMM convolution: 256 channels x 256 pixels per
+// workgroup, 8 wave64s, 8-phase schedule with the LDS-DMA prefetch left in flight across barriers.
+//
+// Same math, operand layout and epilogues as gemm_conv.hip (y = act(alpha * x*w^T + bias) + res,
+// A operand = packed weight rows, B operand = shifted / zero-padded NHWC pixel rows, bf16 in, f32
+// accumulate, v_mfma_f32_16x16x32_bf16), different machine mapping:
+//
+//   * waves form a 2 (channels) x 4 (pixels) grid, each wave owns 128 channels x 64 pixels =
+//     8 x 4 accumulator tiles (128 VGPRs): 64 MFMAs per 64-deep K-tile against 24 KB of LDS reads,
+//     and every byte the workgroup DMAs from L2 feeds twice the MFMAs of the 128 x 128 kernel
+//   * a K-tile is consumed in 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave's tile each);
+//     LDS holds two K-tiles of four 16 KB "half-tiles" (A^0, A^1, B^0, B^1: the rows the waves read in
+//     the same phase sit together), each restaged by two global_load_lds_dwordx4 per wave as soon as
+//     its last reader is two phases (or, for B^0, one phase and a retiring lgkmcnt) behind
+//   * prefetch distance is three half-tiles: the only vector-memory wait in the loop is one counted
+//     s_waitcnt vmcnt(6) per K-tile, barriers are raw s_barrier (no drain), and the two wave rows run
+//     one barrier apart so that on every SIMD one wave is in its MFMA segment while the other issues
+//     LDS reads and DMA
+//   * LDS rows are 128 B with the 16-byte chunk XOR (row & 7) swizzle applied on the DMA source
+//     address and on the ds_read_b128 fragment reads (conflict-free)
+//
+// Used by onedc_conv_gemm for the layers with >= 256 output rows and enough pixels to fill the chip
+// (all VAE up-block convolutions with 256/512 channels, the UNet's 1280-channel layers, the FF GEMMs).
+#include "conv_common.h"
+
+namespace {
+
+constexpr int HALF = 16384;           // bytes of one half-tile (128 rows x 128 B)
+constexpr int STAGE = 4 * HALF;       // one K-tile: A^0 A^1 B^0 B^1
+constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
+
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_params p, int tiles_n, int tiles_m,
+                                                              int M, int Ktot) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_m);
+    const int n0 = (logical % tiles_n) * 256;
+    const int m0 = (logical / tiles_n) * 256;
+
+    const char *xb = (const char *)p.x + (int64_t)blockIdx.z * p.x_bs * 2;
+    const char *wb = (const char *)p.w + (int64_t)blockIdx.z * p.w_bs * 2;
+    const char *zeros = (const char *)p.zeros;
+
+    // ---- DMA geometry: one wave instruction = 8 LDS rows; a wave stages blocks (wave) and (wave + 8)
+    // of every half-tile.  LDS row rho of A^h is tile channel (rho / 64) * 128 + h * 64 + rho % 64,
+    // LDS row rho of B^h is tile pixel (rho / 32) * 64 + h * 32 + rho % 32.
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;           // swizzle on the source side
+    const int t64 = wave * 8 + lrow;               // 0..63: LDS row of block `wave`; block wave + 8 is row t64 + 64
+    // weights: row(h, i) = n0 + i * 128 + h * 64 + t64
+    const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;
+    const int64_t wrow64 = (int64_t)64 * Ktot * 2;         // byte stride of 64 weight rows
+    // pixels: pixel(h, i) = m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
+    int pb[4], pyx[4];                             // [h * 2 + i]: image, packed (oy << 16 | ox); -1 = no pixel
+#pragma unroll
+    for (int hi = 0; hi < 4; ++hi) {
+        const int h = hi >> 1, i = hi & 1;
+        const int m = m0 + ((t64 >> 5) + 2 * i) * 64 + h * 32 + (t64 & 31);
+        if (m < M) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW;
+            pb[hi] = b;
+            pyx[hi] = (oy << 16) | (rem - oy * p.OW);
+        } else {
+            pb[hi] = 0;
+            pyx[hi] = -1;
+        }
+    }
+    const char *psrc[4];
+    unsigned pok = 0;
+    const int nc = p.Cin >> 6;                     // 64-channel K-tiles per tap
+    const int T = p.KH * p.KW * nc;                // K-tiles
+
+    auto tap_sources = [&](int tap) {
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        pok = 0;
+#pragma unroll
+        for (int hi = 0; hi < 4; ++hi) {
+            const int oy = pyx[hi] >> 16, ox = pyx[hi] & 0xffff;
+            int iy = oy * p.stride + ky - p.pad;
+            int ix = ox * p.stride + kx - p.pad;
+            bool ok = pyx[hi] >= 0;
+            if (p.up) {
+                ok = ok && iy >= 0 && ix >= 0 && iy < 2 * p.IH && ix < 2 * p.IW;
+                iy >>= 1;
+                ix >>= 1;
+            } else {
+                ok = ok && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW;
+            }
+            const int64_t pix = ((int64_t)pb[hi] * p.IH + iy) * p.IW + ix;
+            psrc[hi] = xb + (pix * p.x_cs + p.x_co) * 2 + chunk * 16;
+            pok |= ok ? (1u << hi) : 0u;
+        }
+    };
+
+    // stage half-tile A^h of K-tile t (weights are k-contiguous: K-tile t starts at byte t * 128 of a row)
+    auto stage_A = [&](int h, int t, char *stage) {
+        char *dst = stage + (h ? OFF_A1 : OFF_A0) + wave * 1024;
+        const char *s = wsrc + (int64_t)t * 128 + (h ? wrow64 : 0);
+        glds16(s, dst);
+        glds16(s + 2 * wrow64, dst + 8192);
+    };
+    // stage half-tile B^h of the K-tile whose tap is loaded in psrc/pok, channel step ci
+    auto stage_B = [&](int h, int ci, char *stage) {
+        char *dst = stage + (h ? OFF_B1 : OFF_B0) + wave * 1024;
+        const int cbyte = ci * 128;
+        const char *z = zeros + chunk * 16;
+        glds16(((pok >> (2 * h)) & 1) ? psrc[2 * h] + cbyte : z, dst);
+        glds16(((pok >> (2 * h + 1)) & 1) ? psrc[2 * h + 1] + cbyte : z, dst + 8192);
+    };
+
+    // ---- accumulators: acc[a][i][b][j]: channels wr*128 + a*64 + i*16.., pixels wc*64 + b*32 + j*16.. ----
+    f32x4 acc[2][4][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    // fragment byte offsets inside a half-tile: row (base + 16 t + frow), chunk (4 ks + fq) ^ (row & 7)
+    const int fo0 = frow * 128 + ((fq ^ (lane & 7)) << 4);
+    const int fo1 = frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    const int a_off = wr * 64 * 128;               // this wave's 64 rows inside A^h
+    const int b_off = wc * 32 * 128;               // this wave's 32 rows inside B^h
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+
+#define LOAD_A(stage, h)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+        fa[i][0] = *(const bf16x8 *)((stage) + ((h) ? OFF_A1 : OFF_A0) + a_off + i * 2048 + fo0); \
+        fa[i][1] = *(const bf16x8 *)((stage) + ((h) ? OFF_A1 : OFF_A0) + a_off + i * 2048 + fo1); \
+    }
+#define LOAD_B(dstf, stage, h)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+        dstf[j][0] = *(const bf16x8 *)((stage) + ((h) ? OFF_B1 : OFF_B0) + b_off + j * 2048 + fo0); \
+        dstf[j][1] = *(const bf16x8 *)((stage) + ((h) ? OFF_B1 : OFF_B0) + b_off + j * 2048 + fo1); \
+    }
+#define MFMA_QUAD(a, b, fbx)                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
+                acc[a][i][b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fbx[j][ks],  \
+                                                                          acc[a][i][b][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- prologue: K-tile 0 whole, K-tile 1 minus A^1 (which phase 0 of tile 0 stages) ---------------
+    char *const st0 = smem, *const st1 = smem + STAGE;
+    int tap2 = 0, ci2 = 0;                         // (tap, channel step) of the K-tile the B stager is at
+    tap_sources(0);
+    stage_A(0, 0, st0);
+    stage_B(0, 0, st0);
+    stage_A(1, 0, st0);
+    stage_B(1, 0, st0);
+    auto advance2 = [&]() {                        // move the B stager to the next K-tile
+        if (++ci2 == nc) {
+            ci2 = 0;
+            ++tap2;
+            tap_sources(tap2);
+        }
+    };
+    if (T > 1) {
+        advance2();
+        stage_B(0, ci2, st1);
+        stage_A(0, 1, st1);
+        stage_B(1, ci2, st1);
+        WAIT_VMCNT(6);
+    } else {
+        WAIT_VMCNT(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();     // the second wave row runs one barrier behind
+
+    // ---- main loop: 4 phases per K-tile -----------------------------------------------------------------
+    for (int t = 0; t < T; ++t) {
+        char *cur = smem + (t & 1) * STAGE;        // K-tile t (and the target of K-tile t + 2)
+        char *nxt = smem + ((t + 1) & 1) * STAGE;  // K-tile t + 1
+        const bool s1 = t + 1 < T, s2 = t + 2 < T;
+
+        // phase 0: B-sub0 + A-sub0 reads; stage A^1(t+1)
+        LOAD_B(fb0, cur, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD_A(cur, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s1) stage_A(1, t + 1, nxt);
+        WAIT_LGKMCNT(8);                           // the four B reads (issued first) have returned: B^0 may be restaged next phase
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKMCNT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(0, 0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // phase 1: B-sub1 reads; stage B^0(t+2)
+        LOAD_B(fb1, cur, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2) {
+            advance2();
+            stage_B(0, ci2, cur);
+        }
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKMCNT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(0, 1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // phase 2: A-sub1 reads; stage A^0(t+2)
+        LOAD_A(cur, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2) stage_A(0, t + 2, cur);
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKMCNT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(1, 1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // phase 3: no reads (B-sub0 is still in registers); stage B^1(t+2); K-tile t+1 must have landed
+        if (s2) {
+            stage_B(1, ci2, cur);
+            WAIT_VMCNT(6);
+        } else {
+            WAIT_VMCNT(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(1, 0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();     // rejoin the wave rows
+
+    // ---- epilogue --------------------------------------------------------------------------------------
+    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
+    const int cout_store = glu ? p.Cout / 2 : p.Cout;
+    char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
+    const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
+    const int nw = n0 + wr * 128;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
+            if (m >= M) continue;
+            const ConvOutPix op = conv_out_pix(p, m);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (glu && (i & 1)) continue;
+                    const int i2 = (i + 1 < 4) ? i + 1 : i;
+                    conv_epilogue_tile<false>(p, yb, rb, glu, cout_store, acc[a][i][b][j], acc[a][i2][b][j],
+                                              nw + a * 64 + i * 16, fq, op);
+                }
+        }
+}
+
+}  // namespace
+
+// called by onedc_conv_gemm (gemm_conv.hip) for the shapes this tile suits; same contract
+int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        hipFuncSetAttribute((const void *)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        configured = true;
+    }
+    const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
+    if (M64 > 0x7fffffff) return -1;
+    const int M = (int)M64;
+    const int tiles_n = (p.Cout + 255) / 256;
+    const int tiles_m = (M + 255) / 256;
+    const int Ktot = p.KH * p.KW * p.Cin;
+    dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
+    hipLaunchKernelGGL(conv_gemm256_kernel, grid, dim3(512), 2 * STAGE, st, p, tiles_n, tiles_m, M, Ktot);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}

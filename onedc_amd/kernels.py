@@ -25,7 +25,7 @@ class ConvParams(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32),
         ("epi", C.c_int32), ("out_f32", C.c_int32), ("pixel_shuffle", C.c_int32),
         ("alpha", _F), ("slope", _F),
-        ("batch", C.c_int32),
+        ("batch", C.c_int32), ("tile", C.c_int32), ("in_f32", C.c_int32),
         ("x_bs", _L), ("w_bs", _L), ("y_bs", _L), ("r_bs", _L),
     ]
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "onedc_conv_gemm": (_I, [C.POINTER(ConvParams), _P]),
     "onedc_direct_conv": (_I, [C.POINTER(DirectConvParams), _P]),
     "onedc_dwconv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_dwconv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_gn_chunks": (_I, [_I]),
     "onedc_gn_stats": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_scale_shift_act": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -155,8 +156,10 @@ def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
 PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then bracketed by HIP events
 
 
-def conv_tile(cout, glu):
+def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0):
     """The tile instantiation onedc_conv_gemm picks (mirrors the dispatcher in gemm_conv.hip)."""
+    if tile != 128 and cout % 256 == 0 and (((cout // 256) * blocks_m256 >= 160 and ktiles >= 8) or tile == 256):
+        return "256x256"
     if cout <= 16 and not glu:
         return "16x256"
     if cout % 128 != 0 and cout % 128 <= 64:
@@ -165,7 +168,8 @@ def conv_tile(cout, glu):
 
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
-              pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0):
+              pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0,
+              tile=0):
     """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None."""
     p = ConvParams()
     p.x, p.w, p.bias, p.res, p.y = x.ptr, w.data_ptr(), _ptr(bias), (res.ptr if res is not None else None), y.ptr
@@ -185,6 +189,10 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     p.KH = p.KW = KH
     p.stride, p.pad, p.up = stride, KH // 2, up
     p.epi, p.out_f32, p.pixel_shuffle = epi, int(y.f32), pixel_shuffle
+    p.in_f32 = int(x.f32)
+    p.tile = tile
+    if x.f32 and (w.dtype != torch.float32 or not y.f32 or (res is not None and not res.f32)):
+        raise KernelError("f32 conv_gemm needs f32 weights, output and residual")
     p.alpha, p.slope = alpha, slope
     p.batch, p.x_bs, p.w_bs, p.y_bs, p.r_bs = batch, x_bs, w_bs, y_bs, r_bs
     if PROFILE is None:
@@ -195,7 +203,8 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
     e1.record()
     flops = 2.0 * p.B * p.OH * p.OW * p.Cout * (p.KH * p.KW * p.Cin) * max(batch, 1) * flop_scale
-    PROFILE.append((conv_tile(p.Cout, glu), flops, e0, e1))
+    bm = (p.B * p.OH * p.OW + 255) // 256 * max(batch, 1)
+    PROFILE.append(("f32_128x128" if p.in_f32 else conv_tile(p.Cout, glu, bm, tile, p.KH * p.KW * (p.Cin // 64)), flops, e0, e1))
     return y
 
 
@@ -210,6 +219,10 @@ def direct_conv(x, w, bias, y, *, K, epi=EPI_LINEAR, slope=0.01, in_scale=1.0):
 
 
 def dwconv3x3(x, w, bias, y):
+    if x.f32:
+        _ok(lib().onedc_dwconv3x3_f32(x.ptr, w.data_ptr(), _ptr(bias), y.ptr, x.B, x.H, x.W, x.C, x.cs, x.co,
+                                      y.cs, y.co, stream()), "onedc_dwconv3x3_f32")
+        return y
     _ok(lib().onedc_dwconv3x3(x.ptr, w.data_ptr(), _ptr(bias), y.ptr, x.B, x.H, x.W, x.C, x.cs, x.co,
                               y.cs, y.co, stream()), "onedc_dwconv3x3")
     return y

@@ -42,8 +42,9 @@ class Conv:
     """nn.Conv2d / nn.Linear as one implicit-GEMM launch."""
 
     def __init__(self, sd, name, device, *, perm=None, glu=False, shuffle=False, weight=None, bias=None,
-                 flop_scale=1.0):
+                 flop_scale=1.0, f32=False):
         self.flop_scale = flop_scale          # < 1 when rows/cols are zero padding (padded heads)
+        self.f32 = f32                        # exact-f32 path: f32 weights, activations, output
         w = sd[f"{name}.weight"] if weight is None else weight
         b = sd.get(f"{name}.bias") if bias is None and weight is None else bias
         self.k = w.shape[2] if w.dim() == 4 else 1
@@ -53,7 +54,7 @@ class Conv:
             perm = pack.glu_perm(self.cout // 2)
         elif shuffle:
             perm = pack.shuffle_perm(self.cout)
-        self.w = pack.pack_matrix(m, device, perm)
+        self.w = pack.pack_matrix(m, device, perm, torch.float32 if f32 else torch.bfloat16)
         self.b = pack.f32(b, device, perm)
         self.glu, self.shuffle = glu, shuffle
 
@@ -71,10 +72,13 @@ class Conv:
             if self.shuffle:
                 c //= 4
                 oh, ow = 2 * oh, 2 * ow
-            y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if out_f32 else torch.bfloat16)
+            y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else torch.bfloat16)
         return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
                            alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
                            Cout=self.cout, flop_scale=self.flop_scale)
+
+
+_Conv = Conv
 
 
 class GroupNorm:
@@ -90,7 +94,9 @@ class GroupNorm:
 
 
 class DepthConvBlock4:
-    def __init__(self, sd, p, device):
+    def __init__(self, sd, p, device, f32=False):
+        self.f32 = f32
+        Conv = lambda *a, **k: _Conv(*a, f32=f32, **k)          # noqa: E731
         self.conv1 = Conv(sd, f"{p}.block.0.conv1.0", device)
         w = sd[f"{p}.block.0.depth_conv.weight"]                       # (C,1,3,3) -> [9][C]
         self.dw_w = w[:, 0].permute(1, 2, 0).reshape(9, -1).float().contiguous().to(device)
@@ -103,14 +109,16 @@ class DepthConvBlock4:
     def __call__(self, x, y=None, out_f32=False):
         identity = self.adaptor(x) if self.adaptor is not None else x
         t = self.conv1(x, epi=EPI_LEAKY, slope=0.01)
-        t2 = K.dwconv3x3(t, self.dw_w, self.dw_b, new_view(t.B, t.H, t.W, t.C, t.t.device))
+        t2 = K.dwconv3x3(t, self.dw_w, self.dw_b,
+                         new_view(t.B, t.H, t.W, t.C, t.t.device, torch.float32 if self.f32 else torch.bfloat16))
         h = self.conv2(t2, res=identity)
         u = self.ffn_in(h, epi=EPI_GLU_LEAKY)
         return self.ffn_out(u, y, res=h, out_f32=out_f32)
 
 
 class ResidualBlockUpsample:
-    def __init__(self, sd, p, device):
+    def __init__(self, sd, p, device, f32=False):
+        Conv = lambda *a, **k: _Conv(*a, f32=f32, **k)          # noqa: E731
         self.subpel = Conv(sd, f"{p}.subpel_conv.0", device, shuffle=True)
         self.conv = Conv(sd, f"{p}.conv", device)
         self.upsample = Conv(sd, f"{p}.upsample.0", device, shuffle=True)

@@ -38,11 +38,11 @@ def _pad_rows(m):
     return m
 
 
-def pack_matrix(w2d, device, row_perm=None):
-    """[rows][K] f32 -> padded bf16 on `device`."""
+def pack_matrix(w2d, device, row_perm=None, dtype=torch.bfloat16):
+    """[rows][K] f32 -> padded bf16 (or f32 for the exact-f32 prior path) on `device`."""
     if row_perm is not None:
         w2d = w2d[row_perm]
-    return _pad_rows(w2d.contiguous()).to(torch.bfloat16).to(device).contiguous()
+    return _pad_rows(w2d.contiguous()).to(dtype).to(device).contiguous()
 
 
 def conv_matrix(w):

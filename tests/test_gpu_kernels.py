@@ -268,3 +268,169 @@ def test_window_partition_round_trip():
     K.window_partition(v.t, e, 2, 32, 48, 64, 16, region=(16, 32, 16, 16), win_hw=(16, 8))
     ref = x[:, :, 16:32, 32:48].reshape(2, 64, 1, 16, 2, 8).permute(0, 2, 4, 3, 5, 1).reshape(4, 128, 64)
     assert torch.equal(e[:4 * 128 * 64].view(4, 128, 64).float().cpu(), ref)
+
+
+# ---- exact-f32 path (prior networks): v_mfma_f32_16x16x4_f32, tolerance 2e-6 rel. RMS vs fp64 ----------
+def _f64_conv(x, w, b, **kw):
+    return F.conv2d(x.double(), w.double(), None if b is None else b.double(), **kw)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (2, 12, 12, 128, 128, 1),
+    (1, 9, 7, 96, 256, 3),        # Cin = 3 x 32, odd spatial size
+    (3, 8, 8, 256, 512, 1),
+])
+def test_conv_gemm_f32_exact(B, H, W, Cin, Cout, k):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, H, W, generator=g)
+    y = new_view(B, H, W, Cout, DEV, torch.float32)
+    K.conv_gemm(from_nchw(x.to(DEV), torch.float32), pack.pack_matrix(pack.conv_matrix(w), DEV, None, torch.float32),
+                b.to(DEV), y, KH=k, epi=K.EPI_LEAKY, slope=0.01, res=from_nchw(r.to(DEV), torch.float32))
+    ref = F.leaky_relu(_f64_conv(x, w, b, padding=k // 2), 0.01) + r.double()
+    close(y.torch_nchw(), ref, rms=2e-6, mx=2e-6, what="f32 conv")
+
+
+def test_conv_gemm_f32_glu_and_shuffle():
+    g = torch.Generator().manual_seed(22)
+    B, H, W, C = 2, 6, 10, 128
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(4 * C, C, 1, 1, generator=g) * C ** -0.5
+    b = torch.randn(4 * C, generator=g)
+    xv = from_nchw(x.to(DEV), torch.float32)
+    perm = pack.glu_perm(2 * C)
+    y = new_view(B, H, W, 2 * C, DEV, torch.float32)
+    K.conv_gemm(xv, pack.pack_matrix(pack.conv_matrix(w), DEV, perm, torch.float32), b[perm].to(DEV), y, KH=1,
+                epi=K.EPI_GLU_LEAKY)
+    t = _f64_conv(x, w, b)
+    close(y.torch_nchw(), F.leaky_relu(t[:, :2 * C], 0.1) + F.leaky_relu(t[:, 2 * C:], 0.01), rms=2e-6, mx=2e-6,
+          what="f32 glu")
+    perm = pack.shuffle_perm(4 * C)
+    y = new_view(B, 2 * H, 2 * W, C, DEV, torch.float32)
+    K.conv_gemm(xv, pack.pack_matrix(pack.conv_matrix(w), DEV, perm, torch.float32), b[perm].to(DEV), y, KH=1,
+                pixel_shuffle=1)
+    close(y.torch_nchw(), F.pixel_shuffle(t, 2), rms=2e-6, mx=2e-6, what="f32 pixel shuffle")
+
+
+def test_conv_gemm_f32_batch_invariant():
+    """Image 1 alone == image 1 inside a batch of 5, bit for bit (fixed k order, no split-K)."""
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(5, 256, 12, 12, generator=g)
+    w = pack.pack_matrix(torch.randn(256, 256, generator=g) / 16, DEV, None, torch.float32)
+    y5 = new_view(5, 12, 12, 256, DEV, torch.float32)
+    y1 = new_view(1, 12, 12, 256, DEV, torch.float32)
+    K.conv_gemm(from_nchw(x.to(DEV), torch.float32), w, None, y5, KH=1)
+    K.conv_gemm(from_nchw(x[1:2].to(DEV), torch.float32), w, None, y1, KH=1)
+    assert torch.equal(y5.torch_nchw()[1:2], y1.torch_nchw())
+
+
+def test_dwconv3x3_f32():
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(2, 128, 9, 11, generator=g)
+    w = torch.randn(128, 1, 3, 3, generator=g) / 3
+    b = torch.randn(128, generator=g)
+    y = new_view(2, 9, 11, 128, DEV, torch.float32)
+    K.dwconv3x3(from_nchw(x.to(DEV), torch.float32), w[:, 0].permute(1, 2, 0).reshape(9, -1).contiguous().to(DEV),
+                b.to(DEV), y)
+    close(y.torch_nchw(), _f64_conv(x, w, b, padding=1, groups=128), rms=1e-6, mx=1e-6, what="f32 dwconv")
+
+
+# ---- the entropy-parameter head: integer decisions, bit-exact against the oracle's formulas ----------------
+def test_prior_indexes_and_update_match_oracle_exactly():
+    """build_indexes (entropy_models.py:355-362) over the whole scale range incl. the clamps, and the
+    four-part mask / combine_for_writing geometry (compression_model.py:241-301): the int16 index planes
+    and the decoder-side y_hat update must equal the oracle's for identical f32 parameters.
+    (logf differs from torch's in the last ulp for a few inputs: <= 2e-5 of the positions may differ by 1.)"""
+    from oracle import torch_ref as R
+    B, N, H, W = 2, 128, 6, 10
+    g = torch.Generator().manual_seed(50)
+    scales = torch.exp(torch.rand(B, N, H, W, generator=g) * 9 - 4)            # 0.018 .. 148: both clamps hit
+    scales[0, :, 0, 0] = 0.0
+    scales[0, :, 0, 1] = -1.0
+    means = torch.randn(B, N, H, W, generator=g) * 3
+    params = torch.cat([scales, means], 1)
+    pv = from_nchw(params.to(DEV), torch.float32)
+    masks = R.four_part_masks(B, N, H, W)
+    n = (N // 4) * H * W
+    idx_dev = torch.empty(B * n, dtype=torch.int16, device=DEV)
+    y_hat = new_view(B, H, W, N, DEV, torch.float32)
+    ref_hat = None
+    bad = 0
+    for k in range(4):
+        K.prior_indexes(pv, idx_dev, B, H, W, N, k)
+        ref = R.build_indexes(R.combine_for_writing(scales * masks[k])).to(torch.int16)
+        got = idx_dev.view(B, N // 4, H, W).cpu()
+        d = (got.int() - ref.int()).abs()
+        assert int(d.max()) <= 1
+        bad += int((d != 0).sum())
+        sym = torch.randint(-40, 41, (B, N // 4, H, W), generator=g).to(torch.int16)
+        K.prior_update_dec(pv, sym.to(DEV).reshape(-1), y_hat, k)
+        cur = (torch.cat([sym.float()] * 4, 1) + means) * masks[k]
+        ref_hat = cur if k == 0 else ref_hat + cur
+    assert bad <= 2e-5 * 4 * B * n + 1, bad
+    assert torch.equal(y_hat.torch_nchw().cpu(), ref_hat)
+
+
+# ---- the 256 x 256-tile, 8-phase kernel (forced with tile=256) against the same references ---------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (2, 16, 16, 64, 256, 1),      # one K-tile (prologue/tail only)
+    (2, 16, 16, 128, 256, 1),     # two K-tiles
+    (1, 24, 20, 192, 256, 3),     # 27 K-tiles (odd), ragged M (480 pixels), halo rows
+    (2, 12, 12, 256, 512, 3),     # two channel tiles
+    (3, 9, 7, 320, 256, 1),       # 5 K-tiles, M = 189 < one tile
+])
+def test_conv_gemm256_plain(B, H, W, Cin, Cout, k):
+    x, w, b = rnd(B, Cin, H, W, seed=61), rnd(Cout, Cin, k, k, seed=62, scale=(Cin * k * k) ** -0.5), rnd(Cout, seed=63)
+    y = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=k, tile=256)
+    close(y.torch_nchw(), F.conv2d(x, w, b, padding=k // 2), what="conv256")
+    # same bits as the 128-wide kernel?  Both accumulate each output in the same k order (fixed, no split-K)
+    y2 = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y2, KH=k, tile=128)
+    assert torch.equal(y.torch_nchw(), y2.torch_nchw())
+
+
+def test_conv_gemm256_stride_up_shuffle_glu_residual():
+    x, w, b = rnd(2, 128, 16, 12, seed=64), rnd(256, 128, 3, 3, seed=65, scale=1 / 34), rnd(256, seed=66)
+    xv = from_nchw(x.to(DEV))
+    y = new_view(2, 8, 6, 256, DEV)
+    K.conv_gemm(xv, packed(w), b.to(DEV), y, KH=3, stride=2, tile=256)
+    close(y.torch_nchw(), F.conv2d(x, w, b, stride=2, padding=1), what="256 stride2")
+    y = new_view(2, 32, 24, 256, DEV)
+    r = rnd(2, 256, 32, 24, seed=67)
+    K.conv_gemm(xv, packed(w), b.to(DEV), y, KH=3, up=1, tile=256, res=from_nchw(r.to(DEV)), epi=K.EPI_SILU)
+    close(y.torch_nchw(), F.silu(F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)) + r,
+          what="256 up+silu+res")
+    # pixel shuffle
+    w1, b1 = rnd(512, 128, 1, 1, seed=68, scale=128 ** -0.5), rnd(512, seed=69)
+    perm = pack.shuffle_perm(512)
+    y = new_view(2, 32, 24, 128, DEV)
+    K.conv_gemm(xv, packed(w1, perm), b1[perm].to(DEV), y, KH=1, pixel_shuffle=1, tile=256)
+    close(y.torch_nchw(), F.pixel_shuffle(F.conv2d(x, w1, b1), 2), what="256 pixel shuffle")
+    # GLU (ConvFFN3) and GEGLU
+    perm = pack.glu_perm(256)
+    t = F.conv2d(x, w1, b1)
+    y = new_view(2, 16, 12, 256, DEV)
+    K.conv_gemm(xv, packed(w1, perm), b1[perm].to(DEV), y, KH=1, epi=K.EPI_GLU_LEAKY, tile=256)
+    close(y.torch_nchw(), F.leaky_relu(t[:, :256], 0.1) + F.leaky_relu(t[:, 256:], 0.01), what="256 glu")
+    K.conv_gemm(xv, packed(w1, perm), b1[perm].to(DEV), y, KH=1, epi=K.EPI_GEGLU, tile=256)
+    close(y.torch_nchw(), t[:, :256] * F.gelu(t[:, 256:]), what="256 geglu")
+
+
+def test_conv_gemm256_race_screen():
+    """The prefetch pipeline leaves DMA in flight across barriers: a misplaced wait shows up as rare
+    wrong tiles.  Same launch 40 times on a shape with many K-tiles and many workgroups: identical bits."""
+    x, w = rnd(4, 256, 48, 48, seed=70), rnd(512, 256, 3, 3, seed=71, scale=1 / 48)
+    xv, wp = from_nchw(x.to(DEV)), packed(w)
+    ref = None
+    for it in range(40):
+        y = new_view(4, 48, 48, 512, DEV)
+        K.conv_gemm(xv, wp, None, y, KH=3, tile=256)
+        got = y.t[:4 * 48 * 48 * 512].clone()
+        if ref is None:
+            ref = got
+            close(y.torch_nchw(), F.conv2d(x, w, None, padding=1), what="256 race ref")
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"

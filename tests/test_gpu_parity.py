@@ -48,7 +48,14 @@ def codec_sd():
 
 @pytest.fixture(scope="module")
 def codec(codec_sd):
-    m = IntraNoAR(codec_sd, DEV)
+    m = IntraNoAR(codec_sd, DEV)          # default: prior networks in exact f32
+    m.update(force=True)
+    return m
+
+
+@pytest.fixture(scope="module")
+def codec_bf16(codec_sd):
+    m = IntraNoAR(codec_sd, DEV, prior_f32=False)
     m.update(force=True)
     return m
 
@@ -78,19 +85,32 @@ def test_hyper_decoder_and_prior_params(codec, codec_sd):
     idx = torch.from_numpy(g["indices"]).to(DEV)
     fused, z_sem = codec._params_from_indices(idx)
     check(z_sem.torch_nchw(), torch.from_numpy(g["z_semantic"]), 4e-3, "z_semantic vs reference golden")
-    check(fused.torch_nchw(), torch.from_numpy(g["fused"]), 2e-2, "prior params vs reference golden")
+    # the prior networks run in exact f32 (f32 MFMA): tol 1e-5 rel. RMS against the reference's fp32 CPU result
+    check(fused.torch_nchw(), torch.from_numpy(g["fused"]), 1e-5, "prior params (f32 path) vs reference golden")
     with torch.no_grad():
         ref, _ = R.z_indices_to_params(codec_sd, torch.from_numpy(g["indices"]))
-    check(fused.torch_nchw(), ref, 2e-2, "prior params vs oracle")
+    check(fused.torch_nchw(), ref, 1e-5, "prior params (f32 path) vs oracle")
 
 
-def test_entropy_round_trip_and_oracle_agreement(codec, codec_sd, gaussian_tables):
+def test_prior_params_bf16_mode(codec_bf16, codec_sd):
+    """prior_f32=False (the reference's GPU-autocast precision): bf16 tolerance 2e-2."""
+    g = golden("g5_codec_path.npz")
+    fused, _ = codec_bf16._params_from_indices(torch.from_numpy(g["indices"]).to(DEV))
+    check(fused.torch_nchw(), torch.from_numpy(g["fused"]), 2e-2, "prior params (bf16 mode) vs reference golden")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_entropy_round_trip_and_oracle_agreement(mode, codec, codec_bf16, codec_sd, gaussian_tables):
     """encode_latents -> container -> decode: y_hat must come back BIT-EXACT (integer path), for
     a ragged batch size, and image 1 alone must give the same bytes as inside the batch.
     Against the fp32 oracle the quantised latent can only differ by rounding flips
-    (y_hat = round(y - mu) + mu with mu from bf16 matrix products): tol |delta| <= 1.25 everywhere,
-    mean |delta| <= 0.25, stream size within 3 %.  The flip rate itself is reported, not asserted:
-    it is a property of bf16 prior nets (the reference's GPU autocast path has it too)."""
+    (y_hat = round(y - mu) + mu):
+      f32 prior nets (default): a seed flip needs y - mu within ~1e-6 of a half-integer (about one per
+      1e5 symbols, measured by test_prior_steps_teacher_forced) but then changes the next steps'
+      parameters in its neighbourhood, so free-running flips are asserted <= 2 %, stream size within 0.5 %;
+      bf16 prior nets: flips are a property of bf16 matrix products (reported; the reference's GPU
+      autocast path has them too), |delta| <= 1.25 everywhere, stream size within 3 %."""
+    codec = codec if mode == "f32" else codec_bf16
     g = golden("g5_codec_path.npz")
     B = 3
     rng = np.random.default_rng(5)
@@ -106,8 +126,7 @@ def test_entropy_round_trip_and_oracle_agreement(codec, codec_sd, gaussian_table
     from onedc_amd.entropy.utils import decode_i, unpack_indices
     infos = [decode_i(b, 14, 64) for b in blobs]
     y_hat_dec, _ = codec.decompress([d["bit_stream_y"] for d in infos], idx)
-    n = B * H * W * 128
-    assert torch.equal(y_hat_dec.t[:n], y_hat_enc.t[:n]), "decoder did not reproduce the encoder's y_hat"
+    assert torch.equal(y_hat_dec.torch_nchw(), y_hat_enc.torch_nchw()), "decoder did not reproduce the encoder's y_hat"
     assert np.array_equal(np.stack([unpack_indices(d["bit_stream_z"], 6, 14) for d in infos]).reshape(B, 2, 3),
                           idx.cpu().numpy())
     # batch invariance of the whole entropy path: image 1 alone gives the same bytes
@@ -125,13 +144,60 @@ def test_entropy_round_trip_and_oracle_agreement(codec, codec_sd, gaussian_table
     frac = float((diff > 0.5).float().mean())
     print(f"[parity] y_hat rounding flips vs oracle: {frac:.4%}, max |delta| = {float(diff.max()):.3f}, "
           f"mean |delta| = {float(diff.mean()):.4f}")
-    assert float(diff.max()) <= 1.25 and float(diff.mean()) <= 0.25
+    assert float(diff.max()) <= 1.25
+    if mode == "f32":
+        assert frac <= 2e-2, frac
     bits_ref = sum(len(rans_port.encode(sym_ref[b].reshape(-1),
                                         torch.stack([R.build_indexes(s[b:b + 1]) for s in s_w]).to(torch.int16).numpy().reshape(-1),
                                         rans_port.Tables(*gaussian_tables))) for b in range(B))
     bits_got = sum(len(d["bit_stream_y"]) for d in infos)
     print(f"[parity] y stream bytes: product {bits_got}, oracle {bits_ref} ({bits_got / bits_ref - 1:+.3%})")
-    assert abs(bits_got / bits_ref - 1) <= 0.03
+    assert abs(bits_got / bits_ref - 1) <= (5e-3 if mode == "f32" else 0.03)
+
+
+def test_prior_steps_teacher_forced(codec, codec_sd):
+    """The four prior steps one at a time, each fed the ORACLE's y_hat_so_far (so one early rounding
+    flip cannot cascade): parameters within 1e-5 rel. RMS of the fp32 oracle, and the integer decisions
+    taken from them -- symbols round((y - mu) m) and rANS table indexes (build_indexes,
+    entropy_models.py:355-362) -- equal to the oracle's except for <= 5e-4 of the positions (a 1e-6
+    relative difference of sigma moves (ln sigma - ln 0.11)/0.025 by 4e-5: ~1e-4 of the truncations flip)."""
+    B, N = 3, 128
+    rng = np.random.default_rng(15)
+    idx = torch.from_numpy(rng.integers(0, 16384, (B, 2, 3)).astype(np.int32))
+    with torch.no_grad():
+        fused_ref, _ = R.z_indices_to_params(codec_sd, idx)
+        common = R.conv(codec_sd, "y_spatial_prior_reduction", fused_ref)
+    H, W = fused_ref.shape[2:]
+    y = fused_ref[:, N:] + 3.0 * torch.randn(B, N, H, W, generator=torch.Generator().manual_seed(16))
+    masks = R.four_part_masks(B, N, H, W)
+    fused, _ = codec._params_from_indices(idx.to(DEV))
+    common_cat, y_hat = codec._prior_setup(fused)
+    n = (N // 4) * H * W
+    idx_dev = torch.empty(B * n, dtype=torch.int16, device=DEV)
+    yhs = None
+    bad_sym = bad_idx = total = 0
+    for k in range(4):
+        if k == 0:
+            params_ref, params = fused_ref, fused
+        else:
+            with torch.no_grad():
+                params_ref = torch.cat(R._prior_step(codec_sd, k, yhs, common), 1)
+            y_hat.t[:B * H * W * y_hat.cs].view(B, H, W, y_hat.cs)[..., :N] = yhs.permute(0, 2, 3, 1).to(DEV)
+            params = codec._next_params(k, y_hat, common_cat)
+        got = params.torch_nchw().cpu()
+        check(got, params_ref, 1e-5, f"prior params step {k} (teacher forced)")
+        m = masks[k]
+        sym_ref = torch.round((y - params_ref[:, N:] * m) * m)
+        sym_got = torch.round((y - got[:, N:] * m) * m)
+        bad_sym += int((sym_ref != sym_got).sum())
+        K.prior_indexes(params, idx_dev, B, H, W, N, k)
+        idx_ref = R.build_indexes(R.combine_for_writing(params_ref[:, :N] * m)).to(torch.int16)
+        bad_idx += int((idx_dev.view(B, N // 4, H, W).cpu() != idx_ref).sum())
+        total += B * n
+        cur = sym_ref + params_ref[:, N:] * m
+        yhs = cur if k == 0 else yhs + cur
+    print(f"[parity] teacher-forced decisions: {bad_sym} symbol and {bad_idx} index mismatches in {total}")
+    assert total == 4 * B * n and bad_sym <= 5e-4 * total and bad_idx <= 5e-4 * total
 
 
 def test_z_only_prior(codec, codec_sd):
@@ -141,8 +207,8 @@ def test_z_only_prior(codec, codec_sd):
     with torch.no_grad():
         fused_ref, _ = R.z_indices_to_params(codec_sd, idx)
         ref = R.recon_with_z_four_part_prior(codec_sd, fused_ref)
-    check(y_hat.torch_nchw(), ref, 3e-2, "z-only y_hat vs oracle")
-    check(y_hat.torch_nchw(), torch.from_numpy(g["y_hat_zonly"]), 3e-2, "z-only y_hat vs reference golden")
+    check(y_hat.torch_nchw(), ref, 1e-5, "z-only y_hat (f32 prior) vs oracle")
+    check(y_hat.torch_nchw(), torch.from_numpy(g["y_hat_zonly"]), 1e-5, "z-only y_hat (f32 prior) vs reference golden")
 
 
 def test_semantic_adaptor_and_synthesis(codec, codec_sd):
