@@ -192,6 +192,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel": ("conv_gemm256_kernel" if dom == "256x256" else
+                                    "conv_gemm128x256_kernel" if dom == "128x256" else
                                     f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
                                     + (" f32" if dom.startswith("f32") else "")),
                          "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.steps * 1e3, 2),

@@ -87,10 +87,10 @@ class Decoder:
         y = self.t1(self.t0(y_hat))
         for r in self.res_a:
             y = r(y, ws)
-        y = self.up_b(self.up_a(y))
+        y = self.up_b(self.up_a(y), stats=True)
         # torch.cat([y, sem], dim=1) without a copy: both branches write their last layer into
         # channel slices of one buffer
-        cat = new_view(y.B, y.H, y.W, 2 * y.C, dev)
+        cat = new_view(y.B, y.H, y.W, 2 * y.C, dev, stats=True)
         for i, r in enumerate(self.res_b):
             y = r(y, ws, cat.slice(0, y.C) if i == 2 else None)
         s = self.s3(self.s2(self.s1(self.s0(sem_hat))))

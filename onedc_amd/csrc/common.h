@@ -28,7 +28,10 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; the result is stored as bf16 or feeds one)
+__device__ __forceinline__ float silu_f(float v) {
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
 static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }

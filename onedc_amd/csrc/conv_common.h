@@ -37,16 +37,18 @@ __device__ __forceinline__ ConvOutPix conv_out_pix(const onedc_conv_params &p, i
 // Epilogue of one 16x16 MFMA accumulator tile as held by one lane: 4 consecutive packed weight rows
 // (nrow16 + 4*fq + e, e = 0..3) of one pixel.  accg is the gate tile of a GLU pair (ignored otherwise).
 //   v = act(alpha*acc + bias) [+ residual]  ->  bf16 / f32 store, optional pixel-shuffle scatter.
+// ssum / ssq: running sum and sum of squares of the four stored values (GroupNorm statistics of the
+// consumer, see conv_stats_store); untouched when the lane stores nothing.
 template <bool F32>
 __device__ __forceinline__ void conv_epilogue_tile(const onedc_conv_params &p, char *yb, const char *rb, bool glu,
                                                    int cout_store, const f32x4 &accv, const f32x4 &accg, int nrow16,
-                                                   int fq, const ConvOutPix &op) {
+                                                   int fq, const ConvOutPix &op, float &ssum, float &ssq) {
     const int nrow = nrow16 + fq * 4;              // packed weight row of element 0
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float t = accv[e] * p.alpha;
-        if (p.bias) t += p.bias[nrow + e];
+        if (p.bias && nrow < p.Cout) t += p.bias[nrow + e];      // rows past Cout are tile padding
         v[e] = t;
     }
     int n_out = nrow;
@@ -54,7 +56,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const onedc_conv_params &p, c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float g = accg[e] * p.alpha;
-            if (p.bias) g += p.bias[nrow + 16 + e];
+            if (p.bias && nrow + 16 < p.Cout) g += p.bias[nrow + 16 + e];
             v[e] = p.epi == ONEDC_EPI_GLU_LEAKY ? leaky(v[e], 0.1f) + leaky(g, 0.01f) : v[e] * gelu_f(g);
         }
         n_out = nrow16 / 2 + fq * 4;
@@ -97,6 +99,10 @@ __device__ __forceinline__ void conv_epilogue_tile(const onedc_conv_params &p, c
             for (int e = 0; e < 4 && n_out + e < cout_store; ++e) v[e] += bf2f(rp[e]);
         }
     }
+    if (p.stats) {
+        ssum += (v[0] + v[1]) + (v[2] + v[3]);
+        ssq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
     const int64_t yo = opix * p.y_cs + p.y_co + n_out;
     if (p.out_f32) {
         float *yp = (float *)yb + yo;
@@ -112,5 +118,26 @@ __device__ __forceinline__ void conv_epilogue_tile(const onedc_conv_params &p, c
         } else {
             for (int e = 0; e < 4 && n_out + e < cout_store; ++e) yp[e] = f2bf(v[e]);
         }
+    }
+}
+
+// GroupNorm statistics in the producer's epilogue.  A wave covers 64 consecutive output pixels and,
+// per 16-row accumulator tile, 4 x 4 consecutive channels ("quads", one per lane quarter fq).  After
+// the lane-local sums over the wave's pixel tiles, the 16 lanes of a quarter are reduced with four
+// butterfly steps and lane (fq, 0) stores (sum, sum of squares) to
+//     stats[(m_wave / 64) * (y_cs / 4) + (y_co + n_out) / 4]          (float2)
+// Fixed order, no atomics: every (64-pixel block, quad) has exactly one writer.  onedc_gn_from_stats
+// folds the quads of a group and the blocks of an image.  Requires OH*OW % 64 == 0 (a 64-pixel block
+// never straddles two images), y_co % 4 == 0, stored channels % 4 == 0, no pixel shuffle.
+__device__ __forceinline__ void conv_stats_store(const onedc_conv_params &p, float ssum, float ssq, int m_wave,
+                                                 int n_out, int cout_store, int lane, int M) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        ssum += __shfl_xor(ssum, o);
+        ssq += __shfl_xor(ssq, o);
+    }
+    if ((lane & 15) == 0 && n_out < cout_store && m_wave < M) {   // M % 64 == 0: a block is whole or absent
+        float2 *dst = (float2 *)p.stats + (int64_t)(m_wave >> 6) * (p.y_cs >> 2) + ((p.y_co + n_out) >> 2);
+        *dst = make_float2(ssum, ssq);
     }
 }

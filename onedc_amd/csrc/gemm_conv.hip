@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * ES : nullptr;
     const int nw = n0 + wn * T::WTN;               // first packed row of this wave
 
+    float ssum[T::FI], ssq[T::FI];
+#pragma unroll
+    for (int i = 0; i < T::FI; ++i) ssum[i] = ssq[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < T::FJ; ++j) {
         const int m = m0 + wm * T::WTM + j * 16 + frow;
@@ -204,7 +207,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         for (int i = 0; i < T::FI; ++i) {
             if (glu && (i & 1)) continue;          // odd tiles are the gate halves, consumed with their value tile
             const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
-            conv_epilogue_tile<F32>(p, yb, rb, glu, cout_store, acc[i][j], acc[i2][j], nw + i * 16, fq, op);
+            conv_epilogue_tile<F32>(p, yb, rb, glu, cout_store, acc[i][j], acc[i2][j], nw + i * 16, fq, op, ssum[i],
+                                    ssq[i]);
+        }
+    }
+    if (p.stats) {                                 // wave-uniform
+        static_assert(T::WTM == 64, "a wave covers one 64-pixel statistics block");
+#pragma unroll
+        for (int i = 0; i < T::FI; ++i) {
+            if (glu && (i & 1)) continue;
+            const int n_out = (glu ? (nw + i * 16) / 2 : nw + i * 16) + fq * 4;
+            conv_stats_store(p, ssum[i], ssq[i], m0 + wm * T::WTM, n_out, cout_store, lane, M);
         }
     }
 }
@@ -213,7 +226,7 @@ template <class T, bool F32 = false>
 int launch(const onedc_conv_params &p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipFuncSetAttribute((const void *)conv_gemm_kernel<T, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)conv_gemm_kernel<T, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * T::BUF);
         configured = true;
     }
@@ -231,7 +244,8 @@ int launch(const onedc_conv_params &p, hipStream_t st) {
 
 }  // namespace
 
-int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st);   // gemm_conv256.hip
+int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st);      // gemm_conv256.hip
+int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st);  // gemm_conv256.hip
 
 extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (!pp) return -1;
@@ -240,12 +254,15 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (p.Cin <= 0 || (p.Cin & (p.in_f32 ? 31 : 63)) || p.Cout <= 0) return -2;
     if ((p.x_cs | p.x_co) & (p.in_f32 ? 3 : 7)) return -3; // 16-byte aligned source chunks
     if (p.res && ((p.r_cs | p.r_co) & 3)) return -8;       // 8-byte (bf16) / 16-byte (f32) aligned residual reads
-    if (p.in_f32 && !p.out_f32) return -9;                 // the f32 path stays f32
+
     if (p.KH < 1 || p.KW < 1 || p.stride < 1 || p.OH < 1 || p.OW < 1 || p.B < 1) return -4;
     if (p.OW > 0xffff || p.OH > 0x7fff) return -5;
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     if (glu && (p.Cout & 31)) return -6;
     if (p.pixel_shuffle && ((p.Cout & 15) || glu)) return -7;
+    if (p.stats && (p.pixel_shuffle || ((p.OH * p.OW) & 63) || (p.y_co & 3) || (p.y_cs & 3) ||
+                    ((glu ? p.Cout / 2 : p.Cout) & 3) || p.batch > 1))
+        return -10;
     hipStream_t st = as_stream(stream);
     if (p.in_f32) return launch<Tile<128, 128, 2, 2>, true>(p, st);
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
@@ -254,6 +271,12 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);         // short K: prologue + epilogue of the one resident block dominate
     if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 8) || p.tile == 256))
         return onedc_conv_gemm256_launch(p, st);
+    // 128 x 256 tiles (8 waves, 3-deep LDS ring): channel counts that are whole 128-row tiles or waste < 20 %
+    const int rows128 = (p.Cout + 127) / 128 * 128;
+    const int64_t blocks128 = (rows128 / 128) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
+    if (p.tile != 128 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
+        ((blocks128 >= 160 && ktiles >= 6) || p.tile == 129))
+        return onedc_conv_gemm128x256_launch(p, st);
     if (p.Cout <= 16 && !glu) return launch<Tile<16, 256, 1, 4>>(p, st);
     if ((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) return launch<Tile<64, 128, 2, 2>>(p, st);
     return launch<Tile<128, 128, 2, 2>>(p, st);

@@ -249,6 +249,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
     const int nw = n0 + wr * 128;
+    float ssum[2][4], ssq[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ssum[a][i] = ssq[a][i] = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -263,9 +268,243 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
                     if (glu && (i & 1)) continue;
                     const int i2 = (i + 1 < 4) ? i + 1 : i;
                     conv_epilogue_tile<false>(p, yb, rb, glu, cout_store, acc[a][i][b][j], acc[a][i2][b][j],
-                                              nw + a * 64 + i * 16, fq, op);
+                                              nw + a * 64 + i * 16, fq, op, ssum[a][i], ssq[a][i]);
                 }
         }
+    if (p.stats) {                                 // wave-uniform
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (glu && (i & 1)) continue;
+                const int n16 = nw + a * 64 + i * 16;
+                conv_stats_store(p, ssum[a][i], ssq[a][i], m0 + wc * 64, (glu ? n16 / 2 : n16) + fq * 4, cout_store,
+                                 lane, M);
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// 128 channels x 256 pixels: the same machinery for layers whose channel count is not a multiple of
+// 256 (the VAE's 128-channel up block at full resolution, the UNet's 320/640-channel levels).
+// Waves 2 (channels) x 4 (pixels), wave tile 64 x 64 = 4 x 4 accumulator tiles; a K-tile is two phases
+// of 16 MFMAs (pixel halves); LDS holds a ring of THREE K-tiles of 48 KB (A, B^0, B^1), so a K-tile is
+// restaged two whole K-tiles ahead (every half-tile's last reader is >= 2 phases behind) and the loop's
+// only vector-memory wait is again one counted vmcnt(6) per K-tile.
+constexpr int STAGE3 = 3 * HALF;
+constexpr int O3_A = 0, O3_B0 = HALF, O3_B1 = 2 * HALF;
+
+__global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_conv_params p, int tiles_n,
+                                                                  int tiles_m, int M, int Ktot) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_m);
+    const int n0 = (logical % tiles_n) * 128;
+    const int m0 = (logical / tiles_n) * 256;
+
+    const char *xb = (const char *)p.x + (int64_t)blockIdx.z * p.x_bs * 2;
+    const char *wb = (const char *)p.w + (int64_t)blockIdx.z * p.w_bs * 2;
+    const char *zeros = (const char *)p.zeros;
+
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    const int t64 = wave * 8 + lrow;
+    const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;     // weight rows t64 and t64 + 64
+    const int64_t wrow64 = (int64_t)64 * Ktot * 2;
+    int pb[4], pyx[4];                             // [h * 2 + i]: pixel m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
+#pragma unroll
+    for (int hi = 0; hi < 4; ++hi) {
+        const int h = hi >> 1, i = hi & 1;
+        const int m = m0 + ((t64 >> 5) + 2 * i) * 64 + h * 32 + (t64 & 31);
+        if (m < M) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW;
+            pb[hi] = b;
+            pyx[hi] = (oy << 16) | (rem - oy * p.OW);
+        } else {
+            pb[hi] = 0;
+            pyx[hi] = -1;
+        }
+    }
+    const char *psrc[4];
+    unsigned pok = 0;
+    const int nc = p.Cin >> 6;
+    const int T = p.KH * p.KW * nc;
+
+    auto tap_sources = [&](int tap) {
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        pok = 0;
+#pragma unroll
+        for (int hi = 0; hi < 4; ++hi) {
+            const int oy = pyx[hi] >> 16, ox = pyx[hi] & 0xffff;
+            int iy = oy * p.stride + ky - p.pad;
+            int ix = ox * p.stride + kx - p.pad;
+            bool ok = pyx[hi] >= 0;
+            if (p.up) {
+                ok = ok && iy >= 0 && ix >= 0 && iy < 2 * p.IH && ix < 2 * p.IW;
+                iy >>= 1;
+                ix >>= 1;
+            } else {
+                ok = ok && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW;
+            }
+            const int64_t pix = ((int64_t)pb[hi] * p.IH + iy) * p.IW + ix;
+            psrc[hi] = xb + (pix * p.x_cs + p.x_co) * 2 + chunk * 16;
+            pok |= ok ? (1u << hi) : 0u;
+        }
+    };
+    auto stage_A = [&](int t, char *stage) {
+        char *dst = stage + O3_A + wave * 1024;
+        const char *s = wsrc + (int64_t)t * 128;
+        glds16(s, dst);
+        glds16(s + wrow64, dst + 8192);
+    };
+    auto stage_B = [&](int h, int ci, char *stage) {
+        char *dst = stage + (h ? O3_B1 : O3_B0) + wave * 1024;
+        const int cbyte = ci * 128;
+        const char *z = zeros + chunk * 16;
+        glds16(((pok >> (2 * h)) & 1) ? psrc[2 * h] + cbyte : z, dst);
+        glds16(((pok >> (2 * h + 1)) & 1) ? psrc[2 * h + 1] + cbyte : z, dst + 8192);
+    };
+
+    f32x4 acc[4][2][2];                            // [i][b][j]: channels wr*64 + i*16.., pixels wc*64 + b*32 + j*16..
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fo0 = frow * 128 + ((fq ^ (lane & 7)) << 4);
+    const int fo1 = frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    const int a_off = wr * 64 * 128;
+    const int b_off = wc * 32 * 128;
+    bf16x8 fa[4][2], fb[2][2];
+
+#define LOAD3_A(stage)                                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
+        fa[i][0] = *(const bf16x8 *)((stage) + O3_A + a_off + i * 2048 + fo0);    \
+        fa[i][1] = *(const bf16x8 *)((stage) + O3_A + a_off + i * 2048 + fo1);    \
+    }
+#define LOAD3_B(stage, h)                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+        fb[j][0] = *(const bf16x8 *)((stage) + ((h) ? O3_B1 : O3_B0) + b_off + j * 2048 + fo0); \
+        fb[j][1] = *(const bf16x8 *)((stage) + ((h) ? O3_B1 : O3_B0) + b_off + j * 2048 + fo1); \
+    }
+#define MFMA3_HALF(b)                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
+                acc[i][b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][b][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- prologue: K-tiles 0 and 1 ------------------------------------------------------------------
+    int tap2 = 0, ci2 = 0;
+    auto advance2 = [&]() {
+        if (++ci2 == nc) {
+            ci2 = 0;
+            ++tap2;
+            tap_sources(tap2);
+        }
+    };
+    tap_sources(0);
+    stage_A(0, smem);
+    stage_B(0, 0, smem);
+    stage_B(1, 0, smem);
+    if (T > 1) {
+        advance2();
+        stage_A(1, smem + STAGE3);
+        stage_B(0, ci2, smem + STAGE3);
+        stage_B(1, ci2, smem + STAGE3);
+        WAIT_VMCNT(6);
+    } else {
+        WAIT_VMCNT(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    int si = 0;                                    // ring slot of K-tile t
+    for (int t = 0; t < T; ++t) {
+        char *cur = smem + si * STAGE3;
+        const int s2 = si >= 1 ? si - 1 : 2;       // (si + 2) % 3: slot of K-tile t + 2 (= slot of K-tile t - 1)
+        char *tgt = smem + s2 * STAGE3;
+        const bool st2 = t + 2 < T;
+
+        // phase 0: pixels 0..31 of the wave; stage A and B^0 of K-tile t + 2
+        LOAD3_B(cur, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        LOAD3_A(cur)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st2) {
+            advance2();
+            stage_A(t + 2, tgt);
+            stage_B(0, ci2, tgt);
+        }
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKMCNT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA3_HALF(0)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+
+        // phase 1: pixels 32..63; stage B^1 of K-tile t + 2; K-tile t + 1 must have landed
+        LOAD3_B(cur, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st2) {
+            stage_B(1, ci2, tgt);
+            WAIT_VMCNT(6);
+        } else {
+            WAIT_VMCNT(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        WAIT_LGKMCNT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA3_HALF(1)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        si = si == 2 ? 0 : si + 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue --------------------------------------------------------------------------------------
+    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
+    const int cout_store = glu ? p.Cout / 2 : p.Cout;
+    char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
+    const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
+    const int nw = n0 + wr * 64;
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ssum[i] = ssq[i] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
+            if (m >= M) continue;
+            const ConvOutPix op = conv_out_pix(p, m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (glu && (i & 1)) continue;
+                const int i2 = (i + 1 < 4) ? i + 1 : i;
+                conv_epilogue_tile<false>(p, yb, rb, glu, cout_store, acc[i][b][j], acc[i2][b][j], nw + i * 16, fq, op,
+                                          ssum[i], ssq[i]);
+            }
+        }
+    if (p.stats) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (glu && (i & 1)) continue;
+            const int n16 = nw + i * 16;
+            conv_stats_store(p, ssum[i], ssq[i], m0 + wc * 64, (glu ? n16 / 2 : n16) + fq * 4, cout_store, lane, M);
+        }
+    }
 }
 
 }  // namespace
@@ -274,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
 int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipFuncSetAttribute((const void *)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        (void)hipFuncSetAttribute((const void *)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
         configured = true;
     }
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
@@ -285,6 +524,25 @@ int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st) {
     const int Ktot = p.KH * p.KW * p.Cin;
     dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
     hipLaunchKernelGGL(conv_gemm256_kernel, grid, dim3(512), 2 * STAGE, st, p, tiles_n, tiles_m, M, Ktot);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void *)conv_gemm128x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * STAGE3);
+        configured = true;
+    }
+    const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
+    if (M64 > 0x7fffffff) return -1;
+    const int M = (int)M64;
+    const int tiles_n = (p.Cout + 127) / 128;
+    const int tiles_m = (M + 255) / 256;
+    const int Ktot = p.KH * p.KW * p.Cin;
+    dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
+    hipLaunchKernelGGL(conv_gemm128x256_kernel, grid, dim3(512), 3 * STAGE3, st, p, tiles_n, tiles_m, M, Ktot);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

@@ -92,31 +92,87 @@ __global__ void gn_finalize_kernel(const float *__restrict__ part, const float *
     }
 }
 
-// y = act(x * a + bb), 8 channels per lane
-__global__ void scale_shift_act_kernel(const bf16_t *__restrict__ x, const float2 *__restrict__ ab,
-                                       bf16_t *__restrict__ y, int64_t items, int HW, int C, int CC, int x_cs,
-                                       int x_co, int y_cs, int y_co, int silu) {
-    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items;
-         it += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t pix = it / CC;
-        const int cc = (int)(it - pix * CC);
-        const int b = (int)(pix / HW);
-        const uint4 v = *(const uint4 *)(x + pix * x_cs + x_co + cc * 8);
-        float f[8];
-        unpack8(v, f);
-        const float4 *abp = (const float4 *)(ab + (int64_t)b * C + cc * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float4 t = abp[e];
-            float v0 = f[2 * e] * t.x + t.y, v1 = f[2 * e + 1] * t.z + t.w;
-            if (silu) {
-                v0 = silu_f(v0);
-                v1 = silu_f(v1);
-            }
-            f[2 * e] = v0;
-            f[2 * e + 1] = v1;
+// stage 2 when the producing conv left partial sums (onedc_conv_params.stats): block (group, image)
+// folds the group's quads over the image's 64-pixel blocks.  Fixed order: thread t sums entries
+// t, t+256, ... in fp64, then a fixed-shape tree over the 256 threads.
+__global__ void gn_from_stats_kernel(const float2 *__restrict__ stats, const float *__restrict__ gamma,
+                                     const float *__restrict__ beta, float2 *__restrict__ ab, int HW, int C,
+                                     int cs, int co, float eps) {
+    __shared__ double red[2][256];
+    const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int cpg = C / GN_GROUPS, qpg = cpg >> 2;
+    const int rows = HW >> 6, qs = cs >> 2;
+    const float2 *base = stats + (int64_t)b * rows * qs + ((co + g * cpg) >> 2);
+    double ss = 0.0, qq = 0.0;
+    const int n = rows * qpg;
+    for (int e = t; e < n; e += 256) {
+        const int r = e / qpg, q = e - r * qpg;
+        const float2 v = base[(int64_t)r * qs + q];
+        ss += (double)v.x;
+        qq += (double)v.y;
+    }
+    red[0][t] = ss;
+    red[1][t] = qq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            red[0][t] += red[0][t + o];
+            red[1][t] += red[1][t + o];
         }
-        *(uint4 *)(y + pix * y_cs + y_co + cc * 8) = pack8(f);
+        __syncthreads();
+    }
+    const double cnt = (double)HW * cpg;
+    const double mean = red[0][0] / cnt;
+    double var = red[1][0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (t < cpg) {
+        const int c = g * cpg + t;
+        const float a = rstd * gamma[c];
+        ab[(int64_t)b * C + c] = make_float2(a, beta[c] - (float)mean * a);
+    }
+}
+
+// y = act(x * a + bb).  Block (pixel chunk, image); thread = (channel chunk of 8, pixel lane): the
+// thread's 8 (a, bb) pairs are loaded once and stay in registers while it walks its pixels, so the
+// loop is one 16-byte load, 8 fma (+ 8 exp / rcp for SiLU) and one 16-byte store, no index division.
+constexpr int SSA_PPC = 256;  // pixels per block
+__global__ void scale_shift_act_kernel(const bf16_t *__restrict__ x, const float2 *__restrict__ ab,
+                                       bf16_t *__restrict__ y, int HW, int C, int CC, int PL, int x_cs, int x_co,
+                                       int y_cs, int y_co, int silu) {
+    const int t = threadIdx.x;
+    const int cc = t % CC, pl = t / CC;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * SSA_PPC;
+    const int p1 = min(p0 + SSA_PPC, HW);
+    float a[8], bb[8];
+    const float4 *abp = (const float4 *)(ab + (int64_t)b * C + cc * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float4 v = abp[e];
+        a[2 * e] = v.x;
+        bb[2 * e] = v.y;
+        a[2 * e + 1] = v.z;
+        bb[2 * e + 1] = v.w;
+    }
+    const bf16_t *xp = x + ((int64_t)b * HW) * x_cs + x_co + cc * 8;
+    bf16_t *yp = y + ((int64_t)b * HW) * y_cs + y_co + cc * 8;
+    if (silu) {
+        for (int p = p0 + pl; p < p1; p += PL) {
+            float f[8];
+            unpack8(*(const uint4 *)(xp + (int64_t)p * x_cs), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = silu_f(__builtin_fmaf(f[e], a[e], bb[e]));
+            *(uint4 *)(yp + (int64_t)p * y_cs) = pack8(f);
+        }
+    } else {
+        for (int p = p0 + pl; p < p1; p += PL) {
+            float f[8];
+            unpack8(*(const uint4 *)(xp + (int64_t)p * x_cs), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = __builtin_fmaf(f[e], a[e], bb[e]);
+            *(uint4 *)(yp + (int64_t)p * y_cs) = pack8(f);
+        }
     }
 }
 
@@ -230,16 +286,27 @@ int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *
     return 0;
 }
 
+int onedc_gn_from_stats(const float *stats, const float *gamma, const float *beta, float *ab, int B, int HW,
+                        int C, int cs, int co, float eps, void *stream) {
+    if (!stats || !gamma || !beta || !ab) return -1;
+    if (C % 32 || ((C / 32) & 3) || (co & 3) || (cs & 3) || (HW & 63) || C / 32 > 256) return -2;
+    hipLaunchKernelGGL(gn_from_stats_kernel, dim3(GN_GROUPS, B), dim3(256), 0, as_stream(stream),
+                       (const float2 *)stats, gamma, beta, (float2 *)ab, HW, C, cs, co, eps);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
 int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
                           int y_cs, int y_co, int silu, void *stream) {
     if (!x || !ab || !y) return -1;
     if ((C & 7) || (x_cs & 7) || (x_co & 7) || (y_cs & 7) || (y_co & 7)) return -2;
     const int CC = C / 8;
-    const int64_t items = (int64_t)B * HW * CC;
-    const int blocks = (int)min((int64_t)8192, (items + 255) / 256);
-    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
-                       (const bf16_t *)x, (const float2 *)ab, (bf16_t *)y, items, HW, C, CC, x_cs, x_co, y_cs,
-                       y_co, silu);
+    const int PL = CC >= 256 ? 1 : 256 / CC;
+    const int threads = CC * PL;
+    if (threads > 1024) return -3;
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3((HW + SSA_PPC - 1) / SSA_PPC, B), dim3(threads), 0,
+                       as_stream(stream), (const bf16_t *)x, (const float2 *)ab, (bf16_t *)y, HW, C, CC, PL, x_cs,
+                       x_co, y_cs, y_co, silu);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

@@ -27,7 +27,7 @@ class ReduceResblock:
         self.short = Conv(sd, f"{p}.short_cut", device)
 
     def __call__(self, x, ws):
-        h = self.c2(self.n0(x, ws, True))
+        h = self.c2(self.n0(x, ws, True), stats=True)
         h = self.n3(h, ws, True)
         sc = self.short(x)                                  # bf16 (B,H,W,4)
         return self.c5(h, res=sc, out_f32=True)             # f32: feeds the x0 formula (x14.65 gain)
@@ -107,7 +107,7 @@ class UNet:
                 cin_total = blk["ins"][j]
                 h_c = cin_total - skip_c[s]
                 lvl = skip_lvl[s]
-                buf = new_view(B, res[lvl][0], res[lvl][1], cin_total, dev)
+                buf = new_view(B, res[lvl][0], res[lvl][1], cin_total, dev, stats=True)
                 cat_bufs[s] = (buf, h_c)
                 order.append(s)
                 s -= 1
@@ -121,7 +121,7 @@ class UNet:
             return buf.slice(0, h_c)
 
         si = 0
-        h = self.conv_in(sample, skip_slot(si))
+        h = self.conv_in(sample, skip_slot(si), stats=True)
         si += 1
         for i, blk in enumerate(self.down):
             for j in range(2):
@@ -132,7 +132,7 @@ class UNet:
                     h = blk["res"][j](h, ws, skip_slot(si))
                 si += 1
             if blk["down"] is not None:
-                h = blk["down"](h, skip_slot(si), stride=2)
+                h = blk["down"](h, skip_slot(si), stride=2, stats=True)
                 si += 1
 
         h = self.mid_res[0](h, ws)
@@ -160,7 +160,7 @@ class UNet:
                 else:
                     h = blk["res"][j](cat, ws, dst)
             if blk["up"] is not None:
-                h = blk["up"](h, head_slot(order[oi]), up=1)
+                h = blk["up"](h, head_slot(order[oi]), up=1, stats=True)
 
         h = self.norm_out(h, ws, True)
         eps = self.conv_out(h, out_f32=True)

@@ -17,7 +17,7 @@ _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
 class ConvParams(C.Structure):
     _fields_ = [
-        ("x", _P), ("w", _P), ("bias", _P), ("res", _P), ("y", _P), ("zeros", _P),
+        ("x", _P), ("w", _P), ("bias", _P), ("res", _P), ("y", _P), ("zeros", _P), ("stats", _P),
         ("B", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("Cin", C.c_int32),
         ("x_cs", C.c_int32), ("x_co", C.c_int32),
         ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("y_cs", C.c_int32), ("y_co", C.c_int32),
@@ -48,6 +48,7 @@ SIGNATURES = {
     "onedc_gn_chunks": (_I, [_I]),
     "onedc_gn_stats": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_scale_shift_act": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_gn_from_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "onedc_softmax_rows": (_I, [_P, _P, _L, _I, _I, _P]),
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
@@ -108,14 +109,43 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class Stats:
+    """GroupNorm partial sums of a whole NHWC buffer, written by the epilogues of the convs that
+    produce its channel slices: float2 [B*H*W/64][cs/4].  `have` records which 4-channel quads a
+    producer has filled since the buffer was made."""
+    __slots__ = ("t", "have")
+
+    def __init__(self, B, H, W, cs, device):
+        self.t = torch.empty((B * H * W // 64) * (cs // 4) * 2, dtype=torch.float32, device=device)
+        self.have = [False] * (cs // 4)
+
+    @staticmethod
+    def possible(H, W, cs):
+        return (H * W) % 64 == 0 and cs % 4 == 0
+
+    def mark(self, co, C):
+        for q in range(co // 4, (co + C) // 4):
+            self.have[q] = True
+
+    def covers(self, co, C):
+        return co % 4 == 0 and C % 4 == 0 and all(self.have[co // 4:(co + C) // 4])
+
+
 class View:
     """A channel slice [co, co+C) of an NHWC buffer with `cs` channels per pixel."""
-    __slots__ = ("t", "B", "H", "W", "C", "cs", "co")
+    __slots__ = ("t", "B", "H", "W", "C", "cs", "co", "stats")
 
-    def __init__(self, t, B, H, W, C, cs=None, co=0):
+    def __init__(self, t, B, H, W, C, cs=None, co=0, stats=None):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
         self.cs = C if cs is None else cs
         self.co = co
+        self.stats = stats         # Stats of the underlying buffer (shared by all its slices) or None
+
+    def want_stats(self):
+        """Attach a Stats holder to this buffer (no-op if the map is not a multiple of 64 pixels)."""
+        if self.stats is None and Stats.possible(self.H, self.W, self.cs):
+            self.stats = Stats(self.B, self.H, self.W, self.cs, self.t.device)
+        return self
 
     @property
     def ptr(self):
@@ -126,7 +156,7 @@ class View:
         return self.t.dtype == torch.float32
 
     def slice(self, co, C):
-        return View(self.t, self.B, self.H, self.W, C, self.cs, self.co + co)
+        return View(self.t, self.B, self.H, self.W, C, self.cs, self.co + co, self.stats)
 
     def torch_nchw(self):
         """fp32 NCHW copy, for tests."""
@@ -138,9 +168,10 @@ class View:
 SLACK_ROWS = 128   # a GEMM may read (never use) up to one tile of rows past its "weight" operand
 
 
-def new_view(B, H, W, C, device, dtype=torch.bfloat16, cs=None):
+def new_view(B, H, W, C, device, dtype=torch.bfloat16, cs=None, stats=False):
     cs = C if cs is None else cs
-    return View(torch.empty((B * H * W + SLACK_ROWS) * cs, dtype=dtype, device=device), B, H, W, C, cs, 0)
+    v = View(torch.empty((B * H * W + SLACK_ROWS) * cs, dtype=dtype, device=device), B, H, W, C, cs, 0)
+    return v.want_stats() if stats else v
 
 
 def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
@@ -160,6 +191,10 @@ def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0):
     """The tile instantiation onedc_conv_gemm picks (mirrors the dispatcher in gemm_conv.hip)."""
     if tile != 128 and cout % 256 == 0 and (((cout // 256) * blocks_m256 >= 160 and ktiles >= 8) or tile == 256):
         return "256x256"
+    rows128 = (cout + 127) // 128 * 128
+    if (tile not in (128, 256) and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6 and
+            (((rows128 // 128) * blocks_m256 >= 160 and ktiles >= 6) or tile == 129)):
+        return "128x256"
     if cout <= 16 and not glu:
         return "16x256"
     if cout % 128 != 0 and cout % 128 <= 64:
@@ -169,7 +204,7 @@ def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0):
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
               pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0,
-              tile=0):
+              tile=0, stats=False):
     """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None."""
     p = ConvParams()
     p.x, p.w, p.bias, p.res, p.y = x.ptr, w.data_ptr(), _ptr(bias), (res.ptr if res is not None else None), y.ptr
@@ -191,8 +226,11 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     p.epi, p.out_f32, p.pixel_shuffle = epi, int(y.f32), pixel_shuffle
     p.in_f32 = int(x.f32)
     p.tile = tile
-    if x.f32 and (w.dtype != torch.float32 or not y.f32 or (res is not None and not res.f32)):
-        raise KernelError("f32 conv_gemm needs f32 weights, output and residual")
+    if stats and y.stats is not None and not pixel_shuffle and batch <= 1 and y.co % 4 == 0 and y.C % 4 == 0:
+        p.stats = y.stats.t.data_ptr()       # the epilogue leaves GroupNorm partial sums for the consumer
+        y.stats.mark(y.co, y.C)
+    if x.f32 and (w.dtype != torch.float32 or (res is not None and not res.f32)):
+        raise KernelError("f32 conv_gemm needs f32 weights and residual")
     p.alpha, p.slope = alpha, slope
     p.batch, p.x_bs, p.w_bs, p.y_bs, p.r_bs = batch, x_bs, w_bs, y_bs, r_bs
     if PROFILE is None:
@@ -232,13 +270,22 @@ def gn_chunks(HW):
     return lib().onedc_gn_chunks(HW)
 
 
+USE_EPILOGUE_STATS = True    # False: always run the separate statistics pass (tests, A/B)
+
+
 def group_norm(x, gamma, beta, y, eps, silu, ws):
-    """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors."""
+    """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors.  When the convs that
+    produced x left partial sums (x.stats covers the normalised channels and a group is whole quads),
+    the statistics pass over x is skipped."""
     HW = x.H * x.W
-    need = x.B * gn_chunks(HW) * 64
-    part, ab = ws.f32("gn_partial", need), ws.f32("gn_ab", x.B * x.C * 2)
-    _ok(lib().onedc_gn_stats(x.ptr, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), ab.data_ptr(),
-                             x.B, HW, x.C, x.cs, x.co, eps, stream()), "onedc_gn_stats")
+    ab = ws.f32("gn_ab", x.B * x.C * 2)
+    if (USE_EPILOGUE_STATS and x.stats is not None and (x.C // 32) % 4 == 0 and x.stats.covers(x.co, x.C)):
+        _ok(lib().onedc_gn_from_stats(x.stats.t.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ab.data_ptr(),
+                                      x.B, HW, x.C, x.cs, x.co, eps, stream()), "onedc_gn_from_stats")
+    else:
+        part = ws.f32("gn_partial", x.B * gn_chunks(HW) * 64)
+        _ok(lib().onedc_gn_stats(x.ptr, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), ab.data_ptr(),
+                                 x.B, HW, x.C, x.cs, x.co, eps, stream()), "onedc_gn_stats")
     _ok(lib().onedc_scale_shift_act(x.ptr, ab.data_ptr(), y.ptr, x.B, HW, x.C, x.cs, x.co, y.cs, y.co,
                                     int(silu), stream()), "onedc_scale_shift_act")
     return y

@@ -59,7 +59,8 @@ class Conv:
         self.glu, self.shuffle = glu, shuffle
 
     def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
-                 alpha=1.0):
+                 alpha=1.0, stats=False):
+        """stats: the output feeds a GroupNorm -- leave its partial sums in the epilogue."""
         if y is None:
             oh, ow = x.H, x.W
             if stride == 2:
@@ -73,9 +74,11 @@ class Conv:
                 c //= 4
                 oh, ow = 2 * oh, 2 * ow
             y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else torch.bfloat16)
+        if stats:
+            y.want_stats()
         return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
                            alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
-                           Cout=self.cout, flop_scale=self.flop_scale)
+                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats)
 
 
 _Conv = Conv
@@ -137,8 +140,8 @@ class VQResnetBlock:
         self.c2 = Conv(sd, f"{p}.conv2", device)
 
     def __call__(self, x, ws, y=None):
-        h = self.c1(self.n1(x, ws, True))
-        return self.c2(self.n2(h, ws, True), y, res=x)
+        h = self.c1(self.n1(x, ws, True), stats=True)
+        return self.c2(self.n2(h, ws, True), y, res=x, stats=True)
 
 
 class SingleHeadAttention:
@@ -214,10 +217,10 @@ class ResnetBlock2D:
             self.c1.b = (self._c1_bias + self._tw @ temb_act.to(self._tw.device) + self._tb).contiguous().to(self.device)
 
     def __call__(self, x, ws, y=None):
-        h = self.c1(self.n1(x, ws, True))
+        h = self.c1(self.n1(x, ws, True), stats=True)
         h = self.n2(h, ws, True)
         res = self.short(x) if self.short is not None else x
-        return self.c2(h, y, res=res)
+        return self.c2(h, y, res=res, stats=True)
 
 
 class MultiHeadAttention:
@@ -285,7 +288,7 @@ class Transformer2D:
         h = self.attn2(self.n2(h), ctx, h)
         f = self.ff1(self.n3(h), epi=EPI_GEGLU)
         h = self.ff2(f, res=h)
-        return self.proj_out(h, y, res=x)
+        return self.proj_out(h, y, res=x, stats=True)
 
 
 def silu_cpu(v):

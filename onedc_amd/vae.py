@@ -29,8 +29,10 @@ class VAEDecoder:
         # post_quant_conv (1x1, 4->4) and conv_in (3x3, 4->512): tiny-channel direct kernels in f32
         self.pq_w = sd["post_quant_conv.weight"].permute(0, 2, 3, 1).reshape(4, -1).float().contiguous().to(device)
         self.pq_b = sd["post_quant_conv.bias"].float().contiguous().to(device)
-        self.ci_w = sd["decoder.conv_in.weight"].permute(0, 2, 3, 1).reshape(512, -1).float().contiguous().to(device)
-        self.ci_b = sd["decoder.conv_in.bias"].float().contiguous().to(device)
+        # conv_in (3x3, 4 -> 512) on the exact-f32 matrix-core path: input channels zero-padded 4 -> 32
+        wci = torch.zeros(512, 32, 3, 3)
+        wci[:, :4] = sd["decoder.conv_in.weight"].float()
+        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["decoder.conv_in.bias"], f32=True, flop_scale=4 / 32)
         self.mid_res = [ResnetBlock2D(sd, f"decoder.mid_block.resnets.{j}", device, 1e-6) for j in range(2)]
         self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6)
         self.attn = SingleHeadAttention(sd, (f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{a}.to_out.0"), device, 512)
@@ -72,10 +74,10 @@ class VAEDecoder:
     def decode(self, latents):
         """latents: f32 View (B,h,w,4) -> f32 View (B,8h,8w,3) picture in [-1,1] (unclamped)."""
         ws, dev = self.ws, self.device
-        z = new_view(latents.B, latents.H, latents.W, 4, dev, torch.float32)
-        K.direct_conv(latents, self.pq_w, self.pq_b, z, K=1, in_scale=1.0 / self.scaling_factor)
-        h = new_view(latents.B, latents.H, latents.W, 512, dev)
-        K.direct_conv(z, self.ci_w, self.ci_b, h, K=3)
+        zbuf = torch.zeros((latents.B * latents.H * latents.W + K.SLACK_ROWS) * 32, dtype=torch.float32, device=dev)
+        z = View(zbuf, latents.B, latents.H, latents.W, 32)
+        K.direct_conv(latents, self.pq_w, self.pq_b, z.slice(0, 4), K=1, in_scale=1.0 / self.scaling_factor)
+        h = self.conv_in(z, new_view(latents.B, latents.H, latents.W, 512, dev), stats=True)
         h = self.mid_res[0](h, ws)
         h = self._windowed_attention(h)
         h = self.mid_res[1](h, ws)
@@ -83,6 +85,6 @@ class VAEDecoder:
             for r in blk["res"]:
                 h = r(h, ws)
             if blk["up"] is not None:
-                h = blk["up"](h, up=1)
+                h = blk["up"](h, up=1, stats=True)
         h = self.norm_out(h, ws, True)
         return self.conv_out(h, out_f32=True)

@@ -434,3 +434,97 @@ def test_conv_gemm256_race_screen():
             close(y.torch_nchw(), F.conv2d(x, w, None, padding=1), what="256 race ref")
         else:
             assert torch.equal(got, ref), f"run {it} differs"
+
+
+# ---- GroupNorm statistics from the producing conv's epilogue ------------------------------------------------
+@pytest.mark.parametrize("tile,Cout,HW", [(128, 128, (16, 16)), (256, 512, (16, 24)), (128, 640, (8, 8)), (128, 64, (8, 16))])
+def test_group_norm_from_conv_epilogue_stats(tile, Cout, HW):
+    """conv (+bias, residual) with stats=True, then GroupNorm+SiLU fed by those partial sums, against
+    F.group_norm of the conv result; also the two producers-one-buffer (concat) case."""
+    H, W = HW
+    B, Cin = 3, 128
+    x, w, b = rnd(B, Cin, H, W, seed=80), rnd(Cout, Cin, 3, 3, seed=81, scale=1 / 34), rnd(Cout, seed=82)
+    r = rnd(B, Cout, H, W, seed=83)
+    g, be = rnd(Cout, seed=84), rnd(Cout, seed=85)
+    y = new_view(B, H, W, Cout, DEV, stats=True)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=3, res=from_nchw(r.to(DEV)), tile=tile, stats=True)
+    assert y.stats is not None and y.stats.covers(0, Cout)
+    out = new_view(B, H, W, Cout, DEV)
+    K.group_norm(y, g.to(DEV), be.to(DEV), out, 1e-6, True, _WS())
+    ref = F.silu(F.group_norm(F.conv2d(x, w, b, padding=1) + r, 32, g, be, 1e-6))
+    close(out.torch_nchw(), ref, rms=6e-3, mx=4e-2, what="gn from epilogue stats")
+    # the statistics themselves: same (a, b) as the separate pass over the stored bf16 tensor, to 1e-3
+    ws1, ws2 = _WS(), _WS()
+    K.group_norm(y, g.to(DEV), be.to(DEV), out, 1e-6, True, ws1)
+    K.USE_EPILOGUE_STATS = False
+    try:
+        K.group_norm(y, g.to(DEV), be.to(DEV), out, 1e-6, True, ws2)
+    finally:
+        K.USE_EPILOGUE_STATS = True
+    a1, a2 = ws1.t["gn_ab"][:B * Cout * 2].cpu(), ws2.t["gn_ab"][:B * Cout * 2].cpu()
+    assert float((a1 - a2).abs().max() / a2.abs().max()) <= 2e-3
+
+
+def test_group_norm_stats_two_producers_one_buffer():
+    B, H, W = 2, 16, 16
+    xa, xb = rnd(B, 128, H, W, seed=86), rnd(B, 64, H, W, seed=87)
+    wa, wb = rnd(256, 128, 1, 1, seed=88, scale=0.09), rnd(128, 64, 1, 1, seed=89, scale=0.12)
+    cat = new_view(B, H, W, 384, DEV, stats=True)
+    K.conv_gemm(from_nchw(xa.to(DEV)), packed(wa), None, cat.slice(0, 256), KH=1, stats=True)
+    assert not cat.stats.covers(0, 384)
+    K.conv_gemm(from_nchw(xb.to(DEV)), packed(wb), None, cat.slice(256, 128), KH=1, stats=True)
+    assert cat.stats.covers(0, 384)
+    g, be = rnd(384, seed=90), rnd(384, seed=91)
+    out = new_view(B, H, W, 384, DEV)
+    K.group_norm(cat, g.to(DEV), be.to(DEV), out, 1e-5, False, _WS())
+    ref = F.group_norm(torch.cat([F.conv2d(xa, wa), F.conv2d(xb, wb)], 1), 32, g, be, 1e-5)
+    close(out.torch_nchw(), ref, rms=6e-3, mx=4e-2, what="gn stats, concat buffer")
+
+
+# ---- the 128 x 256-tile kernel (8 waves, 3-deep LDS ring; forced with tile=129) ---------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (2, 16, 16, 64, 128, 1),      # one K-tile
+    (2, 16, 16, 128, 128, 1),     # two K-tiles
+    (2, 16, 16, 192, 128, 1),     # three K-tiles (ring wraps)
+    (1, 24, 20, 128, 128, 3),     # 18 K-tiles, ragged M
+    (2, 12, 12, 256, 320, 3),     # 320 channels: three tiles, the last one 5/8 padding rows
+    (3, 9, 7, 320, 640, 1),       # five channel tiles, M = 189
+])
+def test_conv_gemm128x256_plain(B, H, W, Cin, Cout, k):
+    x, w, b = rnd(B, Cin, H, W, seed=101), rnd(Cout, Cin, k, k, seed=102, scale=(Cin * k * k) ** -0.5), rnd(Cout, seed=103)
+    y = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=k, tile=129)
+    close(y.torch_nchw(), F.conv2d(x, w, b, padding=k // 2), what="conv128x256")
+    y2 = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y2, KH=k, tile=128)
+    assert torch.equal(y.torch_nchw(), y2.torch_nchw())
+
+
+def test_conv_gemm128x256_variants_and_race_screen():
+    x, w, b = rnd(2, 128, 16, 12, seed=104), rnd(128, 128, 3, 3, seed=105, scale=1 / 34), rnd(128, seed=106)
+    xv = from_nchw(x.to(DEV))
+    y = new_view(2, 8, 6, 128, DEV)
+    K.conv_gemm(xv, packed(w), b.to(DEV), y, KH=3, stride=2, tile=129)
+    close(y.torch_nchw(), F.conv2d(x, w, b, stride=2, padding=1), what="128x256 stride2")
+    y = new_view(2, 32, 24, 128, DEV, stats=True)
+    r = rnd(2, 128, 32, 24, seed=107)
+    K.conv_gemm(xv, packed(w), b.to(DEV), y, KH=3, up=1, tile=129, res=from_nchw(r.to(DEV)), stats=True)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1) + r
+    close(y.torch_nchw(), ref, what="128x256 up+res")
+    g, be = rnd(128, seed=108), rnd(128, seed=109)
+    out = new_view(2, 32, 24, 128, DEV)
+    K.group_norm(y, g.to(DEV), be.to(DEV), out, 1e-6, True, _WS())
+    close(out.torch_nchw(), F.silu(F.group_norm(ref, 32, g, be, 1e-6)), rms=6e-3, mx=4e-2, what="128x256 stats")
+    # race screen: many K-tiles, many workgroups, identical bits over 40 launches
+    x, w = rnd(4, 256, 48, 48, seed=110), rnd(128, 256, 3, 3, seed=111, scale=1 / 48)
+    xv, wp = from_nchw(x.to(DEV)), packed(w)
+    ref = None
+    for it in range(40):
+        y = new_view(4, 48, 48, 128, DEV)
+        K.conv_gemm(xv, wp, None, y, KH=3, tile=129)
+        got = y.t[:4 * 48 * 48 * 128].clone()
+        if ref is None:
+            ref = got
+            close(y.torch_nchw(), F.conv2d(x, w, None, padding=1), what="128x256 race ref")
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"
