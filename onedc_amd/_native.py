@@ -12,7 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 CODER_SO = os.path.join(CSRC, "libonedc_coder.so")
-HIP_SO = os.path.join(CSRC, "libonedc_hip.so")
+# ONEDC_HIP_SO: developer override for A/B experiment builds of the same sources (tools/exp_build.sh)
+HIP_SO = os.environ.get("ONEDC_HIP_SO") or os.path.join(CSRC, "libonedc_hip.so")
 
 
 class NativeLibraryError(RuntimeError):

@@ -14,6 +14,52 @@ __device__ __forceinline__ int xcd_logical_tile(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// ---- implicit-GEMM pixel sources ------------------------------------------------------------------------
+// Each lane stages NP pixel rows of the B operand.  Output pixel m = (b, oy, ox) is decoded once; for a
+// tap (ky, kx) the input position is (oy*stride - pad + ky, ox*stride - pad + kx) (on the x2 grid when
+// the nearest-neighbour upsample is fused: then >> 1).  Switching taps costs ~10 VALU per pixel row, all
+// 32-bit except one 64-bit multiply-add for the byte address.
+template <int NP>
+struct ConvPixSrc {
+    int base[NP];      // pixel index of (b, 0, 0) in the input
+    int iyx0[NP];      // (iy0 << 16) | (ix0 & 0xffff) for tap (0, 0)
+    unsigned valid;    // bit i: row i is a real output pixel (m < M)
+    const char *src[NP];
+    unsigned ok;       // bit i: row i reads a real input pixel for the current tap (else: zeros)
+
+    __device__ __forceinline__ void init(const onedc_conv_params &p, const int (&m)[NP], int M) {
+        valid = 0;
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int mm = m[i] < M ? m[i] : 0;
+            const int b = mm / ohw, rem = mm - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            base[i] = b * p.IH * p.IW;
+            iyx0[i] = (int)((unsigned)(oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff);
+            valid |= (m[i] < M) ? (1u << i) : 0u;
+        }
+    }
+    // xb0 = input base + (x_co * elem + chunk * 16) bytes; pix_bytes = x_cs * elem
+    __device__ __forceinline__ void tap(const onedc_conv_params &p, const char *xb0, int pix_bytes, int ky, int kx) {
+        ok = 0;
+        const int ly = p.up ? 2 * p.IH : p.IH, lx = p.up ? 2 * p.IW : p.IW;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int iy = (iyx0[i] >> 16) + ky;
+            int ix = (int)(short)(iyx0[i] & 0xffff) + kx;
+            const bool in = ((valid >> i) & 1) && (unsigned)iy < (unsigned)ly && (unsigned)ix < (unsigned)lx;
+            if (p.up) {
+                iy >>= 1;
+                ix >>= 1;
+            }
+            const int pix = base[i] + iy * p.IW + ix;
+            src[i] = xb0 + (int64_t)pix * pix_bytes;
+            ok |= in ? (1u << i) : 0u;
+        }
+    }
+};
+
 // Output position of one pixel row m of the GEMM (decomposed once per pixel, used by every channel tile).
 struct ConvOutPix {
     int m;            // GEMM row (output pixel on the conv grid)
@@ -34,89 +80,142 @@ __device__ __forceinline__ ConvOutPix conv_out_pix(const onedc_conv_params &p, i
     return o;
 }
 
-// Epilogue of one 16x16 MFMA accumulator tile as held by one lane: 4 consecutive packed weight rows
-// (nrow16 + 4*fq + e, e = 0..3) of one pixel.  accg is the gate tile of a GLU pair (ignored otherwise).
-//   v = act(alpha*acc + bias) [+ residual]  ->  bf16 / f32 store, optional pixel-shuffle scatter.
-// ssum / ssq: running sum and sum of squares of the four stored values (GroupNorm statistics of the
-// consumer, see conv_stats_store); untouched when the lane stores nothing.
-template <bool F32>
-__device__ __forceinline__ void conv_epilogue_tile(const onedc_conv_params &p, char *yb, const char *rb, bool glu,
-                                                   int cout_store, const f32x4 &accv, const f32x4 &accg, int nrow16,
-                                                   int fq, const ConvOutPix &op, float &ssum, float &ssq) {
-    const int nrow = nrow16 + fq * 4;              // packed weight row of element 0
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float t = accv[e] * p.alpha;
-        if (p.bias && nrow < p.Cout) t += p.bias[nrow + e];      // rows past Cout are tile padding
-        v[e] = t;
-    }
-    int n_out = nrow;
-    if (glu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float g = accg[e] * p.alpha;
-            if (p.bias && nrow + 16 < p.Cout) g += p.bias[nrow + 16 + e];
-            v[e] = p.epi == ONEDC_EPI_GLU_LEAKY ? leaky(v[e], 0.1f) + leaky(g, 0.01f) : v[e] * gelu_f(g);
-        }
-        n_out = nrow16 / 2 + fq * 4;
-    } else if (p.epi == ONEDC_EPI_LEAKY) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = leaky(v[e], p.slope);
-    } else if (p.epi == ONEDC_EPI_SILU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-    }
-    if (n_out >= cout_store) return;
-    int64_t opix = op.m;                           // output pixel index on the y grid
+// ---- epilogue ------------------------------------------------------------------------------------------
+// One 16x16 MFMA accumulator tile as held by one lane = 4 consecutive packed weight rows
+// (nrow16 + 4*fq + e, e = 0..3) of one pixel.   v = act(alpha*acc + bias) [+ residual]  ->  bf16 / f32
+// store, optional pixel-shuffle scatter.  The epilogue of a workgroup runs in two passes so that no
+// load ever queues behind a store (vmcnt retires in order, a store takes microseconds to retire):
+//   pass 1  conv_epi_pos + conv_epi_load_res for every tile: index math, residual loads in flight
+//   pass 2  conv_epi_finish: activation, residual add, statistics, store
+struct EpiPos {
+    int64_t opix;     // output pixel index on the y grid
+    int n_out;        // first of the four output channels
+    bool store;       // the lane has something to store
+    bool full;        // all four channels exist (vector access allowed if aligned)
+};
+
+__device__ __forceinline__ EpiPos conv_epi_pos(const onedc_conv_params &p, bool glu, int cout_store, int nrow16,
+                                               int fq, const ConvOutPix &op, bool pixel_ok) {
+    EpiPos e;
+    int n_out = (glu ? nrow16 / 2 : nrow16) + fq * 4;
+    e.store = pixel_ok && n_out < cout_store;
+    e.opix = op.m;
     if (p.pixel_shuffle) {
         const int cq = p.Cout >> 2;                // channels after the shuffle
         const int sub = n_out / cq;
-        opix = ((int64_t)op.ob * (2 * p.OH) + 2 * op.ooy + (sub >> 1)) * (2 * p.OW) + 2 * op.oox + (sub & 1);
+        e.opix = ((int64_t)op.ob * (2 * p.OH) + 2 * op.ooy + (sub >> 1)) * (2 * p.OW) + 2 * op.oox + (sub & 1);
         n_out -= sub * cq;
     }
-    const bool full = p.pixel_shuffle || n_out + 3 < cout_store;
-    if (rb && F32) {                               // f32 residual
-        const float *rp = (const float *)rb + opix * p.r_cs + p.r_co + n_out;
-        if (full) {
-            const float4 rv = *(const float4 *)rp;
-            v[0] += rv.x;
-            v[1] += rv.y;
-            v[2] += rv.z;
-            v[3] += rv.w;
+    e.n_out = n_out;
+    e.full = p.pixel_shuffle || n_out + 3 < cout_store;
+    return e;
+}
+
+// residual of one tile: raw bits, 8 B (bf16 x 4) or 16 B (f32 x 4)
+template <bool F32>
+struct EpiRes {
+    uint4 v;
+};
+
+template <bool F32>
+__device__ __forceinline__ void conv_epi_load_res(const onedc_conv_params &p, const char *rb, int cout_store,
+                                                  const EpiPos &e, EpiRes<F32> &r) {
+    r.v = make_uint4(0, 0, 0, 0);
+    if (!rb || !e.store) return;
+    if (F32) {
+        const float *rp = (const float *)rb + e.opix * p.r_cs + p.r_co + e.n_out;
+        if (e.full) {
+            r.v = *(const uint4 *)rp;
         } else {
-            for (int e = 0; e < 4 && n_out + e < cout_store; ++e) v[e] += rp[e];
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) t[k] = __float_as_uint(rp[k]);
+            r.v = make_uint4(t[0], t[1], t[2], t[3]);
         }
-    } else if (rb) {
-        const bf16_t *rp = (const bf16_t *)rb + opix * p.r_cs + p.r_co + n_out;
-        if (full) {
-            const uint2 rv = *(const uint2 *)rp;
-            v[0] += bf2f((bf16_t)(rv.x & 0xffff));
-            v[1] += bf2f((bf16_t)(rv.x >> 16));
-            v[2] += bf2f((bf16_t)(rv.y & 0xffff));
-            v[3] += bf2f((bf16_t)(rv.y >> 16));
+    } else {
+        const bf16_t *rp = (const bf16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out;
+        if (e.full) {
+            const uint2 t = *(const uint2 *)rp;
+            r.v.x = t.x;
+            r.v.y = t.y;
         } else {
-            for (int e = 0; e < 4 && n_out + e < cout_store; ++e) v[e] += bf2f(rp[e]);
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) t[k] = rp[k];
+            r.v.x = t[0] | (t[1] << 16);
+            r.v.y = t[2] | (t[3] << 16);
         }
+    }
+}
+
+// bias of the four rows of a tile (and of its gate tile for GLU), loaded once per lane and tile row
+struct EpiBias {
+    float4 v, g;
+};
+__device__ __forceinline__ EpiBias conv_epi_bias(const onedc_conv_params &p, bool glu, int nrow16, int fq) {
+    EpiBias b;
+    b.v = b.g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nrow = nrow16 + fq * 4;
+    if (p.bias && nrow < p.Cout) b.v = *(const float4 *)(p.bias + nrow);          // rows past Cout are tile padding
+    if (p.bias && glu && nrow + 16 < p.Cout) b.g = *(const float4 *)(p.bias + nrow + 16);
+    return b;
+}
+
+// ssum / ssq: running sum and sum of squares of the four stored values (GroupNorm statistics of the
+// consumer, see conv_stats_store); untouched when the lane stores nothing.
+template <bool F32>
+__device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char *yb, bool glu, int cout_store,
+                                                const f32x4 &accv, const f32x4 &accg, const EpiBias &bias,
+                                                const EpiPos &e, const EpiRes<F32> &r, float &ssum, float &ssq) {
+    if (!e.store) return;
+    float v[4];
+    const float bv[4] = {bias.v.x, bias.v.y, bias.v.z, bias.v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(accv[k], p.alpha, bv[k]);
+    if (glu) {
+        const float bg[4] = {bias.g.x, bias.g.y, bias.g.z, bias.g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = __builtin_fmaf(accg[k], p.alpha, bg[k]);
+            v[k] = p.epi == ONEDC_EPI_GLU_LEAKY ? leaky(v[k], 0.1f) + leaky(g, 0.01f) : v[k] * gelu_f(g);
+        }
+    } else if (p.epi == ONEDC_EPI_LEAKY) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = leaky(v[k], p.slope);
+    } else if (p.epi == ONEDC_EPI_SILU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
+    }
+    if (F32) {
+        v[0] += __uint_as_float(r.v.x);
+        v[1] += __uint_as_float(r.v.y);
+        v[2] += __uint_as_float(r.v.z);
+        v[3] += __uint_as_float(r.v.w);
+    } else {
+        v[0] += bf2f((bf16_t)(r.v.x & 0xffff));
+        v[1] += bf2f((bf16_t)(r.v.x >> 16));
+        v[2] += bf2f((bf16_t)(r.v.y & 0xffff));
+        v[3] += bf2f((bf16_t)(r.v.y >> 16));
     }
     if (p.stats) {
         ssum += (v[0] + v[1]) + (v[2] + v[3]);
         ssq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-    const int64_t yo = opix * p.y_cs + p.y_co + n_out;
+    const int64_t yo = e.opix * p.y_cs + p.y_co + e.n_out;
+#ifdef EXP_NOSTORE
+    if (p.alpha != 12345.f) return;
+#endif
     if (p.out_f32) {
         float *yp = (float *)yb + yo;
-        if (full && ((p.y_cs | p.y_co) & 3) == 0) {
+        if (e.full && ((p.y_cs | p.y_co) & 3) == 0) {
             *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-            for (int e = 0; e < 4 && n_out + e < cout_store; ++e) yp[e] = v[e];
+            for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = v[k];
         }
     } else {
         bf16_t *yp = (bf16_t *)yb + yo;
-        if (full && ((p.y_cs | p.y_co) & 3) == 0) {
+        if (e.full && ((p.y_cs | p.y_co) & 3) == 0) {
             *(uint2 *)yp = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
         } else {
-            for (int e = 0; e < 4 && n_out + e < cout_store; ++e) yp[e] = f2bf(v[e]);
+            for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = f2bf(v[k]);
         }
     }
 }

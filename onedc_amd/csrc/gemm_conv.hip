@@ -66,46 +66,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         const int row = (wave + 4 * i) * 8 + lrow;
         wsrc[i] = wb + ((int64_t)(n0 + row) * Ktot) * ES + chunk * 16;
     }
-    int pb[T::NPI], pyx[T::NPI];                   // image index, packed (oy << 16 | ox); oy = -1: no pixel
+    ConvPixSrc<T::NPI> px;
+    {
+        int mrow[T::NPI];
 #pragma unroll
-    for (int i = 0; i < T::NPI; ++i) {
-        const int m = m0 + (wave + 4 * i) * 8 + lrow;
-        if (m < M) {
-            const int ohw = p.OH * p.OW;
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oy = rem / p.OW;
-            pb[i] = b;
-            pyx[i] = (oy << 16) | (rem - oy * p.OW);
-        } else {
-            pb[i] = 0;
-            pyx[i] = -1;
-        }
+        for (int i = 0; i < T::NPI; ++i) mrow[i] = m0 + (wave + 4 * i) * 8 + lrow;
+        px.init(p, mrow, M);
     }
-    const char *psrc[T::NPI];
-    unsigned pok = 0;                              // bit i: pixel row i of this lane is inside the image
+    const char *xb0 = xb + p.x_co * ES + chunk * 16;
+    const int pix_bytes = p.x_cs * ES;
     const int nc = p.Cin >> KSH;                   // 128-byte steps per tap
     const int steps = p.KH * p.KW * nc;
 
     auto tap_sources = [&](int tap) {
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        pok = 0;
-#pragma unroll
-        for (int i = 0; i < T::NPI; ++i) {
-            const int oy = pyx[i] >> 16, ox = pyx[i] & 0xffff;
-            int iy = oy * p.stride + ky - p.pad;
-            int ix = ox * p.stride + kx - p.pad;
-            bool ok = pyx[i] >= 0;
-            if (p.up) {
-                ok = ok && iy >= 0 && ix >= 0 && iy < 2 * p.IH && ix < 2 * p.IW;
-                iy >>= 1;
-                ix >>= 1;
-            } else {
-                ok = ok && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW;
-            }
-            const int64_t pix = ((int64_t)pb[i] * p.IH + iy) * p.IW + ix;
-            psrc[i] = xb + (pix * p.x_cs + p.x_co) * ES + chunk * 16;
-            pok |= ok ? (1u << i) : 0u;
-        }
+        const int ky = tap / p.KW;
+        px.tap(p, xb0, pix_bytes, ky, tap - ky * p.KW);
     };
 
     auto issue = [&](int step, int tap, int ci, char *buf) {
@@ -118,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         const int cbyte = ci * 128;
 #pragma unroll
         for (int i = 0; i < T::NPI; ++i) {
-            glds16(((pok >> i) & 1) ? psrc[i] + cbyte : zeros + chunk * 16,
+            glds16(((px.ok >> i) & 1) ? px.src[i] + cbyte : zeros + chunk * 16,
                    buf + (T::WBLK + wave + 4 * i) * 1024);
         }
         (void)step;
@@ -196,19 +171,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     const int nw = n0 + wn * T::WTN;               // first packed row of this wave
 
     float ssum[T::FI], ssq[T::FI];
+    EpiBias bias[T::FI];
 #pragma unroll
-    for (int i = 0; i < T::FI; ++i) ssum[i] = ssq[i] = 0.f;
+    for (int i = 0; i < T::FI; ++i) {
+        ssum[i] = ssq[i] = 0.f;
+        bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
+    }
+    // pass 1: positions + residual loads of every tile; pass 2: finish + store
+    EpiRes<F32> res[T::FI][T::FJ];
 #pragma unroll
     for (int j = 0; j < T::FJ; ++j) {
         const int m = m0 + wm * T::WTM + j * 16 + frow;
-        if (m >= M) continue;
         const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
         for (int i = 0; i < T::FI; ++i) {
             if (glu && (i & 1)) continue;          // odd tiles are the gate halves, consumed with their value tile
+            const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+            conv_epi_load_res<F32>(p, rb, cout_store, e, res[i][j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T::FJ; ++j) {
+        const int m = m0 + wm * T::WTM + j * 16 + frow;
+        const ConvOutPix op = conv_out_pix(p, m);
+#pragma unroll
+        for (int i = 0; i < T::FI; ++i) {
+            if (glu && (i & 1)) continue;
             const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
-            conv_epilogue_tile<F32>(p, yb, rb, glu, cout_store, acc[i][j], acc[i2][j], nw + i * 16, fq, op, ssum[i],
-                                    ssq[i]);
+            const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+            conv_epi_finish<F32>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i], ssq[i]);
         }
     }
     if (p.stats) {                                 // wave-uniform

@@ -58,47 +58,21 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;
     const int64_t wrow64 = (int64_t)64 * Ktot * 2;         // byte stride of 64 weight rows
     // pixels: pixel(h, i) = m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
-    int pb[4], pyx[4];                             // [h * 2 + i]: image, packed (oy << 16 | ox); -1 = no pixel
+    ConvPixSrc<4> px;                              // [h * 2 + i]: pixel m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
+    {
+        int mrow[4];
 #pragma unroll
-    for (int hi = 0; hi < 4; ++hi) {
-        const int h = hi >> 1, i = hi & 1;
-        const int m = m0 + ((t64 >> 5) + 2 * i) * 64 + h * 32 + (t64 & 31);
-        if (m < M) {
-            const int ohw = p.OH * p.OW;
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oy = rem / p.OW;
-            pb[hi] = b;
-            pyx[hi] = (oy << 16) | (rem - oy * p.OW);
-        } else {
-            pb[hi] = 0;
-            pyx[hi] = -1;
-        }
+        for (int hi = 0; hi < 4; ++hi) mrow[hi] = m0 + ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31);
+        px.init(p, mrow, M);
     }
-    const char *psrc[4];
-    unsigned pok = 0;
+    const char *xb0 = xb + p.x_co * 2 + chunk * 16;
+    const int pix_bytes = p.x_cs * 2;
     const int nc = p.Cin >> 6;                     // 64-channel K-tiles per tap
     const int T = p.KH * p.KW * nc;                // K-tiles
 
     auto tap_sources = [&](int tap) {
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        pok = 0;
-#pragma unroll
-        for (int hi = 0; hi < 4; ++hi) {
-            const int oy = pyx[hi] >> 16, ox = pyx[hi] & 0xffff;
-            int iy = oy * p.stride + ky - p.pad;
-            int ix = ox * p.stride + kx - p.pad;
-            bool ok = pyx[hi] >= 0;
-            if (p.up) {
-                ok = ok && iy >= 0 && ix >= 0 && iy < 2 * p.IH && ix < 2 * p.IW;
-                iy >>= 1;
-                ix >>= 1;
-            } else {
-                ok = ok && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW;
-            }
-            const int64_t pix = ((int64_t)pb[hi] * p.IH + iy) * p.IW + ix;
-            psrc[hi] = xb + (pix * p.x_cs + p.x_co) * 2 + chunk * 16;
-            pok |= ok ? (1u << hi) : 0u;
-        }
+        const int ky = tap / p.KW;
+        px.tap(p, xb0, pix_bytes, ky, tap - ky * p.KW);
     };
 
     // stage half-tile A^h of K-tile t (weights are k-contiguous: K-tile t starts at byte t * 128 of a row)
@@ -113,8 +87,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
         char *dst = stage + (h ? OFF_B1 : OFF_B0) + wave * 1024;
         const int cbyte = ci * 128;
         const char *z = zeros + chunk * 16;
-        glds16(((pok >> (2 * h)) & 1) ? psrc[2 * h] + cbyte : z, dst);
-        glds16(((pok >> (2 * h + 1)) & 1) ? psrc[2 * h + 1] + cbyte : z, dst + 8192);
+        glds16(((px.ok >> (2 * h)) & 1) ? px.src[2 * h] + cbyte : z, dst);
+        glds16(((px.ok >> (2 * h + 1)) & 1) ? px.src[2 * h + 1] + cbyte : z, dst + 8192);
     };
 
     // ---- accumulators: acc[a][i][b][j]: channels wr*128 + a*64 + i*16.., pixels wc*64 + b*32 + j*16.. ----
@@ -250,16 +224,34 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
     const int nw = n0 + wr * 128;
     float ssum[2][4], ssq[2][4];
+    EpiBias bias[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ssum[a][i] = ssq[a][i] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            ssum[a][i] = ssq[a][i] = 0.f;
+            bias[a][i] = conv_epi_bias(p, glu, nw + a * 64 + i * 16, fq);
+        }
+    // two pixel halves (b), each: pass 1 = positions + residual loads of its 16 tiles, pass 2 = finish + store
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b) {
+        EpiRes<false> res[2][2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
-            if (m >= M) continue;
+            const ConvOutPix op = conv_out_pix(p, m);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (glu && (i & 1)) continue;
+                    const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + a * 64 + i * 16, fq, op, m < M);
+                    conv_epi_load_res<false>(p, rb, cout_store, e, res[j][a][i]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
             const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -267,10 +259,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
                 for (int i = 0; i < 4; ++i) {
                     if (glu && (i & 1)) continue;
                     const int i2 = (i + 1 < 4) ? i + 1 : i;
-                    conv_epilogue_tile<false>(p, yb, rb, glu, cout_store, acc[a][i][b][j], acc[a][i2][b][j],
-                                              nw + a * 64 + i * 16, fq, op, ssum[a][i], ssq[a][i]);
+                    const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + a * 64 + i * 16, fq, op, m < M);
+                    conv_epi_finish<false>(p, yb, glu, cout_store, acc[a][i][b][j], acc[a][i2][b][j], bias[a][i], e,
+                                           res[j][a][i], ssum[a][i], ssq[a][i]);
                 }
         }
+    }
     if (p.stats) {                                 // wave-uniform
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -298,6 +292,21 @@ constexpr int O3_A = 0, O3_B0 = HALF, O3_B1 = 2 * HALF;
 __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_conv_params p, int tiles_n,
                                                                   int tiles_m, int M, int Ktot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef EXP_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define STAMP(i)                                                     \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        unsigned long long t__;                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
+        st_acc[i] += t__ - st_last;                                  \
+        st_last = t__;                                               \
+        __builtin_amdgcn_sched_barrier(0);                           \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,48 +325,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     const int t64 = wave * 8 + lrow;
     const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;     // weight rows t64 and t64 + 64
     const int64_t wrow64 = (int64_t)64 * Ktot * 2;
-    int pb[4], pyx[4];                             // [h * 2 + i]: pixel m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
+    ConvPixSrc<4> px;                              // [h * 2 + i]: pixel m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
+    {
+        int mrow[4];
 #pragma unroll
-    for (int hi = 0; hi < 4; ++hi) {
-        const int h = hi >> 1, i = hi & 1;
-        const int m = m0 + ((t64 >> 5) + 2 * i) * 64 + h * 32 + (t64 & 31);
-        if (m < M) {
-            const int ohw = p.OH * p.OW;
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oy = rem / p.OW;
-            pb[hi] = b;
-            pyx[hi] = (oy << 16) | (rem - oy * p.OW);
-        } else {
-            pb[hi] = 0;
-            pyx[hi] = -1;
-        }
+        for (int hi = 0; hi < 4; ++hi) mrow[hi] = m0 + ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31);
+        px.init(p, mrow, M);
     }
-    const char *psrc[4];
-    unsigned pok = 0;
-    const int nc = p.Cin >> 6;
-    const int T = p.KH * p.KW * nc;
+    const char *xb0 = xb + p.x_co * 2 + chunk * 16;
+    const int pix_bytes = p.x_cs * 2;
+    const int nc = p.Cin >> 6;                     // 64-channel K-tiles per tap
+    const int T = p.KH * p.KW * nc;                // K-tiles
 
     auto tap_sources = [&](int tap) {
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        pok = 0;
-#pragma unroll
-        for (int hi = 0; hi < 4; ++hi) {
-            const int oy = pyx[hi] >> 16, ox = pyx[hi] & 0xffff;
-            int iy = oy * p.stride + ky - p.pad;
-            int ix = ox * p.stride + kx - p.pad;
-            bool ok = pyx[hi] >= 0;
-            if (p.up) {
-                ok = ok && iy >= 0 && ix >= 0 && iy < 2 * p.IH && ix < 2 * p.IW;
-                iy >>= 1;
-                ix >>= 1;
-            } else {
-                ok = ok && iy >= 0 && ix >= 0 && iy < p.IH && ix < p.IW;
-            }
-            const int64_t pix = ((int64_t)pb[hi] * p.IH + iy) * p.IW + ix;
-            psrc[hi] = xb + (pix * p.x_cs + p.x_co) * 2 + chunk * 16;
-            pok |= ok ? (1u << hi) : 0u;
-        }
+        const int ky = tap / p.KW;
+        px.tap(p, xb0, pix_bytes, ky, tap - ky * p.KW);
     };
+
     auto stage_A = [&](int t, char *stage) {
         char *dst = stage + O3_A + wave * 1024;
         const char *s = wsrc + (int64_t)t * 128;
@@ -368,8 +352,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
         char *dst = stage + (h ? O3_B1 : O3_B0) + wave * 1024;
         const int cbyte = ci * 128;
         const char *z = zeros + chunk * 16;
-        glds16(((pok >> (2 * h)) & 1) ? psrc[2 * h] + cbyte : z, dst);
-        glds16(((pok >> (2 * h + 1)) & 1) ? psrc[2 * h + 1] + cbyte : z, dst + 8192);
+        glds16(((px.ok >> (2 * h)) & 1) ? px.src[2 * h] + cbyte : z, dst);
+        glds16(((px.ok >> (2 * h + 1)) & 1) ? px.src[2 * h + 1] + cbyte : z, dst + 8192);
     };
 
     f32x4 acc[4][2][2];                            // [i][b][j]: channels wr*64 + i*16.., pixels wc*64 + b*32 + j*16..
@@ -429,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
+    STAMP(0);
 
     int si = 0;                                    // ring slot of K-tile t
     for (int t = 0; t < T; ++t) {
@@ -447,31 +432,44 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
             stage_A(t + 2, tgt);
             stage_B(0, ci2, tgt);
         }
+        STAMP(1);
         __builtin_amdgcn_s_barrier();
+        STAMP(2);
         WAIT_LGKMCNT(0);
+        STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         MFMA3_HALF(0)
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(4);
         __builtin_amdgcn_s_barrier();
+        STAMP(5);
 
         // phase 1: pixels 32..63; stage B^1 of K-tile t + 2; K-tile t + 1 must have landed
         LOAD3_B(cur, 1)
         __builtin_amdgcn_sched_barrier(0);
         if (st2) {
             stage_B(1, ci2, tgt);
+            STAMP(1);
             WAIT_VMCNT(6);
         } else {
+            STAMP(1);
             WAIT_VMCNT(0);
         }
+        STAMP(6);
         __builtin_amdgcn_s_barrier();
+        STAMP(2);
         WAIT_LGKMCNT(0);
+        STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         MFMA3_HALF(1)
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(4);
         __builtin_amdgcn_s_barrier();
+        STAMP(5);
         si = si == 2 ? 0 : si + 1;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    STAMP(5);
 
     // ---- epilogue --------------------------------------------------------------------------------------
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
@@ -480,23 +478,48 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
     const int nw = n0 + wr * 64;
     float ssum[4], ssq[4];
+    EpiBias bias[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ssum[i] = ssq[i] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        ssum[i] = ssq[i] = 0.f;
+        bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
+    }
+    EpiRes<false> res[2][2][4];                    // pass 1: positions + residual loads of all 16 tiles
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
-            if (m >= M) continue;
+            const ConvOutPix op = conv_out_pix(p, m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (glu && (i & 1)) continue;
+                const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_load_res<false>(p, rb, cout_store, e, res[b][j][i]);
+            }
+        }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)                    // pass 2: finish + store
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
             const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (glu && (i & 1)) continue;
                 const int i2 = (i + 1 < 4) ? i + 1 : i;
-                conv_epilogue_tile<false>(p, yb, rb, glu, cout_store, acc[i][b][j], acc[i2][b][j], nw + i * 16, fq, op,
-                                          ssum[i], ssq[i]);
+                const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_finish<false>(p, yb, glu, cout_store, acc[i][b][j], acc[i2][b][j], bias[i], e, res[b][j][i],
+                                       ssum[i], ssq[i]);
             }
         }
+#ifdef EXP_STAMP
+    STAMP(7);
+    if (lane == 0 && blockIdx.x < 2048) {          // diagnostic build: p.stats is a debug buffer [2048][8 waves][8]
+        unsigned long long *dbg = (unsigned long long *)p.stats + ((int64_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 8; ++i) dbg[i] = st_acc[i];
+    }
+#else
     if (p.stats) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -505,6 +528,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
             conv_stats_store(p, ssum[i], ssq[i], m0 + wc * 64, (glu ? n16 / 2 : n16) + fq * 4, cout_store, lane, M);
         }
     }
+#endif
 }
 
 }  // namespace
