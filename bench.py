@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequential", action="store_true", help="no pipelining across batches")
     ap.add_argument("--cpu-sample", type=int, default=768, help="picture size of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline (16 was the fastest of 16/32/64 on the 2x64-core host)")
@@ -140,19 +141,25 @@ def main():
     del sds_dev
     torch.cuda.empty_cache()
 
-    def step():
-        return model.decode(stream=blobs)
+    # One step = one whole decode of one batch.  Default: the two-stage pipeline (the rANS hops of
+    # batch n+1 overlap the UNet / VAE of batch n; all K batches start and finish inside the timed
+    # region).  --sequential times K back-to-back model.decode() calls instead.
+    pipe = None if args.sequential else model.pipeline()
 
-    for _ in range(args.warmup):
-        step()
+    def run(k):
+        if pipe is None:
+            return [model.decode(stream=blobs) for _ in range(k)][-1]
+        return pipe.map([blobs] * k)[-1]
+
+    if args.warmup:
+        run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     K.PROFILE = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -188,7 +195,9 @@ def main():
                                    f"of the real architecture), bf16 MFMA / fp32 accumulate, {world}xMI355X",
                        "images_per_gpu_per_step": B, "picture": f"{S}x{S}", "parallelism": f"dp{world}",
                        "stream_bytes_per_image": stream_bytes // B, "host_rans_threads": model.codec_model.host_threads,
-                       "timed": "container parse + host rANS + H2D/D2H + all device kernels + crop"},
+                       "timed": "container parse + host rANS + H2D/D2H + all device kernels + crop",
+                       "schedule": "sequential decode() calls" if args.sequential else
+                                   "2-stage pipeline over batches (entropy stage of batch n+1 || UNet+VAE of batch n)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel": ("conv_gemm256_kernel" if dom == "256x256" else
@@ -207,6 +216,8 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_threads, sds[1], sds[0], sds[2])
         print(json.dumps(line), flush=True)
+    if pipe is not None:
+        pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

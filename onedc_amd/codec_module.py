@@ -126,6 +126,7 @@ class IntraNoAR:
         self.gaussian_encoder = GaussianEncoder()
         self.entropy_coder = None
         self._tables = None
+        self._pinned_bufs = {}
 
     # reference CompressionModel.update (compression_model.py:169-171)
     def update(self, force=False):
@@ -187,8 +188,7 @@ class IntraNoAR:
             decoders.append(d)
         idx_dev = torch.empty(B * n, dtype=torch.int16, device=self.device)
         sym_dev = torch.empty(B * n, dtype=torch.int16, device=self.device)
-        idx_host = torch.empty(B, n, dtype=torch.int16).pin_memory()
-        sym_host = torch.empty(B, n, dtype=torch.int16).pin_memory()
+        idx_host, sym_host = self._pinned(B, n)
         params = fused
         for k in range(4):
             if k > 0:
@@ -200,6 +200,16 @@ class IntraNoAR:
             sym_dev.view(B, n).copy_(sym_host, non_blocking=True)
             K.prior_update_dec(params, sym_dev, y_hat, k)
         return y_hat, z_semantic
+
+    def _pinned(self, B, n):
+        """Page-locked staging buffers of the rANS hops, one pair per (thread, shape), allocated once."""
+        import threading
+        key = (threading.get_ident(), B, n)
+        bufs = self._pinned_bufs.get(key)
+        if bufs is None:
+            bufs = (torch.empty(B, n, dtype=torch.int16).pin_memory(), torch.empty(B, n, dtype=torch.int16).pin_memory())
+            self._pinned_bufs[key] = bufs
+        return bufs
 
     @torch.no_grad()
     def recon_with_z(self, indices):
@@ -225,6 +235,15 @@ class IntraNoAR:
     @torch.no_grad()
     def decode(self, fp=None, stream=None):
         """Reference signature (codec_module.py:356-369), one stream or a list of streams."""
+        y_hat, z_semantic, orig_hw, pad_hw, pad = self.decode_entropy(fp=fp, stream=stream)
+        x_hat, y_semantic = self.synthesis(y_hat, z_semantic)
+        return x_hat, y_semantic, orig_hw, pad_hw, pad
+
+    @torch.no_grad()
+    def decode_entropy(self, fp=None, stream=None):
+        """The entropy stage of `decode`: container parse, z unpack, prior networks and the four host
+        rANS hops -> (y_hat, z_semantic, sizes).  Split from the synthesis so that a pipeline can run
+        it for the next batch while the previous one is in the UNet / VAE (DecodePipeline)."""
         assert fp or stream
         blobs = stream if stream else [read_from_file(f) for f in ([fp] if isinstance(fp, str) else fp)]
         if isinstance(blobs, (bytes, bytearray)):
@@ -238,9 +257,8 @@ class IntraNoAR:
         idx = np.stack([unpack_indices(d["bit_stream_z"], zh * zw, self.index_unit_length) for d in infos])
         indices = torch.from_numpy(idx.reshape(len(blobs), zh, zw)).to(self.device)
         y_hat, z_semantic = self.decompress([d["bit_stream_y"] for d in infos], indices)
-        x_hat, y_semantic = self.synthesis(y_hat, z_semantic)
         orig_hw = [(d["height"], d["width"]) for d in infos]
-        return x_hat, y_semantic, orig_hw, (pad_h, pad_w), infos[0]["pad_tuple"]
+        return y_hat, z_semantic, orig_hw, (pad_h, pad_w), infos[0]["pad_tuple"]
 
     # ------------------------------------------------------------------ encode side of the prior
     @torch.no_grad()

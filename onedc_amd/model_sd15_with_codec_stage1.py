@@ -112,15 +112,25 @@ class SD15_1step_codec_stage1:
         """-> f32 tensor [B,3,H,W] (B = 1 for a single path/bytes, as in the reference)."""
         assert fp or stream
         with torch.cuda.device(self.device):
-            h_detail_hat, y_semantic, orig_hw, pad_hw, pad_size = self.codec_model.decode(fp=fp, stream=stream)
-            out = self.decode_latents(h_detail_hat, y_semantic)
-            image = out["image"]
-            H, W = orig_hw[0]
-            if any(hw != (H, W) for hw in orig_hw):
-                H, W = pad_hw                                        # mixed crops: return the padded frame
-            res = torch.empty(image.B, 3, H, W, dtype=torch.float32, device=self.device)
-            K.image_out(image, res, H, W, unit_range)
+            entropy_out = self.codec_model.decode_entropy(fp=fp, stream=stream)
+            return self._decode_after_entropy(entropy_out, unit_range)
+
+    @torch.no_grad()
+    def _decode_after_entropy(self, entropy_out, unit_range=False):
+        """Synthesis transform, UNet step, x0, VAE decoder, crop: everything after the rANS hops."""
+        y_hat, z_semantic, orig_hw, pad_hw, pad_size = entropy_out
+        h_detail_hat, y_semantic = self.codec_model.synthesis(y_hat, z_semantic)
+        out = self.decode_latents(h_detail_hat, y_semantic)
+        image = out["image"]
+        H, W = orig_hw[0]
+        if any(hw != (H, W) for hw in orig_hw):
+            H, W = pad_hw                                            # mixed crops: return the padded frame
+        res = torch.empty(image.B, 3, H, W, dtype=torch.float32, device=self.device)
+        K.image_out(image, res, H, W, unit_range)
         return res
+
+    def pipeline(self, depth=2):
+        return DecodePipeline(self, depth)
 
     @torch.no_grad()
     def decode_z_only(self, indices):
@@ -134,6 +144,65 @@ class SD15_1step_codec_stage1:
             res = torch.empty(image.B, 3, image.H, image.W, dtype=torch.float32, device=self.device)
             K.image_out(image, res, image.H, image.W, False)
         return res
+
+
+class DecodePipeline:
+    """Throughput mode for a stream of batches: a two-stage software pipeline.
+
+    Stage E (entropy: container parse, prior networks, the four host rANS hops, all latency-bound and
+    GPU-light) of batch n+1 runs on a worker thread with its own high-priority HIP stream while stage S
+    (synthesis transform, UNet step, VAE decoder: 97 % of the device time) of batch n runs on the
+    caller's stream.  The hand-over is one HIP event per batch; results are bit-identical to `decode`
+    (same kernels, same order per batch).  No inter-GPU traffic: one pipeline per process / GPU."""
+
+    def __init__(self, model, depth=2):
+        import queue
+        import threading
+        self.model = model
+        self.dev = model.device
+        with torch.cuda.device(self.dev):
+            self.stream_e = torch.cuda.Stream(device=self.dev, priority=-1)
+        self._in = queue.Queue()
+        self._mid = queue.Queue(maxsize=max(1, depth))
+        self._worker = threading.Thread(target=self._entropy_loop, daemon=True)
+        self._worker.start()
+
+    def _entropy_loop(self):
+        torch.cuda.set_device(self.dev)
+        while True:
+            item = self._in.get()
+            if item is None:
+                self._mid.put(None)
+                return
+            try:
+                with torch.cuda.stream(self.stream_e), torch.no_grad():
+                    out = self.model.codec_model.decode_entropy(stream=item)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream_e)
+                self._mid.put((out, ev, None))
+            except BaseException as e:      # surfaced on the caller's thread
+                self._mid.put((None, None, e))
+
+    def map(self, batches, unit_range=False):
+        """Decode a list of batches (each a list of container byte strings) -> list of [B,3,H,W] tensors."""
+        for b in batches:
+            self._in.put(b)
+        results = []
+        cur = torch.cuda.current_stream(self.dev)
+        for _ in batches:
+            out, ev, err = self._mid.get()
+            if err is not None:
+                raise err
+            cur.wait_event(ev)
+            for v in (out[0], out[1]):      # y_hat / z_semantic were allocated on the entropy stream
+                v.t.record_stream(cur)
+            with torch.cuda.device(self.dev):
+                results.append(self.model._decode_after_entropy(out, unit_range))
+        return results
+
+    def close(self):
+        self._in.put(None)
+        self._worker.join(timeout=10)
 
 
 def check_state_dicts(ff, codec, vae):

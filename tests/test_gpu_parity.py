@@ -282,3 +282,28 @@ def test_end_to_end_decode_psnr(gaussian_tables):
     p = R.psnr(img.cpu(), ref)
     print(f"[parity] end-to-end PSNR(product, oracle) = {p:.2f} dB")
     assert p >= 30.0
+
+
+def test_decode_pipeline_matches_sequential_decode():
+    """DecodePipeline (entropy stage of batch n+1 on its own stream/thread while batch n is in the
+    UNet/VAE) must return bit-identical pictures to back-to-back decode() calls."""
+    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0)
+    model.codec_model.update(force=True)
+    rng = np.random.default_rng(19)
+    batches = []
+    for k in range(3):
+        idx = torch.from_numpy(rng.integers(0, 16384, (2, 2, 3)).astype(np.int32)).to(DEV)
+        blobs, _ = model.codec_model.encode_latents(idx, None, noise_seed=20 + k)
+        batches.append(blobs)
+    seq = [model.decode(stream=b) for b in batches]
+    pipe = model.pipeline()
+    try:
+        got = pipe.map(batches)
+        got2 = pipe.map(batches[::-1])
+    finally:
+        pipe.close()
+    torch.cuda.synchronize()
+    for a, b in zip(seq, got):
+        assert torch.equal(a, b)
+    for a, b in zip(seq[::-1], got2):
+        assert torch.equal(a, b)
