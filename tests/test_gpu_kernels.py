@@ -528,3 +528,35 @@ def test_conv_gemm128x256_variants_and_race_screen():
             close(y.torch_nchw(), F.conv2d(x, w, None, padding=1), what="128x256 race ref")
         else:
             assert torch.equal(got, ref), f"run {it} differs"
+
+
+def test_flash_attention_reference_point_moves():
+    """The d=40 kernel keeps a lazily moved softmax reference (set from tile 0, moved only when a later
+    tile exceeds it by 2^12): force that rare path -- logits that grow tile after tile and one spiked key
+    late in the sequence -- and an all-very-negative first tile; full-tensor check against fp64."""
+    B, Hh, d, Nq, Nk = 1, 8, 40, 320, 640
+    DQ, DV = pack.HEAD_PAD[d]
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B, Hh, Nq, d, generator=g)
+    k = torch.randn(B, Hh, Nk, d, generator=g)
+    v = torch.randn(B, Hh, Nk, d, generator=g)
+    ramp = torch.linspace(0.2, 6.0, Nk).view(1, 1, Nk, 1)                   # later keys give larger logits
+    k = k * ramp
+    k[:, :, 500] = q[:, :, 7] * 4.0                                         # a spike for query 7 (and friends)
+    k[:, 3, :64] = -q[:, 3, :1] * 3.0                                       # head 3: first tile strongly negative for query 0
+    q, k, v = (t.to(torch.bfloat16).float() for t in (q, k, v))
+
+    def padded(t, dp):
+        out = torch.zeros(B, t.shape[2], Hh, dp)
+        out[..., :d] = t.permute(0, 2, 1, 3)
+        return out.reshape(B, t.shape[2], Hh * dp).to(torch.bfloat16).to(DEV).contiguous()
+
+    vt = torch.zeros(B, Hh, DV, Nk)
+    vt[:, :, :d] = v.transpose(2, 3)
+    o = torch.empty(B, Nq, Hh * DV, dtype=torch.bfloat16, device=DEV)
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk).to(torch.bfloat16).to(DEV).contiguous(),
+                 o, B, Hh, Nq, Nk, Nk, DQ, DV, d ** -0.5)
+    ref = torch.softmax(q.double() @ k.double().transpose(-1, -2) * d ** -0.5, -1) @ v.double()
+    got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
+    assert torch.isfinite(got).all()
+    close(got, ref, rms=1e-2, mx=4e-2, what="flash attention, moving reference")

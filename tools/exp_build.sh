@@ -8,7 +8,8 @@ mkdir -p tools/exp
 objs=""
 for f in onedc_amd/csrc/*.hip; do
   o=tools/exp/$(basename ${f%.hip})_$name.o
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wno-unused-result "$@" -o $o $f 2>/dev/null &
+  ff=""; [ "$(basename $f)" = attention.hip ] && ff="-fno-honor-nans"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wno-unused-result $ff "$@" -o $o $f 2>/dev/null &
   objs="$objs $o"
 done
 wait
