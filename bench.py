@@ -52,31 +52,6 @@ def parse():
     return ap.parse_args()
 
 
-def broadcast_state_dicts(sds, specs, device, rank, world):
-    """Rank 0 owns the (synthetic or loaded) weights; everyone else receives them in ONE flat
-    RCCL broadcast over xGMI (~4 GB fp32), then folds/packs locally."""
-    import torch.distributed as dist
-    total = sum(int(np.prod(s)) for spec in specs for s in spec.values())
-    flat = torch.empty(total, dtype=torch.float32, device=device)
-    if rank == 0:
-        off = 0
-        for sd, spec in zip(sds, specs):
-            for k, shape in spec.items():
-                n = int(np.prod(shape))
-                flat[off:off + n] = sd[k].reshape(-1).to(device)
-                off += n
-    dist.broadcast(flat, src=0)
-    out, off = [], 0
-    for spec in specs:
-        sd = {}
-        for k, shape in spec.items():
-            n = int(np.prod(shape))
-            sd[k] = flat[off:off + n].view(*shape)
-            off += n
-        out.append(sd)
-    return out
-
-
 def cpu_baseline(sample, threads, codec_sd, unet_sd, vae_sd):
     """Oracle decode (everything after the entropy decode) of one sample x sample picture on the
     host; scaled to 768^2-equivalent images/s by algorithmic FLOPs when sample != 768."""
@@ -116,6 +91,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from onedc_amd import arch, synth
+    from onedc_amd.dataparallel import broadcast_state_dicts, max_over_ranks
     from onedc_amd import kernels as K
     from onedc_amd.model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
 
@@ -167,10 +143,7 @@ def main():
     prof, K.PROFILE = K.PROFILE, None
     assert out.shape == (B, 3, S, S) and bool(torch.isfinite(out).all())
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, device, world)
 
     if rank == 0:
         by_tile = {}
@@ -202,6 +175,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel": ("conv_gemm256_kernel" if dom == "256x256" else
                                     "conv_gemm128x256_kernel" if dom == "128x256" else
+                                    "conv_win_kernel" if dom == "win3x3" else
                                     f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
                                     + (" f32" if dom.startswith("f32") else "")),
                          "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.steps * 1e3, 2),

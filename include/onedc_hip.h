@@ -64,7 +64,8 @@ typedef struct onedc_conv_params {
     int32_t batch;                      /* >1: batched GEMM over blockIdx.z */
     int32_t tile;                       /* 0: pick the kernel automatically.  Forcing one (tests, benchmarks):
                                            128 = 4-wave kernels (128x128 / 64x128 / 16x256 tiles),
-                                           256 = 8-wave 256x256 tile, 129 = 8-wave 128(ch)x256(px) tile */
+                                           256 = 8-wave 256x256 tile, 129 = 8-wave 128(ch)x256(px) tile,
+                                           130 = 3x3 window kernel (16x16-pixel patches, stride 1, pad 1) */
     int32_t in_f32;                     /* 1: x, w, res are f32 (exact f32 MFMA; Cin multiple of 32): the prior
                                            networks, whose outputs feed integer decisions, and the VAE's conv_in */
     int64_t x_bs, w_bs, y_bs, r_bs;     /* element strides between batches */

@@ -228,15 +228,22 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
 // Fixed order, no atomics: every (64-pixel block, quad) has exactly one writer.  onedc_gn_from_stats
 // folds the quads of a group and the blocks of an image.  Requires OH*OW % 64 == 0 (a 64-pixel block
 // never straddles two images), y_co % 4 == 0, stored channels % 4 == 0, no pixel shuffle.
-__device__ __forceinline__ void conv_stats_store(const onedc_conv_params &p, float ssum, float ssq, int m_wave,
-                                                 int n_out, int cout_store, int lane, int M) {
+// row: index of the wave's 64-pixel block among all blocks of the batch (any numbering that keeps the
+// blocks of one image contiguous: the finalize only sums over an image's rows)
+__device__ __forceinline__ void conv_stats_store_row(const onedc_conv_params &p, float ssum, float ssq, int row,
+                                                     int n_out, int cout_store, int lane) {
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
         ssum += __shfl_xor(ssum, o);
         ssq += __shfl_xor(ssq, o);
     }
-    if ((lane & 15) == 0 && n_out < cout_store && m_wave < M) {   // M % 64 == 0: a block is whole or absent
-        float2 *dst = (float2 *)p.stats + (int64_t)(m_wave >> 6) * (p.y_cs >> 2) + ((p.y_co + n_out) >> 2);
+    if ((lane & 15) == 0 && n_out < cout_store) {
+        float2 *dst = (float2 *)p.stats + (int64_t)row * (p.y_cs >> 2) + ((p.y_co + n_out) >> 2);
         *dst = make_float2(ssum, ssq);
     }
+}
+__device__ __forceinline__ void conv_stats_store(const onedc_conv_params &p, float ssum, float ssq, int m_wave,
+                                                 int n_out, int cout_store, int lane, int M) {
+    // M % 64 == 0: a block is whole or absent
+    conv_stats_store_row(p, ssum, ssq, m_wave >> 6, m_wave < M ? n_out : cout_store, cout_store, lane);
 }

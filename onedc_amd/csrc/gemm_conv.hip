@@ -237,6 +237,8 @@ int launch(const onedc_conv_params &p, hipStream_t st) {
 
 int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st);      // gemm_conv256.hip
 int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st);  // gemm_conv256.hip
+bool onedc_conv_win_ok(const onedc_conv_params &p);                             // gemm_conv_win.hip
+int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
 
 extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (!pp) return -1;
@@ -256,8 +258,19 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         return -10;
     hipStream_t st = as_stream(stream);
     if (p.in_f32) return launch<Tile<128, 128, 2, 2>, true>(p, st);
-    // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
+    // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per chunk)
+    {
+        const int rows128w = (p.Cout + 127) / 128 * 128;
+        const int64_t blocksw = (rows128w / 128) * (M64 / 256);
+        // measured (tools/bench_conv.py): 3-13 % faster than the 128x256 kernel on the 128 -> 128 layers at
+        // 768x768, 15-25 % slower on the 256 / 512-channel layers, so it is only taken when forced (tile = 130)
+        (void)blocksw;
+        if (p.tile == 130 && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) && rows128w * 5 <= p.Cout * 6)
+            return onedc_conv_win_launch(p, st);
+        if (p.tile == 130) return -11;
+    }
+    // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);         // short K: prologue + epilogue of the one resident block dominate
     if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 8) || p.tile == 256))

@@ -187,8 +187,11 @@ def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
 PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then bracketed by HIP events
 
 
-def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0):
+def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
     """The tile instantiation onedc_conv_gemm picks (mirrors the dispatcher in gemm_conv.hip)."""
+    rows128 = (cout + 127) // 128 * 128
+    if tile == 130 and win_ok and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6:
+        return "win3x3"
     if tile != 128 and cout % 256 == 0 and (((cout // 256) * blocks_m256 >= 160 and ktiles >= 8) or tile == 256):
         return "256x256"
     rows128 = (cout + 127) // 128 * 128
@@ -242,7 +245,10 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     e1.record()
     flops = 2.0 * p.B * p.OH * p.OW * p.Cout * (p.KH * p.KW * p.Cin) * max(batch, 1) * flop_scale
     bm = (p.B * p.OH * p.OW + 255) // 256 * max(batch, 1)
-    PROFILE.append(("f32_128x128" if p.in_f32 else conv_tile(p.Cout, glu, bm, tile, p.KH * p.KW * (p.Cin // 64)), flops, e0, e1))
+    win_ok = (p.KH == 3 and p.stride == 1 and not pixel_shuffle and batch <= 1 and not p.in_f32 and p.OH % 16 == 0 and
+              p.OW % 16 == 0 and p.Cin % 64 == 0)
+    PROFILE.append(("f32_128x128" if p.in_f32 else conv_tile(p.Cout, glu, bm, tile, p.KH * p.KW * (p.Cin // 64), win_ok),
+                    flops, e0, e1))
     return y
 
 

@@ -1,0 +1,87 @@
+"""The N > 1 path on CPU: two processes, gloo, 127.0.0.1.  Checks the weight broadcast (rank 1 ends up
+with bit-identical tensors of the right shapes), the static sharding of batches (a partition), the
+MAX reduction of step times, and that two ranks entropy-decoding their own shards with the host coder
+reproduce what a single process decodes (the data path needs no collective)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from onedc_amd import arch, synth
+from onedc_amd.dataparallel import broadcast_state_dicts, max_over_ranks, shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = arch.codec_decode_spec()
+        sds = [synth.codec_state_dict(0)] if rank == 0 else [None]
+        got = broadcast_state_dicts(sds, [spec], torch.device("cpu"), rank, world)[0]
+        ref = synth.codec_state_dict(0)
+        assert set(got) == set(spec)
+        for k, shape in spec.items():
+            assert tuple(got[k].shape) == tuple(shape), k
+            assert torch.equal(got[k], ref[k].float()), k
+        # sharding: every batch exactly once
+        mine = shard(7, rank, world)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        assert sorted(sum(gathered, [])) == list(range(7))
+        # slowest rank decides
+        t = max_over_ranks(1.0 + rank, torch.device("cpu"), world)
+        assert t == float(world)
+        # data path without collectives: each rank decodes its own streams with the host coder
+        from onedc_amd.entropy import rans
+        from onedc_amd.entropy.entropy_models import EntropyCoder, GaussianEncoder
+        ge = GaussianEncoder()
+        ge.update(force=True, entropy_coder=EntropyCoder(False, 1))
+        tables = ge.get_cdf_info()
+        rng = np.random.default_rng(123)
+        streams, syms, idxs = [], [], []
+        for b in range(6):
+            idx = rng.integers(0, 256, 4096).astype(np.int16)
+            sym = np.clip(np.rint(rng.normal(0, 3, 4096)), -60, 60).astype(np.int16)
+            e = rans.RansEncoder(False, 1)
+            e.add_cdf(*tables)
+            e.encode_with_indexes(sym, idx, 0)
+            e.flush()
+            streams.append(e.get_encoded_stream().tobytes())
+            syms.append(sym)
+            idxs.append(idx)
+        for b in shard(6, rank, world):
+            d = rans.RansDecoder(1)
+            d.add_cdf(*tables)
+            d.set_stream(np.frombuffer(streams[b], dtype=np.uint8))
+            assert np.array_equal(d.decode_stream(idxs[b], 0), syms[b])
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_broadcast_shard_and_decode(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_shard_is_a_partition():
+    for n in (0, 1, 5, 16, 129):
+        for world in (1, 2, 4, 8):
+            parts = [shard(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1

@@ -560,3 +560,57 @@ def test_flash_attention_reference_point_moves():
     got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
     assert torch.isfinite(got).all()
     close(got, ref, rms=1e-2, mx=4e-2, what="flash attention, moving reference")
+
+
+# ---- 3x3 window kernel (16x16-pixel patches, every input pixel staged once per chunk; tile=130) -----------
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 16, 16, 64, 128),         # one patch, one chunk: nine K-tiles, borders on all four sides
+    (2, 32, 48, 128, 128),        # interior patches, two chunks (window double buffer)
+    (1, 48, 32, 192, 320),        # three chunks, 320 channels (last channel tile mostly padding rows)
+    (3, 16, 32, 256, 256),        # two channel tiles, batch
+])
+def test_conv_win3x3_plain(B, H, W, Cin, Cout):
+    x, w, b = rnd(B, Cin, H, W, seed=121), rnd(Cout, Cin, 3, 3, seed=122, scale=(Cin * 9) ** -0.5), rnd(Cout, seed=123)
+    y = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=3, tile=130)
+    close(y.torch_nchw(), F.conv2d(x, w, b, padding=1), what="win3x3")
+    # against the generic kernel: same products, different summation order (chunk-major vs tap-major)
+    y2 = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y2, KH=3, tile=128)
+    close(y.torch_nchw(), y2.torch_nchw(), rms=3e-3, mx=2e-2, what="win3x3 vs generic")
+
+
+def test_conv_win3x3_upsample_residual_stats_slices():
+    B, H, W, Cin, Cout = 2, 16, 24, 128, 128
+    x, w, b = rnd(B, Cin, H, W, seed=124), rnd(Cout, Cin, 3, 3, seed=125, scale=1 / 34), rnd(Cout, seed=126)
+    r = rnd(B, Cout, 2 * H, 2 * W, seed=127)
+    xbuf = from_nchw(torch.cat([rnd(B, 64, H, W, seed=128), x], 1).to(DEV))          # input from a channel slice
+    ybuf = new_view(B, 2 * H, 2 * W, Cout + 64, DEV, stats=True)
+    ybuf.t.zero_()
+    K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), ybuf.slice(64, Cout), KH=3, up=1, tile=130,
+                res=from_nchw(r.to(DEV)), epi=K.EPI_SILU, stats=True)
+    ref = F.silu(F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)) + r
+    close(ybuf.slice(64, Cout).torch_nchw(), ref, what="win3x3 up+silu+res")
+    assert float(ybuf.slice(0, 64).torch_nchw().abs().max()) == 0.0
+    g, be = rnd(Cout, seed=129), rnd(Cout, seed=130)
+    out = new_view(B, 2 * H, 2 * W, Cout, DEV)
+    K.group_norm(ybuf.slice(64, Cout), g.to(DEV), be.to(DEV), out, 1e-6, True, _WS())
+    close(out.torch_nchw(), F.silu(F.group_norm(ref, 32, g, be, 1e-6)), rms=6e-3, mx=4e-2, what="win3x3 stats")
+
+
+def test_conv_win3x3_race_screen_and_batch_invariance():
+    x, w = rnd(4, 256, 48, 48, seed=131), rnd(128, 256, 3, 3, seed=132, scale=1 / 48)
+    xv, wp = from_nchw(x.to(DEV)), packed(w)
+    ref = None
+    for it in range(40):
+        y = new_view(4, 48, 48, 128, DEV)
+        K.conv_gemm(xv, wp, None, y, KH=3, tile=130)
+        got = y.t[:4 * 48 * 48 * 128].clone()
+        if ref is None:
+            ref = got
+            close(y.torch_nchw(), F.conv2d(x, w, None, padding=1), what="win3x3 race ref")
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"
+    y1 = new_view(1, 48, 48, 128, DEV)
+    K.conv_gemm(from_nchw(x[2:3].to(DEV)), wp, None, y1, KH=3, tile=130)
+    assert torch.equal(y1.t[:48 * 48 * 128], ref.view(4, -1)[2])

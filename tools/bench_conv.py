@@ -29,7 +29,7 @@ SHAPES = [  # (name, B, H, W, Cin, Cout, k, up)
 ]
 
 
-TILES = (128, 129, 256)
+TILES = (129, 256, 130)
 
 
 def main():
@@ -46,7 +46,8 @@ def main():
         fl = 2.0 * B * OH * OW * Cout * k * k * Cin
         res = []
         for tile in TILES:                      # interleaved in one process (same data, same clocks)
-            if (tile == 256 and Cout % 256) or (tile == 129 and (Cout + 127) // 128 * 128 * 5 > Cout * 6):
+            if ((tile == 256 and Cout % 256) or (tile in (129, 130) and (Cout + 127) // 128 * 128 * 5 > Cout * 6) or
+                    (tile == 130 and (k != 3 or OH % 16 or OW % 16))):
                 res.append(float("nan"))
                 continue
             for _ in range(2):

@@ -12,6 +12,7 @@ from onedc_amd import kernels as K
 from onedc_amd import pack
 
 B, H, W, Cin, Cout, k, up = map(int, sys.argv[1:8])
+TILE = int(sys.argv[8]) if len(sys.argv) > 8 else 129
 DEV = "cuda:0"
 g = torch.Generator(device=DEV).manual_seed(0)
 x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(torch.bfloat16), B, H, W, Cin)
@@ -30,7 +31,7 @@ class FakeStats:
 
 y.stats = FakeStats()
 for _ in range(3):
-    K.conv_gemm(x, w, None, y, KH=k, up=up, tile=129, stats=True)
+    K.conv_gemm(x, w, None, y, KH=k, up=up, tile=TILE, stats=True)
 torch.cuda.synchronize()
 d = dbg.view(2048, 8, 8).cpu().double()
 names = ["prologue", "load-seg issue", "barrier1", "lgkmcnt wait", "mfma seg", "barrier2", "vmcnt wait", "epilogue"]
