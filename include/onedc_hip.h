@@ -66,6 +66,7 @@ typedef struct onedc_conv_params {
                                            128 = 4-wave kernels (128x128 / 64x128 / 16x256 tiles),
                                            256 = 8-wave 256x256 tile, 129 = 8-wave 128(ch)x256(px) tile,
                                            130 = 3x3 window kernel (16x16-pixel patches, stride 1, pad 1) */
+    int32_t patch16;                    /* set by onedc_conv_gemm (callers leave 0): pixel tiles are 16x16 patches */
     int32_t in_f32;                     /* 1: x, w, res are f32 (exact f32 MFMA; Cin multiple of 32): the prior
                                            networks, whose outputs feed integer decisions, and the VAE's conv_in */
     int64_t x_bs, w_bs, y_bs, r_bs;     /* element strides between batches */

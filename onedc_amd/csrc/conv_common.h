@@ -60,6 +60,37 @@ struct ConvPixSrc {
     }
 };
 
+// 2-D pixel tiles.  A GEMM row tile of 256 pixels is by default 256 consecutive pixels of the row-major
+// (image, y, x) order: at 768 pixels per line that is a third of a line, and the 3x3 taps of a tile touch
+// three such segments whose neighbours above and below belong to tiles that run much later (or on another
+// XCD) -- measured HBM reads of the 256-tile kernel were 4.6x the input bytes.  With patch16 the tile is a
+// 16 x 16 patch: its nine taps touch one 18 x 18 window (1.27x the patch), and tiles that follow each other
+// on an XCD are neighbouring patches.  Needs OH, OW multiples of 16.
+struct ConvPatch {
+    int img, y0, x0;      // patch origin of this workgroup's pixel tile (patch16 only)
+    bool on;
+};
+__device__ __forceinline__ ConvPatch conv_patch(const onedc_conv_params &p, int m0) {
+    ConvPatch c;
+    c.on = p.patch16 != 0;
+    c.img = c.y0 = c.x0 = 0;
+    if (c.on) {
+        const int px = p.OW >> 4, pi = (p.OH >> 4) * px;
+        const int T = m0 >> 8;
+        c.img = T / pi;
+        const int r = T - c.img * pi;
+        const int ty = r / px;
+        c.y0 = ty << 4;
+        c.x0 = (r - ty * px) << 4;
+    }
+    return c;
+}
+// linear output pixel index of tile position t (0..255) of the tile starting at GEMM row m0
+__device__ __forceinline__ int conv_tile_pixel(const onedc_conv_params &p, const ConvPatch &c, int m0, int t) {
+    if (c.on) return (c.img * p.OH + c.y0 + (t >> 4)) * p.OW + c.x0 + (t & 15);
+    return m0 + t;
+}
+
 // Output position of one pixel row m of the GEMM (decomposed once per pixel, used by every channel tile).
 struct ConvOutPix {
     int m;            // GEMM row (output pixel on the conv grid)

@@ -242,7 +242,13 @@ int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
 
 extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (!pp) return -1;
-    const onedc_conv_params &p = *pp;
+    onedc_conv_params p = *pp;
+    // 2-D pixel tiles for the 8-wave kernels (conv_common.h: ConvPatch); EXP_NOPATCH builds keep linear tiles
+#ifndef EXP_NOPATCH
+    p.patch16 = (p.KH > 1 && (p.OH & 15) == 0 && (p.OW & 15) == 0 && !p.pixel_shuffle && p.batch <= 1) ? 1 : 0;
+#else
+    p.patch16 = 0;
+#endif
     if (!p.x || !p.w || !p.y || !p.zeros) return -1;
     if (p.Cin <= 0 || (p.Cin & (p.in_f32 ? 31 : 63)) || p.Cout <= 0) return -2;
     if ((p.x_cs | p.x_co) & (p.in_f32 ? 3 : 7)) return -3; // 16-byte aligned source chunks

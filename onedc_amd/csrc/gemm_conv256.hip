@@ -58,11 +58,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;
     const int64_t wrow64 = (int64_t)64 * Ktot * 2;         // byte stride of 64 weight rows
     // pixels: pixel(h, i) = m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
-    ConvPixSrc<4> px;                              // [h * 2 + i]: pixel m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
+    const ConvPatch patch = conv_patch(p, m0);
+    ConvPixSrc<4> px;                              // [h * 2 + i]: tile position ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
     {
         int mrow[4];
 #pragma unroll
-        for (int hi = 0; hi < 4; ++hi) mrow[hi] = m0 + ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31);
+        for (int hi = 0; hi < 4; ++hi)
+            mrow[hi] = conv_tile_pixel(p, patch, m0, ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31));
         px.init(p, mrow, M);
     }
     const char *xb0 = xb + p.x_co * 2 + chunk * 16;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
         EpiRes<false> res[2][2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
+            const int m = conv_tile_pixel(p, patch, m0, wc * 64 + b * 32 + j * 16 + frow);
             const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
+            const int m = conv_tile_pixel(p, patch, m0, wc * 64 + b * 32 + j * 16 + frow);
             const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -325,11 +327,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     const int t64 = wave * 8 + lrow;
     const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;     // weight rows t64 and t64 + 64
     const int64_t wrow64 = (int64_t)64 * Ktot * 2;
-    ConvPixSrc<4> px;                              // [h * 2 + i]: pixel m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
+    const ConvPatch patch = conv_patch(p, m0);
+    ConvPixSrc<4> px;                              // [h * 2 + i]: tile position ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
     {
         int mrow[4];
 #pragma unroll
-        for (int hi = 0; hi < 4; ++hi) mrow[hi] = m0 + ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31);
+        for (int hi = 0; hi < 4; ++hi)
+            mrow[hi] = conv_tile_pixel(p, patch, m0, ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31));
         px.init(p, mrow, M);
     }
     const char *xb0 = xb + p.x_co * 2 + chunk * 16;
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
+            const int m = conv_tile_pixel(p, patch, m0, wc * 64 + b * 32 + j * 16 + frow);
             const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     for (int b = 0; b < 2; ++b)                    // pass 2: finish + store
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wc * 64 + b * 32 + j * 16 + frow;
+            const int m = conv_tile_pixel(p, patch, m0, wc * 64 + b * 32 + j * 16 + frow);
             const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

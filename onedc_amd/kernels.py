@@ -25,7 +25,7 @@ class ConvParams(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32),
         ("epi", C.c_int32), ("out_f32", C.c_int32), ("pixel_shuffle", C.c_int32),
         ("alpha", _F), ("slope", _F),
-        ("batch", C.c_int32), ("tile", C.c_int32), ("in_f32", C.c_int32),
+        ("batch", C.c_int32), ("tile", C.c_int32), ("patch16", C.c_int32), ("in_f32", C.c_int32),
         ("x_bs", _L), ("w_bs", _L), ("y_bs", _L), ("r_bs", _L),
     ]
 
