@@ -129,6 +129,9 @@ int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int 
 /* FSQ.indices_to_codes, levels [4]*7 (codec_module.py:431): idx int32 [n] -> f32 codes [n][8]
  * (7 used, channel 7 = 0). */
 int onedc_fsq_codes(const int32_t *idx, float *codes, int64_t n, void *stream);
+/* FSQ.forward quantisation of the hyper latent on the encode side (codec_module.py:379; same levels):
+ * z NHWC (bf16 / f32) with channel stride z_cs, the 7 dims at offset z_co -> int32 indices [n] */
+int onedc_fsq_quantize(const void *z, int z_f32, int z_cs, int z_co, int32_t *idx, int64_t n, void *stream);
 
 /* One step k of the four-part prior (compression_model.py:369-407 decode, :303-358 encode).
  * params: bf16/f32 NHWC [B][H][W][2C] = (scales | means), C = 128.

@@ -117,6 +117,23 @@ def codec_decode_spec(N=128, internal_ch=512, semantic_ch=768, ctrl_ch=320, z_di
     return d
 
 
+def hyper_enc_spec(N=128, internal_ch=512, semantic_ch=768, z_dim=7):
+    """HyperEncoder — codec_module.py:119-142 (the hyper analysis of the encode path)."""
+    d = OrderedDict()
+    p = "hyper_enc"
+    dcb4(d, f"{p}.y_trans_coding.0", N, N)
+    _conv(d, f"{p}.y_trans_coding.1", N, N, 3)              # stride 2
+    dcb4(d, f"{p}.y_trans_coding.2", N, N)
+    _conv(d, f"{p}.y_trans_coding.3", N, N, 3)              # stride 2
+    dcb4(d, f"{p}.fusion.0", N + semantic_ch, semantic_ch)
+    vq_attn(d, f"{p}.fusion.1", semantic_ch)
+    dcb4(d, f"{p}.fusion.2", semantic_ch, internal_ch)
+    vq_attn(d, f"{p}.fusion.3", internal_ch)
+    dcb4(d, f"{p}.fusion.4", internal_ch, internal_ch)
+    _conv(d, f"{p}.fusion.5", z_dim, internal_ch, 1)
+    return d
+
+
 CODEC_IGNORED_PREFIXES = ("enc.", "hyper_enc.", "z_vq.")
 
 

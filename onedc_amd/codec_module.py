@@ -6,9 +6,10 @@ four-part prior of src/modules/entropy/compression_model.py:303-407.  The refere
 here every call takes a list of bitstreams and runs them as one batch (same arithmetic per image:
 all kernels are batch-invariant), which is what makes the rANS hops and launches amortise.
 
-The analysis transform (`enc`, `hyper_enc`) is out of scope for this round; `encode_latents`
-implements the encode side of the prior + entropy coder from given (z indices, y) so that valid
-bitstreams can be produced and the enc/dec round trip can be tested.
+Encode side built so far: `HyperEncoder` + FSQ quantisation + `compress` (hyper analysis
+-> indices -> four-part prior -> rANS -> container) from the analysis transform's outputs (y, sem), and
+`encode_latents` (the prior + entropy coder from given (z indices, y)).  The analysis transform `enc`
+itself (SD-VAE encoder + UNet2DModel, third-party bodies) is not built yet.
 """
 import os
 
@@ -47,6 +48,38 @@ class HyperDecoder:
         if self.f32:
             z = K.copy_channels(z, new_view(z.B, z.H, z.W, z.C, dev))
         return h, z
+
+
+class HyperEncoder:
+    """Encode side: reference HyperEncoder, codec_module.py:119-142.
+    z = fusion(cat(y_trans_coding(y), sem)); the FSQ quantisation of z is `IntraNoAR.compress`."""
+
+    def __init__(self, sd, device, N=128, semantic_ch=768, internal_ch=512, p="hyper_enc"):
+        self.N, self.semantic_ch = N, semantic_ch
+        self.t0 = DepthConvBlock4(sd, f"{p}.y_trans_coding.0", device)
+        self.t1 = Conv(sd, f"{p}.y_trans_coding.1", device)
+        self.t2 = DepthConvBlock4(sd, f"{p}.y_trans_coding.2", device)
+        self.t3 = Conv(sd, f"{p}.y_trans_coding.3", device)
+        self.f0 = DepthConvBlock4(sd, f"{p}.fusion.0", device)
+        self.f1 = VQAttnBlock(sd, f"{p}.fusion.1", device, semantic_ch)
+        self.f2 = DepthConvBlock4(sd, f"{p}.fusion.2", device)
+        self.f3 = VQAttnBlock(sd, f"{p}.fusion.3", device, internal_ch)
+        self.f4 = DepthConvBlock4(sd, f"{p}.fusion.4", device)
+        self.f5 = Conv(sd, f"{p}.fusion.5", device)
+
+    def __call__(self, y, sem, ws):
+        """y: bf16 View (B,H/16,W/16,N); sem: bf16 View (B,H/64,W/64,semantic_ch) -> z f32 View (.., 7 of 8)."""
+        dev = y.t.device
+        z = self.t1(self.t0(y), stride=2)
+        cat = new_view(sem.B, sem.H, sem.W, self.N + self.semantic_ch, dev)     # torch.cat([z, sem], 1) without a copy
+        self.t3(self.t2(z), cat.slice(0, self.N), stride=2)
+        K.copy_channels(sem, cat.slice(self.N, self.semantic_ch))
+        h = self.f1(self.f0(cat), ws)
+        h = self.f3(self.f2(h), ws)
+        h = self.f4(h)
+        zbuf = View(torch.zeros((h.B * h.H * h.W + K.SLACK_ROWS) * 8, dtype=torch.float32, device=dev), h.B, h.H, h.W, 8)
+        self.f5(h, zbuf.slice(0, 7))
+        return zbuf
 
 
 class SemanticAdaptor:
@@ -259,6 +292,34 @@ class IntraNoAR:
         y_hat, z_semantic = self.decompress([d["bit_stream_y"] for d in infos], indices)
         orig_hw = [(d["height"], d["width"]) for d in infos]
         return y_hat, z_semantic, orig_hw, (pad_h, pad_w), infos[0]["pad_tuple"]
+
+    # ------------------------------------------------------------------ encode side
+    def load_hyper_encoder(self, sd):
+        """The hyper analysis weights (`hyper_enc.*` of model_1.safetensors; a decode-only load skips them)."""
+        self.hyper_enc = HyperEncoder(sd, self.device, self.N)
+        return self
+
+    @torch.no_grad()
+    def compress(self, y, sem, heights=None, widths=None):
+        """codec_module.py:372-415 after the analysis transform `enc` (SD-VAE encoder + UNet2DModel: not
+        built yet): hyper analysis, FSQ quantisation, four-part prior, rANS, index packing, container.
+        y: f32 NHWC device tensor (B,H/16,W/16,N); sem: bf16/f32 NHWC tensor (B,H/64,W/64,768).
+        -> (list of container bytes, indices int32 (B,h,w), y_hat View)."""
+        if getattr(self, "hyper_enc", None) is None:
+            raise RuntimeError("compress needs the hyper encoder weights: call load_hyper_encoder(state_dict)")
+        B, H, W, N = y.shape
+        yb = View(torch.empty((B * H * W + K.SLACK_ROWS) * N, dtype=torch.bfloat16, device=self.device), B, H, W, N)
+        yb.t[:B * H * W * N] = y.reshape(-1).to(torch.bfloat16)
+        sb = View(torch.empty((sem.shape[0] * sem.shape[1] * sem.shape[2] + K.SLACK_ROWS) * sem.shape[3],
+                              dtype=torch.bfloat16, device=self.device), sem.shape[0], sem.shape[1], sem.shape[2],
+                  sem.shape[3])
+        sb.t[:sem.numel()] = sem.reshape(-1).to(torch.bfloat16)
+        z = self.hyper_enc(yb, sb, self.ws)
+        indices = torch.empty(B * z.H * z.W, dtype=torch.int32, device=self.device)
+        K.fsq_quantize(z.slice(0, 7), indices)
+        indices = indices.view(B, z.H, z.W)
+        blobs, y_hat = self.encode_latents(indices, y.contiguous().float(), heights=heights, widths=widths)
+        return blobs, indices, y_hat
 
     # ------------------------------------------------------------------ encode side of the prior
     @torch.no_grad()

@@ -106,6 +106,24 @@ __global__ void fsq_codes_kernel(const int32_t *idx, float *codes, int64_t n) {
     }
 }
 
+// FSQ quantisation, levels [4]*7 (vector-quantize-pytorch FSQ.forward; call site codec_module.py:379):
+// q_d = round(tanh(z_d + atanh(0.5 / 1.5015)) * 1.5015 - 0.5) in {-2..1}; index = sum (q_d + 2) 4^d
+template <bool F32>
+__global__ void fsq_quantize_kernel(const void *z, int z_cs, int z_co, int32_t *idx, int64_t n) {
+    const float half_l = 1.5015f;                    // (4 - 1)(1 + 1e-3) / 2
+    const float shift = 0.34619963f;                 // atanh(0.5 / 1.5015)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int v = 0;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {
+            const float q = rintf(tanhf(ldp<F32>(z, i * z_cs + z_co + d) + shift) * half_l - 0.5f);
+            v |= (((int)q + 2) & 3) << (2 * d);
+        }
+        idx[i] = v;
+    }
+}
+
 __global__ void x0_kernel(const float *reduced, const float *eps, float *x0, int64_t n, double sa, double sb) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
@@ -316,6 +334,13 @@ const char *onedc_hip_version(void) { return "onedc-hip 0.1 (gfx950)"; }
 int onedc_fsq_codes(const int32_t *idx, float *codes, int64_t n, void *stream) {
     if (!idx || !codes) return -1;
     LAUNCH(fsq_codes_kernel, n * 8, idx, codes, n);
+    return 0;
+}
+
+int onedc_fsq_quantize(const void *z, int z_f32, int z_cs, int z_co, int32_t *idx, int64_t n, void *stream) {
+    if (!z || !idx || z_cs < 7) return -1;
+    if (z_f32) LAUNCH(fsq_quantize_kernel<true>, n, z, z_cs, z_co, idx, n);
+    else LAUNCH(fsq_quantize_kernel<false>, n, z, z_cs, z_co, idx, n);
     return 0;
 }
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "onedc_softmax_rows": (_I, [_P, _P, _L, _I, _I, _P]),
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_fsq_codes": (_I, [_P, _P, _L, _P]),
+    "onedc_fsq_quantize": (_I, [_P, _I, _I, _I, _P, _L, _P]),
     "onedc_prior_indexes": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "onedc_prior_update_dec": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_prior_update_enc": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -317,6 +318,13 @@ def flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale):
 def fsq_codes(idx, codes):
     _ok(lib().onedc_fsq_codes(idx.data_ptr(), codes.data_ptr(), idx.numel(), stream()), "onedc_fsq_codes")
     return codes
+
+
+def fsq_quantize(z, idx):
+    """z: View (B,h,w,>=7) -> int32 indices tensor [B*h*w]."""
+    _ok(lib().onedc_fsq_quantize(z.ptr, int(z.f32), z.cs, z.co, idx.data_ptr(), z.B * z.H * z.W, stream()),
+        "onedc_fsq_quantize")
+    return idx
 
 
 def prior_indexes(params, indexes, B, H, W, Cc, step):

@@ -51,6 +51,14 @@ def codec_state_dict(seed=0, scale_bias=1.0):
     return sd
 
 
+def hyper_enc_state_dict(seed=0):
+    """HyperEncoder weights (encode side).  The last 1x1 gets a x3 gain so the synthetic z spreads over
+    all four FSQ levels per dimension instead of sitting at the two central ones."""
+    sd = make_state_dict(arch.hyper_enc_spec(), seed)
+    sd["hyper_enc.fusion.5.weight"] *= 3.0
+    return sd
+
+
 def unet_state_dict(seed=0, lora=True):
     return make_state_dict(arch.unet_spec(lora=lora), seed)
 

@@ -104,6 +104,42 @@ def fsq_indices_to_codes(indices, levels=(4,) * 7):
     return torch.stack(codes, dim=1)
 
 
+def fsq_quantize(z, levels=(4,) * 7, eps=1e-3):
+    """vector-quantize-pytorch 1.21.2 FSQ.forward for dim == len(levels) (no projections; call sites
+    codec_module.py:235, :301, :379): bound -> round -> codes and their mixed-radix index.
+        half_l = (L-1)(1+eps)/2; offset = 0.5 for even L; shift = atanh(offset/half_l)
+        q = round(tanh(z + shift) * half_l - offset);  code = q / (L//2);  digit = q + L//2
+    z (B,len(levels),H,W) float -> (z_hat (B,D,H,W) float32, indices (B,H,W) int32).
+    PARITY UNPINNED (third-party formula restated)."""
+    z = z.float()
+    codes, index, basis = [], 0, 1
+    for d, L in enumerate(levels):
+        half_l = (L - 1) * (1 + eps) / 2
+        offset = 0.5 if L % 2 == 0 else 0.0
+        shift = math.atanh(offset / half_l)
+        q = torch.round(torch.tanh(z[:, d] + shift) * half_l - offset)
+        codes.append(q / (L // 2))
+        index = index + (q + (L // 2)).to(torch.int64) * basis
+        basis *= L
+    return torch.stack(codes, 1), index.to(torch.int32)
+
+
+def hyper_encoder(sd, y, sem, p="hyper_enc"):
+    """codec_module.py:119-142: z = fusion(cat(y_trans_coding(y), sem)).  y (B,128,H/16,W/16),
+    sem (B,768,H/64,W/64) -> z (B,7,H/64,W/64)."""
+    z = depth_conv_block4(sd, f"{p}.y_trans_coding.0", y)
+    z = conv(sd, f"{p}.y_trans_coding.1", z, stride=2, padding=1)
+    z = depth_conv_block4(sd, f"{p}.y_trans_coding.2", z)
+    z = conv(sd, f"{p}.y_trans_coding.3", z, stride=2, padding=1)
+    z = torch.cat([z, sem], 1)
+    z = depth_conv_block4(sd, f"{p}.fusion.0", z)
+    z = vq_attn_block(sd, f"{p}.fusion.1", z)
+    z = depth_conv_block4(sd, f"{p}.fusion.2", z)
+    z = vq_attn_block(sd, f"{p}.fusion.3", z)
+    z = depth_conv_block4(sd, f"{p}.fusion.4", z)
+    return conv(sd, f"{p}.fusion.5", z)
+
+
 def hyper_decoder(sd, z_hat, p="hyper_dec"):
     """codec_module.py:145-166 -> (params, z_semantic)."""
     z = F.leaky_relu(conv(sd, f"{p}.feat_in.0", z_hat), 0.01)

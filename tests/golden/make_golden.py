@@ -277,6 +277,18 @@ def main():
          mask2=masks[2][0, ::32, :4, :4], mask3=masks[3][0, ::32, :4, :4],
          y_semantic=sample_points(y_semantic, 4096), x_hat=sample_points(x_hat, 8192))
 
+    # ---------------------------------------------------------------- G7 hyper encoder (encode side)
+    print("G7 hyper encoder")
+    with torch.no_grad():
+        henc = rcm.HyperEncoder(N, 768, 512, [4] * 7)
+        henc.load_state_dict(sub_sd(synth.hyper_enc_state_dict(0), "hyper_enc."), strict=True)
+        henc.eval()
+        g7 = torch.Generator().manual_seed(11)
+        y7 = 2.0 * torch.randn(2, N, 8, 12, generator=g7)            # a 128x192 picture: y at 1/16, sem at 1/64
+        sem7 = torch.randn(2, 768, 2, 3, generator=g7)
+        z7 = henc(y7, sem7)
+    save("g7_hyper_enc.npz", y=y7, sem=sem7, z=z7)
+
     # ---------------------------------------------------------------- G6 closed forms
     print("G6 closed forms")
     from modules.dmd.utils import get_x0_from_noise

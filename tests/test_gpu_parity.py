@@ -307,3 +307,40 @@ def test_decode_pipeline_matches_sequential_decode():
         assert torch.equal(a, b)
     for a, b in zip(seq[::-1], got2):
         assert torch.equal(a, b)
+
+
+# ---- encode side -----------------------------------------------------------------------------
+def test_hyper_encoder_fsq_and_compress_round_trip(codec, codec_sd):
+    """HyperEncoder on HIP vs the oracle (bf16 nets: 3e-2 rel. RMS), the FSQ quantisation kernel vs the
+    oracle's formula on identical z (integer result: equal except for values within float rounding of a
+    cell edge, <= 1e-4 of the entries), and compress() -> decode(): the decoder recovers the encoder's
+    indices and y_hat bit for bit."""
+    g = golden("g7_hyper_enc.npz")
+    henc_sd = synth.hyper_enc_state_dict(0)
+    codec.load_hyper_encoder(henc_sd)
+    y, sem = torch.from_numpy(g["y"]), torch.from_numpy(g["sem"])
+    yv, sv = from_nchw(y.to(DEV)), from_nchw(sem.to(DEV))
+    z = codec.hyper_enc(yv, sv, codec.ws)
+    with torch.no_grad():
+        z_ref = R.hyper_encoder(henc_sd, y.to(torch.bfloat16).float(), sem.to(torch.bfloat16).float())
+    check(z.slice(0, 7).torch_nchw(), z_ref, 3e-2, "hyper encoder z vs oracle")
+    check(z.slice(0, 7).torch_nchw(), torch.from_numpy(g["z"]), 3e-2, "hyper encoder z vs reference golden")
+    # FSQ kernel on a dense sweep of z values
+    zz = (torch.rand(4, 7, 16, 16, generator=torch.Generator().manual_seed(31)) * 6 - 3)
+    zzv = from_nchw(zz.to(DEV), torch.float32, pad_to=8)
+    idx = torch.empty(4 * 16 * 16, dtype=torch.int32, device=DEV)
+    K.fsq_quantize(zzv.slice(0, 7), idx)
+    _, idx_ref = R.fsq_quantize(zz)
+    bad = int((idx.cpu().view(4, 16, 16) != idx_ref).sum())
+    assert bad <= 1, bad
+    # compress -> decode
+    yn = (2.0 * torch.randn(2, 8, 12, 128, generator=torch.Generator().manual_seed(32))).to(DEV)
+    sn = sem.permute(0, 2, 3, 1).contiguous().to(DEV)
+    blobs, indices, y_hat_enc = codec.compress(yn, sn, heights=[128, 120], widths=[192, 180])
+    y_hat_dec, z_sem, orig_hw, pad_hw, _ = codec.decode_entropy(stream=blobs)
+    assert orig_hw == [(128, 192), (120, 180)] and pad_hw == (128, 192)
+    assert torch.equal(y_hat_dec.torch_nchw(), y_hat_enc.torch_nchw())
+    from onedc_amd.entropy.utils import decode_i, unpack_indices
+    got = np.stack([unpack_indices(decode_i(b, 14, 64)["bit_stream_z"], 6, 14) for b in blobs]).reshape(2, 2, 3)
+    assert np.array_equal(got, indices.cpu().numpy())
+    assert len(set(indices.cpu().numpy().reshape(-1).tolist())) > 1         # the synthetic z really spreads

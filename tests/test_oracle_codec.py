@@ -1,5 +1,7 @@
 """Pins oracle/torch_ref.py (the fp32 restatement every GPU parity test is checked against) to
 outputs of the reference's own Python modules (tests/golden/g5*, g6*; see make_golden.py)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -182,3 +184,35 @@ def test_windowed_attention_equals_full_when_patch_covers_map():
     with torch.no_grad():
         assert torch.allclose(R.windowed_attn(sd, p, x, 8), R.vae_attention(sd, p, x), atol=1e-6)
         assert not torch.allclose(R.windowed_attn(sd, p, x, 4), R.vae_attention(sd, p, x), atol=1e-3)
+
+
+# ---- encode side: hyper analysis + FSQ quantisation ------------------------------------------
+def test_hyper_encoder_matches_reference_golden():
+    """oracle hyper_encoder vs the reference's own HyperEncoder module (strict-loaded with the synthetic
+    weights, tests/golden/make_golden.py G7): fp32 both sides, tolerance 2e-5 rel. RMS (op order)."""
+    g = golden("g7_hyper_enc.npz")
+    sd = synth.hyper_enc_state_dict(0)
+    with torch.no_grad():
+        z = R.hyper_encoder(sd, torch.from_numpy(g["y"]), torch.from_numpy(g["sem"]))
+    ref = torch.from_numpy(g["z"])
+    assert z.shape == ref.shape == (2, 7, 2, 3)
+    err = float((z - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert err <= 2e-5, err
+
+
+def test_fsq_quantize_inverts_indices_to_codes_on_all_16384_entries():
+    """quantize(z) at the centre of every cell returns that cell: codes and mixed-radix index agree with
+    indices_to_codes (the decode side) for the whole code book; cell edges sit at half-integers of
+    tanh(z + shift) * 1.5015 - 0.5."""
+    idx = torch.arange(16384, dtype=torch.int32).view(1, 128, 128)
+    codes = R.fsq_indices_to_codes(idx)                                   # (1,7,128,128) in {-1,-.5,0,.5}
+    q = codes * 2                                                        # {-2..1}
+    z = torch.atanh((q + 0.5) / 1.5015) - math.atanh(0.5 / 1.5015)       # pre-image of the cell centres
+    z_hat, got = R.fsq_quantize(z)
+    assert torch.equal(got, idx) and torch.equal(z_hat, codes)
+    # just inside / outside a cell edge
+    edge = torch.atanh(torch.tensor((0.5 + 0.5) / 1.5015)) - math.atanh(0.5 / 1.5015)   # between q = 0 and q = 1
+    zz = torch.zeros(1, 7, 1, 2)
+    zz[0, 0, 0, 0], zz[0, 0, 0, 1] = edge - 1e-3, edge + 1e-3
+    zh, _ = R.fsq_quantize(zz)
+    assert zh[0, 0, 0, 0] == 0.0 and zh[0, 0, 0, 1] == 0.5
