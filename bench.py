@@ -147,13 +147,23 @@ def main():
 
     if rank == 0:
         by_tile = {}
-        for tile, flops, e0, e1 in prof:
-            d = by_tile.setdefault(tile, [0.0, 0.0, 0])
+        for tile, flops, e0, e1, nbytes in prof:
+            d = by_tile.setdefault(tile, [0.0, 0.0, 0, 0.0])
             d[0] += flops
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += 1
+            d[3] += nbytes
         dom = max(by_tile, key=lambda k: by_tile[k][1])
-        flops, secs, launches = by_tile[dom]
+        flops, secs, launches, dom_bytes = by_tile[dom]
+        # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in
+        # separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) and committed under
+        # profiles/; PMC passes serialise every dispatch, so they cannot run inside the timed region.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get("conv_gemm256_kernel" if dom == "256x256" else dom)
+            if t:
+                traffic = t["hbm_bytes_per_launch"]
         all_flops = sum(v[0] for v in by_tile.values())
         all_secs = sum(v[1] for v in by_tile.values())
         achieved = flops / secs / 1e12
@@ -172,7 +182,8 @@ def main():
                        "schedule": "sequential decode() calls" if args.sequential else
                                    "2-stage pipeline over batches (entropy stage of batch n+1 || UNet+VAE of batch n)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(dom_bytes / launches),
                          "kernel": ("conv_gemm256_kernel" if dom == "256x256" else
                                     "conv_gemm128x256_kernel" if dom == "128x256" else
                                     "conv_win_kernel" if dom == "win3x3" else

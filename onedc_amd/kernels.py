@@ -248,8 +248,14 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     bm = (p.B * p.OH * p.OW + 255) // 256 * max(batch, 1)
     win_ok = (p.KH == 3 and p.stride == 1 and not pixel_shuffle and batch <= 1 and not p.in_f32 and p.OH % 16 == 0 and
               p.OW % 16 == 0 and p.Cin % 64 == 0)
+    es_in = 4 if p.in_f32 else 2
+    es_out = 4 if p.out_f32 else 2
+    cout_store = p.Cout // 2 if glu else p.Cout
+    nbytes = (p.B * p.IH * p.IW * p.Cin * es_in + p.B * p.OH * p.OW * cout_store * es_out +
+              p.Cout * p.KH * p.KW * p.Cin * es_in + (p.B * p.OH * p.OW * cout_store * es_in if res is not None else 0)) \
+        * max(batch, 1)
     PROFILE.append(("f32_128x128" if p.in_f32 else conv_tile(p.Cout, glu, bm, tile, p.KH * p.KW * (p.Cin // 64), win_ok),
-                    flops, e0, e1))
+                    flops, e0, e1, float(nbytes)))
     return y
 
 
