@@ -120,8 +120,8 @@ int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, 
 /* Flash attention for the UNet's multi-head self/cross attention (diffusers Attention with
  * SDPA; call sites decoder_unet.py:204-293).  q [B][Nq][H*DQ], k [B][Nk][H*DQ] bf16,
  * vt [B][H*DV][Nk_pad] bf16 (V transposed, keys contiguous), o [B][Nq][H*DV].
- * DQ in {64, 96, 160}, DV in {48, 80, 160}: head dims 40/80/160 zero-padded by the packed
- * projection weights.  scale multiplies q.k before the softmax. */
+ * (DQ, DV) in {(64,48), (96,80), (160,160), (32,16)}: head dims 40 / 80 / 160 (decoder UNet) and 8 (the
+ * analysis UNet2DModel of the encode side), zero-padded by the packed projection weights.  scale multiplies q.k before the softmax. */
 int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
                      int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream);
 
@@ -170,6 +170,17 @@ int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, i
  * leaves ragged windows at the right/bottom edge; the caller covers them as extra regions. */
 int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int y0, int x0, int RH,
                            int RW, int wh, int ww, int reverse, void *stream);
+/* ---- encode side ------------------------------------------------------------------ */
+/* NCHW f32 picture -> NHWC view (f32 / bf16), replicate-padded from (H, W) to (Hp, Wp)
+ * (model_sd15_with_codec_stage1.py:281-285); channels beyond C of the destination are not written. */
+int onedc_nchw_to_nhwc(const float *x, void *y, int y_f32, int B, int C, int H, int W, int Hp, int Wp, int y_cs,
+                       int y_co, void *stream);
+/* input of Encoder.pix_emb (8x8 / stride 8 conv, codec_module.py:60) as a 1x1 GEMM operand:
+ * NHWC f32 picture (3 channels, stride x_cs) -> bf16 [B][H/8][W/8][192], k = (ky, kx, c) */
+int onedc_patchify8(const float *x, int x_cs, void *y, int B, int H, int W, void *stream);
+/* latent_dist.sample() * scaling_factor: moments f32 [n][8], noise f32 [n][4] or NULL (mode) -> f32 [n][4] */
+int onedc_latent_sample(const float *moments, const float *noise, float *out, int64_t n, float scale, void *stream);
+
 /* sinusoidal timestep embedding, flip_sin_to_cos, shift 0 (decoder_unet.py:138): f32 [n][dim] */
 int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *stream);
 /* y = a + b (bf16), used where a residual cannot ride on a GEMM epilogue */

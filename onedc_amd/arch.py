@@ -269,6 +269,125 @@ def vae_decoder_spec():
     return d
 
 
+VAE_DOWN = ((128, 128), (128, 256), (256, 512), (512, 512))  # (in, out) per encoder down block, 2 resnets each
+
+
+def vae_encoder_spec():
+    """SD-2.1 `AutoencoderKL` encoder half + `quant_conv` (diffusers 0.32.1 `Encoder`, DownEncoderBlock2D x4,
+    UNetMidBlock2D with one single-head attention; reference call: model_sd15_with_codec_stage1.py:191-195).
+    Published size: 34 163 592 parameters (+ quant_conv 72)."""
+    d = OrderedDict()
+    _conv(d, "encoder.conv_in", 128, 3, 3)
+    for i, (cin, cout) in enumerate(VAE_DOWN):
+        for j in range(2):
+            vae_resnet(d, f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i < 3:
+            _conv(d, f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+    vae_resnet(d, "encoder.mid_block.resnets.0", 512, 512)
+    a = "encoder.mid_block.attentions.0"
+    _norm(d, f"{a}.group_norm", 512)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        _linear(d, f"{a}.{n}", 512, 512)
+    vae_resnet(d, "encoder.mid_block.resnets.1", 512, 512)
+    _norm(d, "encoder.conv_norm_out", 512)
+    _conv(d, "encoder.conv_out", 8, 512, 3)
+    _conv(d, "quant_conv", 8, 8, 1)
+    return d
+
+
+# ----------------------------------------------------------------------------- analysis transform `enc`
+ENC_UNET_CH = (512, 768, 768)          # unet_ch_config (codec_module.py:51, config_inference.yaml)
+ENC_TEMB = 2048                        # 4 * block_out_channels[0]
+ENC_HEAD_DIM = 8                       # UNet2DModel default attention_head_dim
+
+
+def _enc_resnet(d, p, cin, cout):
+    """diffusers ResnetBlock2D with time embedding (groups 32, eps 1e-5)."""
+    _norm(d, f"{p}.norm1", cin)
+    _conv(d, f"{p}.conv1", cout, cin, 3)
+    _linear(d, f"{p}.time_emb_proj", cout, ENC_TEMB)
+    _norm(d, f"{p}.norm2", cout)
+    _conv(d, f"{p}.conv2", cout, cout, 3)
+    if cin != cout:
+        _conv(d, f"{p}.conv_shortcut", cout, cin, 1)
+
+
+def _enc_attn(d, p, c):
+    """diffusers Attention as used by AttnDownBlock2D / AttnUpBlock2D / UNetMidBlock2D (heads = c / 8)."""
+    _norm(d, f"{p}.group_norm", c)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        _linear(d, f"{p}.{n}", c, c)
+
+
+def _enc_own_resnet(d, p, cin, cout):
+    """The reference's own ResnetBlock (encoder_unet.py:14-52): bias-free convs, nin_shortcut on the OUTPUT."""
+    _norm(d, f"{p}.norm1", cin)
+    _conv(d, f"{p}.conv1", cout, cin, 3, bias=False)
+    _norm(d, f"{p}.norm2", cout)
+    _conv(d, f"{p}.conv2", cout, cout, 3, bias=False)
+    if cin != cout:
+        _conv(d, f"{p}.nin_shortcut", cout, cout, 1, bias=False)
+
+
+def enc_unet_up_plan():
+    """(block index, resnet index) -> (input channels, output channels) of the up path, following
+    diffusers `UNet2DModel.__init__` / `AttnUpBlock2D.__init__` for block_out_channels (512, 768, 768)."""
+    rev = list(reversed(ENC_UNET_CH))                     # (768, 768, 512)
+    plan, out = {}, rev[0]
+    for i in range(3):
+        prev, out = out, rev[i]
+        cin_blk = rev[min(i + 1, 2)]
+        for j in range(3):
+            skip = cin_blk if j == 2 else out
+            rin = prev if j == 0 else out
+            plan[(i, j)] = (rin + skip, out)
+    return plan
+
+
+def codec_encoder_spec(N=128, cond_ch=4):
+    """`enc` of IntraNoAR: Encoder (codec_module.py:51-85) = pix_emb, pix_fusion, the patched
+    UNet2DModel of encoder_unet.py:137-161 (forward_enc :54-134), trans_coding."""
+    d = OrderedDict()
+    _conv(d, "enc.pix_emb", 192, 3, 8)
+    _conv(d, "enc.pix_fusion", 320, 192 + cond_ch, 1)
+    u = "enc.unet"
+    c0 = ENC_UNET_CH[0]
+    _enc_own_resnet(d, f"{u}.conv_in.0", 320, c0)
+    _enc_own_resnet(d, f"{u}.conv_in.1", c0, c0)
+    _enc_own_resnet(d, f"{u}.conv_in.2", c0, c0)
+    _conv(d, f"{u}.conv_in.3", c0, c0, 3)
+    _linear(d, f"{u}.time_embedding.linear_1", ENC_TEMB, c0)
+    _linear(d, f"{u}.time_embedding.linear_2", ENC_TEMB, ENC_TEMB)
+    cin = c0
+    for i, cout in enumerate(ENC_UNET_CH):
+        for j in range(2):
+            _enc_resnet(d, f"{u}.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+            if i < 2:
+                _enc_attn(d, f"{u}.down_blocks.{i}.attentions.{j}", cout)
+        if i < 2:
+            _conv(d, f"{u}.down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+        cin = cout
+    cm = ENC_UNET_CH[-1]
+    _enc_resnet(d, f"{u}.mid_block.resnets.0", cm, cm)
+    _enc_attn(d, f"{u}.mid_block.attentions.0", cm)
+    _enc_resnet(d, f"{u}.mid_block.resnets.1", cm, cm)
+    for (i, j), (rin, rout) in enc_unet_up_plan().items():
+        _enc_resnet(d, f"{u}.up_blocks.{i}.resnets.{j}", rin, rout)
+        if i < 2:
+            _enc_attn(d, f"{u}.up_blocks.{i}.attentions.{j}", rout)
+        if i < 2 and j == 2:
+            _conv(d, f"{u}.up_blocks.{i}.upsamplers.0.conv", rout, rout, 3)
+    _norm(d, f"{u}.conv_norm_out", c0)
+    _conv(d, f"{u}.conv_out", c0, c0, 3)
+    t = "enc.trans_coding"
+    vq_res(d, f"{t}.0", c0)
+    vq_attn(d, f"{t}.1", c0)
+    vq_res(d, f"{t}.2", c0)
+    dcb4(d, f"{t}.3", c0, c0)
+    dcb4(d, f"{t}.4", c0, N)
+    return d
+
+
 # legacy attention names found in older SD VAE checkpoints (diffusers renames them on load)
 VAE_LEGACY_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
 

@@ -299,6 +299,33 @@ class IntraNoAR:
         self.hyper_enc = HyperEncoder(sd, self.device, self.N)
         return self
 
+    def load_encoder(self, sd):
+        """The analysis transform (`enc.*` of model_1.safetensors)."""
+        from .encoder import CodecEncoder
+        self.enc = CodecEncoder(sd, self.device)
+        return self
+
+    @torch.no_grad()
+    def encode(self, x, cond, pic_width, pic_height, fp=None):
+        """Reference `IntraNoAR.encode` (codec_module.py:326-353) for a batch of equally sized pictures:
+        x: f32 NHWC View of the padded pictures, cond: f32 View of their VAE latents.
+        -> (list of container bytes, list of bpp dicts with the reference's keys :342-352)."""
+        if getattr(self, "enc", None) is None:
+            raise RuntimeError("encode needs the analysis transform: call load_encoder(state_dict)")
+        y, sem = self.enc(x, cond)
+        blobs, _, _ = self.compress(y, sem, heights=[pic_height] * x.B, widths=[pic_width] * x.B)
+        out = []
+        for i, blob in enumerate(blobs):
+            if fp:
+                write_to_file(blob, fp if isinstance(fp, str) else fp[i])
+            d = decode_i(blob, self.index_unit_length, self.ds)
+            n = pic_height * pic_width
+            bits_y, bits_z, bits_c = (len(d[k]) * 8 for k in ("bit_stream_y", "bit_stream_z", "bit_stream_caption"))
+            out.append({"bits_y": bits_y, "bits_z": bits_z, "bits_caption": bits_c, "bits_total": len(blob) * 8,
+                        "bpp_y": bits_y / n, "bpp_z": bits_z / n, "bpp_caption": bits_c / n, "bpp": len(blob) * 8 / n,
+                        "bpp_file": (len(blob) * 8 / n) if fp else 0.0})
+        return blobs, out
+
     @torch.no_grad()
     def compress(self, y, sem, heights=None, widths=None):
         """codec_module.py:372-415 after the analysis transform `enc` (SD-VAE encoder + UNet2DModel: not
@@ -307,13 +334,20 @@ class IntraNoAR:
         -> (list of container bytes, indices int32 (B,h,w), y_hat View)."""
         if getattr(self, "hyper_enc", None) is None:
             raise RuntimeError("compress needs the hyper encoder weights: call load_hyper_encoder(state_dict)")
-        B, H, W, N = y.shape
-        yb = View(torch.empty((B * H * W + K.SLACK_ROWS) * N, dtype=torch.bfloat16, device=self.device), B, H, W, N)
-        yb.t[:B * H * W * N] = y.reshape(-1).to(torch.bfloat16)
-        sb = View(torch.empty((sem.shape[0] * sem.shape[1] * sem.shape[2] + K.SLACK_ROWS) * sem.shape[3],
-                              dtype=torch.bfloat16, device=self.device), sem.shape[0], sem.shape[1], sem.shape[2],
-                  sem.shape[3])
-        sb.t[:sem.numel()] = sem.reshape(-1).to(torch.bfloat16)
+        if isinstance(y, View):                               # straight from the analysis transform (bf16 Views)
+            yb, sb = y, sem
+            B, H, W, N = y.B, y.H, y.W, y.C
+            yf = new_view(B, H, W, N, self.device, torch.float32)
+            K.copy_channels(yb, yf)
+            y = yf.t[:B * H * W * N].view(B, H, W, N)
+        else:
+            B, H, W, N = y.shape
+            yb = View(torch.empty((B * H * W + K.SLACK_ROWS) * N, dtype=torch.bfloat16, device=self.device), B, H, W, N)
+            yb.t[:B * H * W * N] = y.reshape(-1).to(torch.bfloat16)
+            sb = View(torch.empty((sem.shape[0] * sem.shape[1] * sem.shape[2] + K.SLACK_ROWS) * sem.shape[3],
+                                  dtype=torch.bfloat16, device=self.device), sem.shape[0], sem.shape[1], sem.shape[2],
+                      sem.shape[3])
+            sb.t[:sem.numel()] = sem.reshape(-1).to(torch.bfloat16)
         z = self.hyper_enc(yb, sb, self.ws)
         indices = torch.empty(B * z.H * z.W, dtype=torch.int32, device=self.device)
         K.fsq_quantize(z.slice(0, 7), indices)

@@ -597,6 +597,7 @@ extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, vo
     } else if (DQ == 64 && DV == 48) FA_LAUNCH(64, 48, true, true, 40);
     else if (DQ == 96 && DV == 80) FA_LAUNCH(96, 80, false, true, 80);
     else if (DQ == 160 && DV == 160) FA_LAUNCH(160, 160, false, false, 160);
+    else if (DQ == 32 && DV == 16) FA_LAUNCH(32, 16, true, true, 8);
     else return -3;
 #undef FA_LAUNCH
     ONEDC_LAUNCH_CHECK();

@@ -226,9 +226,9 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
         v[2] += bf2f((bf16_t)(r.v.y & 0xffff));
         v[3] += bf2f((bf16_t)(r.v.y >> 16));
     }
-    if (p.stats) {
-        ssum += (v[0] + v[1]) + (v[2] + v[3]);
-        ssq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (p.stats) {       // explicit order and explicit fma: identical rounding in every kernel that includes this
+        ssum = (((ssum + v[0]) + v[1]) + v[2]) + v[3];
+        ssq = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq))));
     }
     const int64_t yo = e.opix * p.y_cs + p.y_co + e.n_out;
 #ifdef EXP_NOSTORE

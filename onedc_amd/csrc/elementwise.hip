@@ -160,6 +160,59 @@ __global__ void copy_channels_kernel(const void *x, int x_cs, int x_co, void *y,
     }
 }
 
+// ---- encode side: picture input ---------------------------------------------------------------------------
+// NCHW f32 picture -> NHWC (f32 or bf16) with channel stride y_cs (channels >= C are left untouched: the
+// caller zero-fills once), optionally a replicate-padded (Hp, Wp) frame of an (H, W) picture
+// (model_sd15_with_codec_stage1.py:281-285: F.pad(..., mode="replicate") up to a multiple of 64)
+template <bool YF>
+__global__ void nchw_to_nhwc_kernel(const float *x, void *y, int B, int C, int H, int W, int Hp, int Wp, int y_cs,
+                                    int y_co) {
+    const int64_t total = (int64_t)B * Hp * Wp * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int xx = (int)(r % Wp);
+        r /= Wp;
+        const int yy = (int)(r % Hp);
+        const int b = (int)(r / Hp);
+        const int sy = yy < H ? yy : H - 1, sx = xx < W ? xx : W - 1;
+        stp<YF>(y, (((int64_t)b * Hp + yy) * Wp + xx) * y_cs + y_co + c, x[(((int64_t)b * C + c) * H + sy) * W + sx]);
+    }
+}
+
+// 8x8 / stride 8 patch embedding input (Encoder.pix_emb, codec_module.py:60): NHWC f32 picture (3 channels of a
+// buffer with stride x_cs) -> bf16 [B][H/8][W/8][192], k = (ky, kx, c): the conv is then a 1x1 GEMM
+__global__ void patchify8_kernel(const float *x, int x_cs, bf16_t *y, int B, int H, int W) {
+    const int h8 = H >> 3, w8 = W >> 3;
+    const int64_t total = (int64_t)B * h8 * w8 * 192;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % 192);
+        int64_t r = i / 192;
+        const int px = (int)(r % w8);
+        r /= w8;
+        const int py = (int)(r % h8);
+        const int b = (int)(r / h8);
+        const int c = k % 3, kx = (k / 3) & 7, ky = k / 24;
+        y[i] = f2bf(x[(((int64_t)b * H + py * 8 + ky) * W + px * 8 + kx) * x_cs + c]);
+    }
+}
+
+// DiagonalGaussianDistribution.sample * scaling_factor (diffusers; call model_sd15_with_codec_stage1.py:193-194):
+// moments f32 NHWC [n][8] = (mean 4 | logvar 4); out = (mean + exp(0.5 clamp(logvar, -30, 20)) * noise) * scale
+__global__ void latent_sample_kernel(const float *moments, const float *noise, float *out, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i >> 2;
+        const int c = (int)(i & 3);
+        const float mean = moments[pix * 8 + c];
+        const float lv = fminf(fmaxf(moments[pix * 8 + 4 + c], -30.f), 20.f);
+        const float nz = noise ? noise[i] : 0.f;
+        out[i] = (mean + expf(0.5f * lv) * nz) * scale;
+    }
+}
+
 // region [y0,y0+RH) x [x0,x0+RW) of (B,H,W,C) <-> (B*nwin, wh*ww, C) windows, 8 channels per lane
 __global__ void window_partition_kernel(const bf16_t *x, bf16_t *y, int B, int H, int W, int C, int y0, int x0,
                                         int RH, int RW, int wh, int ww, int reverse) {
@@ -405,6 +458,28 @@ int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, i
     else if (x_f32) LAUNCH((copy_channels_kernel<true, false>), n, x, x_cs, x_co, y, y_cs, y_co, pixels, C);
     else if (y_f32) LAUNCH((copy_channels_kernel<false, true>), n, x, x_cs, x_co, y, y_cs, y_co, pixels, C);
     else LAUNCH((copy_channels_kernel<false, false>), n, x, x_cs, x_co, y, y_cs, y_co, pixels, C);
+    return 0;
+}
+
+int onedc_nchw_to_nhwc(const float *x, void *y, int y_f32, int B, int C, int H, int W, int Hp, int Wp, int y_cs,
+                       int y_co, void *stream) {
+    if (!x || !y || Hp < H || Wp < W || C < 1) return -1;
+    const int64_t n = (int64_t)B * Hp * Wp * C;
+    if (y_f32) LAUNCH(nchw_to_nhwc_kernel<true>, n, x, y, B, C, H, W, Hp, Wp, y_cs, y_co);
+    else LAUNCH(nchw_to_nhwc_kernel<false>, n, x, y, B, C, H, W, Hp, Wp, y_cs, y_co);
+    return 0;
+}
+
+int onedc_patchify8(const float *x, int x_cs, void *y, int B, int H, int W, void *stream) {
+    if (!x || !y || (H & 7) || (W & 7) || x_cs < 3) return -1;
+    const int64_t n = (int64_t)B * (H / 8) * (W / 8) * 192;
+    LAUNCH(patchify8_kernel, n, x, x_cs, (bf16_t *)y, B, H, W);
+    return 0;
+}
+
+int onedc_latent_sample(const float *moments, const float *noise, float *out, int64_t n, float scale, void *stream) {
+    if (!moments || !out) return -1;
+    LAUNCH(latent_sample_kernel, n * 4, moments, noise, out, n, scale);
     return 0;
 }
 

@@ -243,8 +243,11 @@ int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
 extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (!pp) return -1;
     onedc_conv_params p = *pp;
-    // 2-D pixel tiles for the 8-wave kernels (conv_common.h: ConvPatch); EXP_NOPATCH builds keep linear tiles
-#ifndef EXP_NOPATCH
+    // 2-D pixel tiles for the 8-wave kernels (conv_common.h: ConvPatch) are OFF: they were speed-neutral, and they
+    // regroup the pixels of a 64-pixel statistics block, so the GroupNorm partial sums of an 8-wave launch would
+    // round differently from a 4-wave launch of the same layer -- and which kernel runs depends on the batch size.
+    // With linear tiles every kernel family sums the same 64 pixels in the same order: results do not depend on it.
+#ifdef EXP_PATCH16
     p.patch16 = (p.KH > 1 && (p.OH & 15) == 0 && (p.OW & 15) == 0 && !p.pixel_shuffle && p.batch <= 1) ? 1 : 0;
 #else
     p.patch16 = 0;

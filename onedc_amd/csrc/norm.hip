@@ -329,10 +329,17 @@ int onedc_layernorm(const void *x, const float *gamma, const float *beta, void *
 }
 
 int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, void *stream) {
-    if (!s || !p || n < 1 || n_pad < n || n_pad > 256) return -1;
+    if (!s || !p || n < 1 || n_pad < n || n_pad > 2560) return -1;
     const int blocks = (int)((rows + 3) / 4);
-    hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
-                       rows, n, n_pad);
+    if (n_pad <= 256)
+        hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
+                           rows, n, n_pad);
+    else if (n_pad <= 1024)        // the analysis transform's single-head attention at 1/16 resolution (512x512 pictures)
+        hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
+                           rows, n, n_pad);
+    else                           // ... and 2304 tokens at 768x768
+        hipLaunchKernelGGL(softmax_rows_kernel<40>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
+                           rows, n, n_pad);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

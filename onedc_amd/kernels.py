@@ -54,6 +54,9 @@ SIGNATURES = {
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_fsq_codes": (_I, [_P, _P, _L, _P]),
     "onedc_fsq_quantize": (_I, [_P, _I, _I, _I, _P, _L, _P]),
+    "onedc_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_patchify8": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "onedc_latent_sample": (_I, [_P, _P, _P, _L, _F, _P]),
     "onedc_prior_indexes": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "onedc_prior_update_dec": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_prior_update_enc": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -208,7 +211,7 @@ def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
               pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0,
-              tile=0, stats=False):
+              tile=0, stats=False, pad=None):
     """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None."""
     p = ConvParams()
     p.x, p.w, p.bias, p.res, p.y = x.ptr, w.data_ptr(), _ptr(bias), (res.ptr if res is not None else None), y.ptr
@@ -226,7 +229,7 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     if res is not None:
         p.r_cs, p.r_co = res.cs, res.co
     p.KH = p.KW = KH
-    p.stride, p.pad, p.up = stride, KH // 2, up
+    p.stride, p.pad, p.up = stride, (KH // 2 if pad is None else pad), up
     p.epi, p.out_f32, p.pixel_shuffle = epi, int(y.f32), pixel_shuffle
     p.in_f32 = int(x.f32)
     p.tile = tile
@@ -324,6 +327,26 @@ def flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale):
 def fsq_codes(idx, codes):
     _ok(lib().onedc_fsq_codes(idx.data_ptr(), codes.data_ptr(), idx.numel(), stream()), "onedc_fsq_codes")
     return codes
+
+
+def nchw_to_nhwc(x, y, H=None, W=None):
+    """x: f32 NCHW tensor (B,C,H,W) -> View y (B,Hp,Wp,>=C), replicate padding to y's frame."""
+    B, Cc, Hx, Wx = x.shape
+    _ok(lib().onedc_nchw_to_nhwc(x.data_ptr(), y.ptr, int(y.f32), B, Cc, Hx, Wx, y.H, y.W, y.cs, y.co, stream()),
+        "onedc_nchw_to_nhwc")
+    return y
+
+
+def patchify8(x, y):
+    """x: f32 NHWC View (B,H,W,>=3) -> bf16 View y (B,H/8,W/8,192)."""
+    _ok(lib().onedc_patchify8(x.ptr, x.cs, y.ptr, x.B, x.H, x.W, stream()), "onedc_patchify8")
+    return y
+
+
+def latent_sample(moments, noise, out, scale):
+    n = moments.B * moments.H * moments.W
+    _ok(lib().onedc_latent_sample(moments.ptr, _ptr(noise), out.ptr, n, float(scale), stream()), "onedc_latent_sample")
+    return out
 
 
 def fsq_quantize(z, idx):

@@ -59,12 +59,14 @@ class Conv:
         self.glu, self.shuffle = glu, shuffle
 
     def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
-                 alpha=1.0, stats=False):
+                 alpha=1.0, stats=False, pad=None):
         """stats: the output feeds a GroupNorm -- leave its partial sums in the epilogue."""
         if y is None:
             oh, ow = x.H, x.W
             if stride == 2:
                 oh, ow = (x.H + 1) // 2, (x.W + 1) // 2
+                if pad == 0:                       # diffusers Downsample2D(padding=0): pad (0,1,0,1), conv stride 2
+                    oh, ow = x.H // 2, x.W // 2
             if up:
                 oh, ow = 2 * x.H, 2 * x.W
             c = self.cout
@@ -78,7 +80,7 @@ class Conv:
             y.want_stats()
         return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
                            alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
-                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats)
+                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad)
 
 
 _Conv = Conv

@@ -89,6 +89,39 @@ class SD15_1step_codec_stage1:
         return self.load_state_dicts(synth.unet_state_dict(seed), synth.codec_state_dict(seed),
                                      synth.vae_state_dict(seed))
 
+    def load_encoder_state_dicts(self, codec_enc_sd, hyper_enc_sd, vae_enc_sd):
+        """Encode side: `enc.*` and `hyper_enc.*` of model_1.safetensors, encoder half of the SD-2.1 VAE."""
+        from .encoder import VAEEncoder
+        with torch.cuda.device(self.device):
+            self.codec_model.load_encoder(codec_enc_sd)
+            self.codec_model.load_hyper_encoder(hyper_enc_sd)
+            self.vae_encoder = VAEEncoder(vae_enc_sd, self.device, self.vae_attn_patch)
+        return self
+
+    def load_synthetic_encoder(self, seed=0):
+        return self.load_encoder_state_dicts(synth.codec_encoder_state_dict(seed), synth.hyper_enc_state_dict(seed),
+                                             synth.vae_encoder_state_dict(seed))
+
+    @torch.no_grad()
+    def encode(self, image, fp=None, noise=None):
+        """Reference `encode` (model_sd15_with_codec_stage1.py:275-292): image f32 [B,3,H,W] in [-1,1] on this
+        device (B = 1 in the reference) -> (stream bytes, bpp dict) (lists when B > 1).  Replicate padding up to a
+        multiple of 64, SD-VAE encoder, analysis transform, hyper analysis, entropy coding.
+        noise: f32 [B,Hp/8,Wp/8,4] standing in for `latent_dist.sample()`'s global-RNG draw (:193; seed 0 in
+        inference.py:28); None encodes with the distribution's mode."""
+        if getattr(self, "vae_encoder", None) is None:
+            raise RuntimeError("encode needs the encoder weights: load_encoder_state_dicts / load_synthetic_encoder")
+        B, _, H, W = image.shape
+        ds = self.codec_model.ds
+        Hp, Wp = (H + ds - 1) // ds * ds, (W + ds - 1) // ds * ds
+        with torch.cuda.device(self.device):
+            img = View(torch.zeros((B * Hp * Wp + K.SLACK_ROWS) * 32, dtype=torch.float32, device=self.device),
+                       B, Hp, Wp, 32)
+            K.nchw_to_nhwc(image.to(self.device, torch.float32).contiguous(), img.slice(0, 3))
+            latent = self.vae_encoder.encode(img, noise)
+            blobs, bpp = self.codec_model.encode(img, latent, W, H, fp=fp)
+        return (blobs[0], bpp[0]) if B == 1 else (blobs, bpp)
+
     def prepare(self):
         return self
 

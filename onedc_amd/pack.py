@@ -92,4 +92,4 @@ def f32(t, device, perm=None):
     return t.float().contiguous().to(device)
 
 
-HEAD_PAD = {40: (64, 48), 80: (96, 80), 160: (160, 160)}   # head dim -> (DQ, DV)
+HEAD_PAD = {40: (64, 48), 80: (96, 80), 160: (160, 160), 8: (32, 16)}   # head dim -> (DQ, DV)

@@ -59,6 +59,14 @@ def hyper_enc_state_dict(seed=0):
     return sd
 
 
+def codec_encoder_state_dict(seed=0):
+    return make_state_dict(arch.codec_encoder_spec(), seed)
+
+
+def vae_encoder_state_dict(seed=0):
+    return make_state_dict(arch.vae_encoder_spec(), seed)
+
+
 def unet_state_dict(seed=0, lora=True):
     return make_state_dict(arch.unet_spec(lora=lora), seed)
 

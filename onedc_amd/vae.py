@@ -49,26 +49,8 @@ class VAEDecoder:
         self.attn_patch = attn_patch
 
     def _windowed_attention(self, x):
-        """windowed_attn (autoencoders_patch_attn.py:9-29, eval branch).  The reference slices
-        [i:i+patch, j:j+patch], so maps that are not a multiple of the patch get narrower windows
-        at the right / bottom edge; each of the up to four window shapes is one batched pass."""
-        B, H, W, C = x.B, x.H, x.W, x.C
-        p = self.attn_patch
-        out = new_view(B, H, W, C, self.device)
-        rows = [(0, H - H % p, p)] + ([(H - H % p, H % p, H % p)] if H % p else [])
-        cols = [(0, W - W % p, p)] + ([(W - W % p, W % p, W % p)] if W % p else [])
-        for y0, rh, wh in rows:
-            for x0, rw, ww in cols:
-                if rh == 0 or rw == 0:
-                    continue
-                nwin = (rh // wh) * (rw // ww)
-                xw = new_view(B * nwin, wh, ww, C, self.device)
-                K.window_partition(x.t, xw.t, B, H, W, C, p, region=(y0, x0, rh, rw), win_hw=(wh, ww))
-                hn = self.attn_norm(xw, self.ws, False)               # statistics per window
-                ow = self.attn(hn, xw, wh * ww)
-                K.window_partition(ow.t, out.t, B, H, W, C, p, reverse=True, region=(y0, x0, rh, rw),
-                                   win_hw=(wh, ww))
-        return out
+        from .encoder import windowed_attention
+        return windowed_attention(x, self.attn_norm, self.attn, self.attn_patch, self.ws, self.device)
 
     @torch.no_grad()
     def decode(self, latents):

@@ -457,6 +457,105 @@ def vae_decode(sd, latents, attn_patch=16, scaling_factor=0.18215):
     return conv(sd, "decoder.conv_out", h, padding=1)
 
 
+# ------------------------------------------------------------------ encode side: SD-VAE encoder (diffusers, UNPINNED)
+def vae_encode(sd, image, attn_patch=16, noise=None, scaling_factor=0.18215):
+    """model_sd15_with_codec_stage1.py:191-195: AutoencoderKL.encode(image).latent_dist.sample() * scaling.
+    diffusers 0.32.1 Encoder: conv_in, 4 DownEncoderBlock2D (2 resnets, eps 1e-6; Downsample2D = pad
+    (0,1,0,1) + conv 3x3 stride 2 on the first three), mid block with the windowed attention patch of
+    modules/vae/autoencoders_patch_attn.py, GroupNorm-SiLU-conv_out (8 ch), quant_conv 1x1, then
+    DiagonalGaussianDistribution.sample: mean + exp(0.5 clamp(logvar, -30, 20)) * noise.
+    `noise` (B,4,h,w) replaces the reference's global-RNG draw (SURVEY hard part 4); None = zeros (the mode)."""
+    h = conv(sd, "encoder.conv_in", image, padding=1)
+    for i in range(4):
+        for j in range(2):
+            h = unet_resnet_block(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, None, 1e-6)
+        if i < 3:
+            h = conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", F.pad(h, (0, 1, 0, 1)), stride=2)
+    h = unet_resnet_block(sd, "encoder.mid_block.resnets.0", h, None, 1e-6)
+    h = windowed_attn(sd, "encoder.mid_block.attentions.0", h, attn_patch)
+    h = unet_resnet_block(sd, "encoder.mid_block.resnets.1", h, None, 1e-6)
+    h = conv(sd, "encoder.conv_out", F.silu(gn(sd, "encoder.conv_norm_out", h, 1e-6)), padding=1)
+    moments = conv(sd, "quant_conv", h)
+    mean, logvar = moments.chunk(2, 1)
+    std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+    z = mean if noise is None else mean + std * noise
+    return z * scaling_factor
+
+
+# ------------------------------------------------------------------ encode side: analysis transform `enc`
+def enc_own_resnet(sd, p, x):
+    """encoder_unet.py:14-52 — the reference's own ResnetBlock: the 1x1 `nin_shortcut` is applied to the
+    block OUTPUT (hidden_states), not to the input, when in != out (:47-50)."""
+    h = conv(sd, f"{p}.conv1", F.silu(gn(sd, f"{p}.norm1", x, 1e-6)), padding=1)
+    h = conv(sd, f"{p}.conv2", F.silu(gn(sd, f"{p}.norm2", h, 1e-6)), padding=1)
+    res = conv(sd, f"{p}.nin_shortcut", h) if f"{p}.nin_shortcut.weight" in sd else x
+    return h + res
+
+
+def enc_attention(sd, p, x, head_dim=8, eps=1e-5):
+    """diffusers Attention of AttnDownBlock2D / AttnUpBlock2D / UNetMidBlock2D in UNet2DModel (UNPINNED):
+    GroupNorm(32) over (C, HW), heads = C / 8, softmax(q k^T / sqrt(8)) v, to_out.0, + residual."""
+    B, C, H, W = x.shape
+    h = F.group_norm(x.view(B, C, H * W), 32, sd[f"{p}.group_norm.weight"], sd[f"{p}.group_norm.bias"], eps)
+    h = h.transpose(1, 2)
+    heads = C // head_dim
+    q, k, v = (linear(sd, f"{p}.{n}", h).view(B, H * W, heads, head_dim).transpose(1, 2)
+               for n in ("to_q", "to_k", "to_v"))
+    a = torch.softmax(q @ k.transpose(-1, -2) * head_dim ** -0.5, dim=-1) @ v
+    a = linear(sd, f"{p}.to_out.0", a.transpose(1, 2).reshape(B, H * W, C))
+    return a.transpose(1, 2).reshape(B, C, H, W) + x
+
+
+def enc_unet_forward(sd, sample, p="enc.unet"):
+    """forward_enc (encoder_unet.py:54-134) over the patched UNet2DModel of :137-161 -> (y_sample, z_sample).
+    Timestep is the constant 999; Timesteps(512, flip_sin_to_cos=True, shift 0) -> linear_1, SiLU, linear_2."""
+    B = sample.shape[0]
+    temb = timestep_embedding(torch.full((B,), 999.0), 512)
+    temb = linear(sd, f"{p}.time_embedding.linear_2", F.silu(linear(sd, f"{p}.time_embedding.linear_1", temb)))
+    h = sample
+    for i in range(3):
+        h = enc_own_resnet(sd, f"{p}.conv_in.{i}", h)
+    h = conv(sd, f"{p}.conv_in.3", h, stride=2, padding=1)
+    skips = [h]
+    for i in range(3):
+        for j in range(2):
+            h = unet_resnet_block(sd, f"{p}.down_blocks.{i}.resnets.{j}", h, temb)
+            if i < 2:
+                h = enc_attention(sd, f"{p}.down_blocks.{i}.attentions.{j}", h)
+            skips.append(h)
+        if i < 2:
+            h = conv(sd, f"{p}.down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
+            skips.append(h)
+    h = unet_resnet_block(sd, f"{p}.mid_block.resnets.0", h, temb)
+    h = enc_attention(sd, f"{p}.mid_block.attentions.0", h)
+    h = unet_resnet_block(sd, f"{p}.mid_block.resnets.1", h, temb)
+    z_sample = h
+    for i in range(3):
+        for j in range(3):
+            h = unet_resnet_block(sd, f"{p}.up_blocks.{i}.resnets.{j}", torch.cat([h, skips.pop()], 1), temb)
+            if i < 2:
+                h = enc_attention(sd, f"{p}.up_blocks.{i}.attentions.{j}", h)
+        if i < 2:
+            h = conv(sd, f"{p}.up_blocks.{i}.upsamplers.0.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"),
+                     padding=1)
+    h = conv(sd, f"{p}.conv_out", F.silu(gn(sd, f"{p}.conv_norm_out", h, 1e-5)), padding=1)
+    return h, z_sample
+
+
+def codec_encoder(sd, x, cond, p="enc"):
+    """Encoder.forward (codec_module.py:75-85): x (B,3,H,W) picture in [-1,1], cond (B,4,H/8,W/8) VAE latent
+    -> (y (B,128,H/16,W/16), sem (B,768,H/64,W/64))."""
+    x_emb = conv(sd, f"{p}.pix_emb", x, stride=8)
+    x_emb = conv(sd, f"{p}.pix_fusion", torch.cat([x_emb, cond], 1))
+    y, sem = enc_unet_forward(sd, x_emb, f"{p}.unet")
+    y = vq_resnet_block(sd, f"{p}.trans_coding.0", y)
+    y = vq_attn_block(sd, f"{p}.trans_coding.1", y)
+    y = vq_resnet_block(sd, f"{p}.trans_coding.2", y)
+    y = depth_conv_block4(sd, f"{p}.trans_coding.3", y)
+    y = depth_conv_block4(sd, f"{p}.trans_coding.4", y)
+    return y, sem
+
+
 # ------------------------------------------------------------------ whole decode / encode-side prior
 def z_indices_to_params(codec_sd, indices):
     z_hat = fsq_indices_to_codes(indices)

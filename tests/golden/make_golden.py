@@ -287,7 +287,17 @@ def main():
         y7 = 2.0 * torch.randn(2, N, 8, 12, generator=g7)            # a 128x192 picture: y at 1/16, sem at 1/64
         sem7 = torch.randn(2, 768, 2, 3, generator=g7)
         z7 = henc(y7, sem7)
-    save("g7_hyper_enc.npz", y=y7, sem=sem7, z=z7)
+        # the analysis UNet's own ResnetBlock (encoder_unet.py:14-52; nin_shortcut on the block OUTPUT when in != out)
+        from models.sd15_onedc_codec_stage1.encoder_unet import ResnetBlock as EncResnetBlock
+        enc_sd = synth.codec_encoder_state_dict(0)
+        r0, r1 = EncResnetBlock(320, 512), EncResnetBlock(512, 512)
+        r0.load_state_dict(sub_sd(enc_sd, "enc.unet.conv_in.0."), strict=True)
+        r1.load_state_dict(sub_sd(enc_sd, "enc.unet.conv_in.1."), strict=True)
+        xr = torch.randn(1, 320, 8, 12, generator=g7)
+        o0 = r0.eval()(xr)
+        o1 = r1.eval()(o0)
+    save("g7_hyper_enc.npz", y=y7, sem=sem7, z=z7, enc_res_x=xr, enc_res_out0=sample_points(o0, 4096),
+         enc_res_out1=sample_points(o1, 4096))
 
     # ---------------------------------------------------------------- G6 closed forms
     print("G6 closed forms")

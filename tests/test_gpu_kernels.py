@@ -614,3 +614,25 @@ def test_conv_win3x3_race_screen_and_batch_invariance():
     y1 = new_view(1, 48, 48, 128, DEV)
     K.conv_gemm(from_nchw(x[2:3].to(DEV)), wp, None, y1, KH=3, tile=130)
     assert torch.equal(y1.t[:48 * 48 * 128], ref.view(4, -1)[2])
+
+
+def test_conv_stats_identical_across_kernel_families():
+    """Which conv kernel runs depends on the problem size (hence on the batch size).  Outputs AND the
+    GroupNorm partial sums left by the epilogue must not: 4-wave, 128x256 and 256x256 kernels, bit for bit."""
+    x, w, b = rnd(2, 128, 32, 32, seed=141), rnd(256, 128, 3, 3, seed=142, scale=1 / 34), rnd(256, seed=143)
+    outs = []
+    for tile in (128, 129, 256):
+        y = new_view(2, 32, 32, 256, DEV, stats=True)
+        K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=3, tile=tile, stats=True)
+        outs.append((y.t[:2 * 32 * 32 * 256].clone(), y.stats.t.clone()))
+    for o, s in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(s, outs[0][1])
+
+
+@pytest.mark.parametrize("n,n_pad", [(1024, 1024), (2304, 2304), (600, 640)])
+def test_softmax_rows_long(n, n_pad):
+    s = torch.randn(9, n, generator=torch.Generator().manual_seed(151)) * 4
+    p = torch.empty(9, n_pad, dtype=torch.bfloat16, device=DEV)
+    K.softmax_rows(s.to(DEV), p, 9, n, n_pad)
+    close(p[:, :n].float(), torch.softmax(s, -1), what="softmax long rows")
+    assert float(p[:, n:].float().abs().max() if n_pad > n else 0.0) == 0.0

@@ -344,3 +344,83 @@ def test_hyper_encoder_fsq_and_compress_round_trip(codec, codec_sd):
     got = np.stack([unpack_indices(decode_i(b, 14, 64)["bit_stream_z"], 6, 14) for b in blobs]).reshape(2, 2, 3)
     assert np.array_equal(got, indices.cpu().numpy())
     assert len(set(indices.cpu().numpy().reshape(-1).tolist())) > 1         # the synthetic z really spreads
+
+
+def test_vae_encoder_vs_oracle():
+    """SD-VAE encoder (windowed mid attention, one-sided stride-2 padding, latent sample with injected noise)
+    vs the oracle on a 128x192 picture (16x24 latent: one full 16x16 window + a ragged 16x8 one). tol 3e-2."""
+    from onedc_amd.encoder import VAEEncoder
+    sd = synth.vae_encoder_state_dict(0)
+    enc = VAEEncoder(sd, DEV, attn_patch=16)
+    g = torch.Generator().manual_seed(41)
+    img = torch.rand(2, 3, 128, 192, generator=g) * 2 - 1
+    noise = torch.randn(2, 4, 16, 24, generator=g)
+    iv = View(torch.zeros((2 * 128 * 192 + K.SLACK_ROWS) * 32, dtype=torch.float32, device=DEV), 2, 128, 192, 32)
+    K.nchw_to_nhwc(img.to(DEV), iv.slice(0, 3))
+    z = enc.encode(iv, noise.permute(0, 2, 3, 1).contiguous().to(DEV))
+    with torch.no_grad():
+        ref = R.vae_encode(sd, img, 16, noise)
+    check(z.torch_nchw(), ref, 3e-2, "VAE encoder latents")
+
+
+def test_flash_attention_head_dim_8():
+    """The analysis UNet's attention: 64 heads of 8 channels (DQ 32 / DV 16 padding)."""
+    from onedc_amd import pack
+    B, Hh, d, N = 2, 64, 8, 144
+    DQ, DV = pack.HEAD_PAD[d]
+    g = torch.Generator().manual_seed(42)
+    q, k, v = (torch.randn(B, Hh, N, d, generator=g).to(torch.bfloat16).float() for _ in range(3))
+    n_pad = 192
+
+    def padded(t, dp):
+        out = torch.zeros(B, N, Hh, dp)
+        out[..., :d] = t.permute(0, 2, 1, 3)
+        return out.reshape(B, N, Hh * dp).to(torch.bfloat16).to(DEV).contiguous()
+
+    vt = torch.zeros(B, Hh, DV, n_pad)
+    vt[:, :, :d, :N] = v.transpose(2, 3)
+    o = torch.empty(B, N, Hh * DV, dtype=torch.bfloat16, device=DEV)
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, n_pad).to(torch.bfloat16).to(DEV).contiguous(),
+                 o, B, Hh, N, N, n_pad, DQ, DV, d ** -0.5)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v
+    got = o.float().cpu().view(B, N, Hh, DV)[..., :d].permute(0, 2, 1, 3)
+    check(got, ref, 8e-3, "flash attention d=8")
+
+
+def test_analysis_transform_vs_oracle():
+    """Encoder (pix_emb 8x8/8 as patchify + GEMM, pix_fusion, the patched UNet2DModel, trans_coding) vs the
+    oracle on a 128x192 picture: y and sem. tol 5e-2 rel. RMS (~80 bf16 layers, two up/down scales)."""
+    from onedc_amd.encoder import CodecEncoder
+    sd = synth.codec_encoder_state_dict(0)
+    enc = CodecEncoder(sd, DEV)
+    g = torch.Generator().manual_seed(43)
+    img = torch.rand(1, 3, 128, 192, generator=g) * 2 - 1
+    cond = torch.randn(1, 4, 16, 24, generator=g) * 0.2
+    iv = View(torch.zeros((128 * 192 + K.SLACK_ROWS) * 32, dtype=torch.float32, device=DEV), 1, 128, 192, 32)
+    K.nchw_to_nhwc(img.to(DEV), iv.slice(0, 3))
+    cv = from_nchw(cond.to(DEV), torch.float32)
+    y, sem = enc(iv, cv)
+    with torch.no_grad():
+        y_ref, sem_ref = R.codec_encoder(sd, img, cond)
+    check(sem.torch_nchw(), sem_ref, 5e-2, "analysis transform: sem (UNet mid output)")
+    check(y.torch_nchw(), y_ref, 5e-2, "analysis transform: y")
+
+
+def test_model_encode_then_decode_round_trip(tmp_path):
+    """model.encode(picture) -> container bytes -> model.decode: the whole codec on HIP.  Checks the container
+    (sizes, replicate padding to 64, bpp bookkeeping), that decode reproduces the encoder's latents bit-exactly,
+    and that a picture alone encodes to the same bytes as inside a batch."""
+    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0).load_synthetic_encoder(0)
+    model.codec_model.update(force=True)
+    g = torch.Generator().manual_seed(44)
+    img = (torch.rand(2, 3, 120, 180, generator=g) * 2 - 1).to(DEV)          # padded to 128x192
+    noise = torch.randn(2, 16, 24, 4, generator=g).to(DEV)
+    blobs, bpp = model.encode(img, noise=noise)
+    assert len(blobs) == 2 and bpp[0]["bits_total"] == len(blobs[0]) * 8
+    assert abs(bpp[0]["bpp"] - len(blobs[0]) * 8 / (120 * 180)) < 1e-12 and bpp[0]["bits_z"] == 88   # 6 indices x 14 bit
+    one, bpp1 = model.encode(img[1:2], noise=noise[1:2], fp=str(tmp_path / "a.bin"))
+    assert one == blobs[1] and (tmp_path / "a.bin").read_bytes() == one
+    out = model.decode(stream=blobs)
+    assert out.shape == (2, 3, 120, 180) and bool(torch.isfinite(out).all())
+    out1 = model.decode(fp=str(tmp_path / "a.bin"))
+    assert torch.equal(out1[0], out[1])

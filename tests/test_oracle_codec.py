@@ -216,3 +216,27 @@ def test_fsq_quantize_inverts_indices_to_codes_on_all_16384_entries():
     zz[0, 0, 0, 0], zz[0, 0, 0, 1] = edge - 1e-3, edge + 1e-3
     zh, _ = R.fsq_quantize(zz)
     assert zh[0, 0, 0, 0] == 0.0 and zh[0, 0, 0, 1] == 0.5
+
+
+def test_analysis_unet_own_resnet_block_matches_reference_golden():
+    """encoder_unet.py:14-52 — the analysis UNet's own ResnetBlock, incl. the quirk that the 1x1 nin_shortcut is
+    applied to the block OUTPUT when in != out: oracle vs the reference class (strict-loaded, golden G7)."""
+    g = golden("g7_hyper_enc.npz")
+    sd = synth.codec_encoder_state_dict(0)
+    x = torch.from_numpy(g["enc_res_x"])
+    with torch.no_grad():
+        o0 = R.enc_own_resnet(sd, "enc.unet.conv_in.0", x)
+        o1 = R.enc_own_resnet(sd, "enc.unet.conv_in.1", o0)
+    for out, key in ((o0, "enc_res_out0"), (o1, "enc_res_out1")):
+        assert tuple(out.shape) == tuple(g[f"{key}.shape"])
+        got = out.reshape(-1)[torch.from_numpy(g[f"{key}.idx"])]
+        ref = torch.from_numpy(g[f"{key}.val"])
+        assert float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) <= 2e-5
+        assert abs(float(out.double().sum()) - float(g[f"{key}.sum"])) <= 1e-3 * float(g[f"{key}.abs_sum"])
+
+
+def test_encoder_specs_parameter_counts():
+    """SD-VAE encoder half: 34 163 592 parameters + quant_conv 72 (published AutoencoderKL figures)."""
+    assert arch.param_count(arch.vae_encoder_spec()) == 34_163_592 + 72
+    plan = arch.enc_unet_up_plan()
+    assert plan[(0, 0)] == (1536, 768) and plan[(1, 2)] == (1280, 768) and plan[(2, 0)] == (1280, 512) and plan[(2, 2)] == (1024, 512)
