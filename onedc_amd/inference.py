@@ -8,7 +8,10 @@ Same flags, same YAML keys (config_inference.yaml), CLI values override the file
 (:154-156), checkpoint directory = model.safetensors + model_1.safetensors loaded strictly (:87-93).
 Additions: --vae_path (the reference downloads the SD-2.1 VAE from the HF hub), and
 --decoder_bin_path may be a directory: all *.bin files of one padded size are decoded as batches.
-The encode half of `evaluate()` (analysis transform) is SURVEY 8(f) and not built yet.
+Without --decoder_only the harness runs the reference's evaluate loop (:109-134): every .jpg/.png of
+--eval_image_path is encoded to <output_path>/stream/<name>.bin, decoded to <output_path>/recon/<name>.png,
+and the bpp dictionaries land in detail_bpp_caption.xlsx / summary_bpp.xlsx (CSV content, like the
+reference, which calls to_csv on those names).
 """
 import argparse
 import glob
@@ -24,6 +27,13 @@ def save_image(img, path):
     from PIL import Image
     arr = img.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
     Image.fromarray(arr).save(path)
+
+
+def load_image(path):
+    """data/evalset.py:15-20: RGB, ToTensor() * 2 - 1 -> f32 [3,H,W] in [-1,1]."""
+    from PIL import Image
+    arr = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+    return torch.from_numpy(arr).permute(2, 0, 1).contiguous() * 2 - 1
 
 
 def parse_args(argv=None):
@@ -65,8 +75,7 @@ class Evaluator:
         args = self.args
         self.model.eval()
         if not args["decoder_only"]:
-            raise NotImplementedError(
-                "encode (analysis transform) is not part of this build yet; use --decoder_only")
+            return self.evaluate_folder()
         src, dst = args["decoder_bin_path"], args["decoder_out_path"]
         if os.path.isdir(src):
             os.makedirs(dst, exist_ok=True)
@@ -87,8 +96,46 @@ class Evaluator:
         save_image(recon[0], dst)
 
 
+    @torch.no_grad()
+    def evaluate_folder(self):
+        """The encode + decode loop of the reference (inference.py:109-134), one picture at a time."""
+        import shutil
+
+        import pandas as pd
+        args = self.args
+        out = args["output_path"]
+        recon_path, stream_path = os.path.join(out, "recon"), os.path.join(out, "stream")
+        if os.path.exists(out):
+            shutil.rmtree(out)
+        os.makedirs(recon_path)
+        os.makedirs(stream_path)
+        src = args["eval_image_path"]
+        names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
+        torch.manual_seed(0)                                   # inference.py:28: the draw of latent_dist.sample()
+        rows = []
+        for idx, fname in enumerate(names):
+            name = os.path.splitext(fname)[0]
+            image = load_image(os.path.join(src, fname))[None].to(self.model.device)
+            _, _, H, W = image.shape
+            Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
+            noise = torch.randn(1, Hp // 8, Wp // 8, 4, device=self.model.device)
+            stream_file = os.path.join(stream_path, f"{name}.bin")
+            _, bpp = self.model.encode(image, fp=stream_file, noise=noise)
+            recon = self.model.decode(fp=stream_file, unit_range=True)
+            save_image(recon[0], os.path.join(recon_path, f"{name}.png"))
+            bpp = dict(bpp)
+            bpp["image_name"] = name
+            rows.append(pd.DataFrame(bpp, index=[idx]))
+        detail = pd.concat(rows) if rows else pd.DataFrame()
+        detail.to_csv(os.path.join(out, "detail_bpp_caption.xlsx"))
+        avg = detail.mean(numeric_only=True).to_dict() if rows else {}
+        pd.DataFrame([avg]).to_csv(os.path.join(out, "summary_bpp.xlsx"))
+        print(avg)
+        return avg
+
+
 def main(argv=None):
-    Evaluator(parse_args(argv)).evaluate()
+    return Evaluator(parse_args(argv)).evaluate()
 
 
 if __name__ == "__main__":

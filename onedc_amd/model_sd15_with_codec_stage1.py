@@ -82,7 +82,11 @@ class SD15_1step_codec_stage1:
         vae_path = vae_path or os.path.join(checkpoint_path, "vae", "diffusion_pytorch_model.safetensors")
         vae = load_safetensor(vae_path)
         check_state_dicts(ff, codec, vae)
-        return self.load_state_dicts(ff, codec, vae)
+        self.load_state_dicts(ff, codec, vae)
+        # encode side, when the files carry it (model_1.safetensors always does: enc.*, hyper_enc.*)
+        if "enc.pix_emb.weight" in codec and "encoder.conv_in.weight" in vae:
+            self.load_encoder_state_dicts(codec, codec, vae)
+        return self
 
     def load_synthetic(self, seed=0):
         """Deterministic random-init weights of the real architecture (no checkpoints offline)."""

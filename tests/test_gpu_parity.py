@@ -424,3 +424,46 @@ def test_model_encode_then_decode_round_trip(tmp_path):
     assert out.shape == (2, 3, 120, 180) and bool(torch.isfinite(out).all())
     out1 = model.decode(fp=str(tmp_path / "a.bin"))
     assert torch.equal(out1[0], out[1])
+
+
+def test_cli_harness_encode_decode_and_decoder_only(tmp_path):
+    """The reference's command-line surface end to end on synthetic checkpoint FILES: strict loader of
+    model.safetensors / model_1.safetensors / the VAE file (decode + encode side), evaluate loop over a picture
+    folder (stream/, recon/, the two CSVs with the reference's bpp keys), then --decoder_only on a written stream."""
+    import pandas as pd
+    import yaml
+    from PIL import Image
+    from safetensors.torch import save_file
+    from onedc_amd import inference
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    save_file(synth.unet_state_dict(0), str(ckpt / "model.safetensors"))
+    codec_full = dict(synth.codec_state_dict(0))
+    codec_full.update(synth.codec_encoder_state_dict(0))
+    codec_full.update(synth.hyper_enc_state_dict(0))
+    save_file(codec_full, str(ckpt / "model_1.safetensors"))
+    vae_full = dict(synth.vae_state_dict(0))
+    vae_full.update(synth.vae_encoder_state_dict(0))
+    save_file(vae_full, str(ckpt / "vae.safetensors"))
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump({"vae_attn_patch": 16, "conditioning_timestep": 999}))
+    pics = tmp_path / "pics"
+    pics.mkdir()
+    rng = np.random.default_rng(51)
+    for name, (h, w) in (("a", (96, 150)), ("b", (128, 192))):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(pics / f"{name}.png")
+    out = tmp_path / "out"
+    avg = inference.main(["--config_path", str(tmp_path / "cfg.yaml"), "--checkpoint_path", str(ckpt),
+                          "--vae_path", str(ckpt / "vae.safetensors"), "--output_path", str(out),
+                          "--eval_image_path", str(pics)])
+    for name, (h, w) in (("a", (96, 150)), ("b", (128, 192))):
+        assert (out / "stream" / f"{name}.bin").stat().st_size > 16
+        assert Image.open(out / "recon" / f"{name}.png").size == (w, h)
+    detail = pd.read_csv(out / "detail_bpp_caption.xlsx")
+    assert set(["bits_y", "bits_z", "bits_caption", "bits_total", "bpp_y", "bpp_z", "bpp_caption", "bpp", "bpp_file",
+                "image_name"]) <= set(detail.columns) and len(detail) == 2
+    assert abs(detail["bpp_file"][0] - (out / "stream" / "a.bin").stat().st_size * 8 / (96 * 150)) < 1e-9
+    # --decoder_only reproduces the picture the evaluate loop wrote
+    inference.main(["--config_path", str(tmp_path / "cfg.yaml"), "--checkpoint_path", str(ckpt),
+                    "--vae_path", str(ckpt / "vae.safetensors"), "--decoder_only",
+                    "--decoder_bin_path", str(out / "stream" / "b.bin"), "--decoder_out_path", str(tmp_path / "b2.png")])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "b2.png")), np.asarray(Image.open(out / "recon" / "b.png")))
