@@ -171,10 +171,11 @@ int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, i
 int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, int y0, int x0, int RH,
                            int RW, int wh, int ww, int reverse, void *stream);
 /* ---- encode side ------------------------------------------------------------------ */
-/* NCHW f32 picture -> NHWC view (f32 / bf16), replicate-padded from (H, W) to (Hp, Wp)
- * (model_sd15_with_codec_stage1.py:281-285); channels beyond C of the destination are not written. */
+/* NCHW f32 picture -> NHWC view (f32 / bf16), padded on the right / bottom from (H, W) to (Hp, Wp): replicate
+ * (model_sd15_with_codec_stage1.py:281-285) or, reflect = 1, reflect (z-only harness,
+ * models/sd15_onedc_codec_z_only/inference.py:106-109); channels beyond C of the destination are not written. */
 int onedc_nchw_to_nhwc(const float *x, void *y, int y_f32, int B, int C, int H, int W, int Hp, int Wp, int y_cs,
-                       int y_co, void *stream);
+                       int y_co, int reflect, void *stream);
 /* input of Encoder.pix_emb (8x8 / stride 8 conv, codec_module.py:60) as a 1x1 GEMM operand:
  * NHWC f32 picture (3 channels, stride x_cs) -> bf16 [B][H/8][W/8][192], k = (ky, kx, c) */
 int onedc_patchify8(const float *x, int x_cs, void *y, int B, int H, int W, void *stream);

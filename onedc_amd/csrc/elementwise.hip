@@ -166,7 +166,7 @@ __global__ void copy_channels_kernel(const void *x, int x_cs, int x_co, void *y,
 // (model_sd15_with_codec_stage1.py:281-285: F.pad(..., mode="replicate") up to a multiple of 64)
 template <bool YF>
 __global__ void nchw_to_nhwc_kernel(const float *x, void *y, int B, int C, int H, int W, int Hp, int Wp, int y_cs,
-                                    int y_co) {
+                                    int y_co, int reflect) {
     const int64_t total = (int64_t)B * Hp * Wp * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -176,7 +176,9 @@ __global__ void nchw_to_nhwc_kernel(const float *x, void *y, int B, int C, int H
         r /= Wp;
         const int yy = (int)(r % Hp);
         const int b = (int)(r / Hp);
-        const int sy = yy < H ? yy : H - 1, sx = xx < W ? xx : W - 1;
+        // replicate (stage-1 model) or reflect (z-only harness, models/sd15_onedc_codec_z_only/inference.py:106-109)
+        const int sy = yy < H ? yy : (reflect ? 2 * (H - 1) - yy : H - 1);
+        const int sx = xx < W ? xx : (reflect ? 2 * (W - 1) - xx : W - 1);
         stp<YF>(y, (((int64_t)b * Hp + yy) * Wp + xx) * y_cs + y_co + c, x[(((int64_t)b * C + c) * H + sy) * W + sx]);
     }
 }
@@ -462,11 +464,12 @@ int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, i
 }
 
 int onedc_nchw_to_nhwc(const float *x, void *y, int y_f32, int B, int C, int H, int W, int Hp, int Wp, int y_cs,
-                       int y_co, void *stream) {
+                       int y_co, int reflect, void *stream) {
     if (!x || !y || Hp < H || Wp < W || C < 1) return -1;
+    if (reflect && (Hp - H >= H || Wp - W >= W)) return -2;
     const int64_t n = (int64_t)B * Hp * Wp * C;
-    if (y_f32) LAUNCH(nchw_to_nhwc_kernel<true>, n, x, y, B, C, H, W, Hp, Wp, y_cs, y_co);
-    else LAUNCH(nchw_to_nhwc_kernel<false>, n, x, y, B, C, H, W, Hp, Wp, y_cs, y_co);
+    if (y_f32) LAUNCH(nchw_to_nhwc_kernel<true>, n, x, y, B, C, H, W, Hp, Wp, y_cs, y_co, reflect);
+    else LAUNCH(nchw_to_nhwc_kernel<false>, n, x, y, B, C, H, W, Hp, Wp, y_cs, y_co, reflect);
     return 0;
 }
 

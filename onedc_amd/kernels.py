@@ -54,7 +54,7 @@ SIGNATURES = {
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_fsq_codes": (_I, [_P, _P, _L, _P]),
     "onedc_fsq_quantize": (_I, [_P, _I, _I, _I, _P, _L, _P]),
-    "onedc_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_patchify8": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "onedc_latent_sample": (_I, [_P, _P, _P, _L, _F, _P]),
     "onedc_prior_indexes": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
@@ -329,11 +329,11 @@ def fsq_codes(idx, codes):
     return codes
 
 
-def nchw_to_nhwc(x, y, H=None, W=None):
-    """x: f32 NCHW tensor (B,C,H,W) -> View y (B,Hp,Wp,>=C), replicate padding to y's frame."""
+def nchw_to_nhwc(x, y, reflect=False):
+    """x: f32 NCHW tensor (B,C,H,W) -> View y (B,Hp,Wp,>=C), replicate (or reflect) padding to y's frame."""
     B, Cc, Hx, Wx = x.shape
-    _ok(lib().onedc_nchw_to_nhwc(x.data_ptr(), y.ptr, int(y.f32), B, Cc, Hx, Wx, y.H, y.W, y.cs, y.co, stream()),
-        "onedc_nchw_to_nhwc")
+    _ok(lib().onedc_nchw_to_nhwc(x.data_ptr(), y.ptr, int(y.f32), B, Cc, Hx, Wx, y.H, y.W, y.cs, y.co, int(reflect),
+                                 stream()), "onedc_nchw_to_nhwc")
     return y
 
 

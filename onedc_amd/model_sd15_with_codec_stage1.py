@@ -126,6 +126,36 @@ class SD15_1step_codec_stage1:
             blobs, bpp = self.codec_model.encode(img, latent, W, H, fp=fp)
         return (blobs[0], bpp[0]) if B == 1 else (blobs, bpp)
 
+    @torch.no_grad()
+    def forward_z_only(self, image, noise=None):
+        """The ex-low-rate model's harness (models/sd15_onedc_codec_z_only/inference.py:100-131 around
+        model_sd15_with_codec_stage1.py:198-218): reflect padding to a multiple of 64, analysis -> FSQ indices, the
+        picture is reconstructed from the indices alone (four-part prior run with means only, no y stream).
+        -> (dict with 'indices', 'stream' = the container with an empty y part: 16 B header + ceil(n*14/8) B of
+        indices -- the reference never writes one --, 'bpp_z' as the harness computes it, pictures [B,3,H,W])."""
+        if getattr(self, "vae_encoder", None) is None:
+            raise RuntimeError("forward_z_only needs the encoder weights")
+        from .entropy.utils import encode_i, pack_indices
+        B, _, H, W = image.shape
+        Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
+        with torch.cuda.device(self.device):
+            img = View(torch.zeros((B * Hp * Wp + K.SLACK_ROWS) * 32, dtype=torch.float32, device=self.device),
+                       B, Hp, Wp, 32)
+            K.nchw_to_nhwc(image.to(self.device, torch.float32).contiguous(), img.slice(0, 3), reflect=True)
+            latent = self.vae_encoder.encode(img, noise)
+            cm = self.codec_model
+            y, sem = cm.enc(img, latent)
+            z = cm.hyper_enc(y, sem, cm.ws)
+            indices = torch.empty(B * z.H * z.W, dtype=torch.int32, device=self.device)
+            K.fsq_quantize(z.slice(0, 7), indices)
+            indices = indices.view(B, z.H, z.W)
+            recon = self.decode_z_only(indices)[:, :, :H, :W]
+        idx_host = indices.cpu().numpy()
+        streams = [encode_i(H, W, b"", pack_indices(idx_host[b].reshape(-1), cm.index_unit_length), b"", 0)
+                   for b in range(B)]
+        bits = (Hp // 64) * (Wp // 64) * 14
+        return {"indices": indices, "stream": streams, "bpp_z": bits / (H * W)}, recon
+
     def prepare(self):
         return self
 

@@ -467,3 +467,27 @@ def test_cli_harness_encode_decode_and_decoder_only(tmp_path):
                     "--vae_path", str(ckpt / "vae.safetensors"), "--decoder_only",
                     "--decoder_bin_path", str(out / "stream" / "b.bin"), "--decoder_out_path", str(tmp_path / "b2.png")])
     assert np.array_equal(np.asarray(Image.open(tmp_path / "b2.png")), np.asarray(Image.open(out / "recon" / "b.png")))
+
+
+def test_z_only_harness_forward():
+    """Ex-low-rate harness: reflect padding, indices from the analysis side, picture from the indices alone; the
+    252-byte payload at 768x768 (readme: "0.24 KB") = 144 indices x 14 bit, here 6 indices -> 11 bytes."""
+    from onedc_amd.entropy.utils import decode_i, unpack_indices
+    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0).load_synthetic_encoder(0)
+    model.codec_model.update(force=True)
+    img = (torch.rand(1, 3, 100, 170, generator=torch.Generator().manual_seed(61)) * 2 - 1).to(DEV)
+    enc, recon = model.forward_z_only(img)
+    assert recon.shape == (1, 3, 100, 170) and bool(torch.isfinite(recon).all())
+    d = decode_i(enc["stream"][0], 14, 64)
+    assert (d["height"], d["width"], d["pad_height"], d["pad_width"]) == (100, 170, 128, 192)
+    assert len(d["bit_stream_y"]) == 0 and len(d["bit_stream_z"]) == 11
+    assert np.array_equal(unpack_indices(d["bit_stream_z"], 6, 14).reshape(2, 3), enc["indices"][0].cpu().numpy())
+    assert abs(enc["bpp_z"] - 6 * 14 / (100 * 170)) < 1e-12
+    # the same indices through the decode-only entry give the same picture
+    again = model.decode_z_only(enc["indices"])[:, :, :100, :170]
+    assert torch.equal(again, recon)
+    # reflect padding really is a reflection
+    iv = View(torch.zeros((128 * 192 + K.SLACK_ROWS) * 32, dtype=torch.float32, device=DEV), 1, 128, 192, 32)
+    K.nchw_to_nhwc(img, iv.slice(0, 3), reflect=True)
+    ref = torch.nn.functional.pad(img.cpu(), (0, 22, 0, 28), mode="reflect")
+    assert torch.equal(iv.slice(0, 3).torch_nchw().cpu(), ref)
