@@ -8,6 +8,19 @@ __device__ __forceinline__ void glds16(const char *src, char *lds_dst) {
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: global address = descriptor base + voff (per lane) + soff (wave-uniform
+// SGPR), range-checked against the descriptor's byte count.  A lane whose voff is >= that count transfers ZEROS
+// to LDS: halo / tail rows need no zero page and no address select, and everything that is uniform over the
+// wave (K-tile, channel step, row-block stride) rides in soff, so the per-instruction VALU work is nil.
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int onedc_rsrc_t;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char *lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, (int)voff,
+                                             (int)soff, 0, 0);
+}
+
 // XCD-aware bijective remap of the launch index: consecutive logical tiles land on one XCD (one L2).
 __device__ __forceinline__ int xcd_logical_tile(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
@@ -27,17 +40,38 @@ struct ConvPixSrc {
     const char *src[NP];
     unsigned ok;       // bit i: row i reads a real input pixel for the current tap (else: zeros)
 
-    __device__ __forceinline__ void init(const onedc_conv_params &p, const int (&m)[NP], int M) {
+    // img0: image that pixel indices are relative to (0, or the first image of the workgroup's tile when the
+    // byte offsets must stay below 4 GB: buffer-descriptor DMA)
+    __device__ __forceinline__ void init(const onedc_conv_params &p, const int (&m)[NP], int M, int img0 = 0) {
         valid = 0;
         const int ohw = p.OH * p.OW;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int mm = m[i] < M ? m[i] : 0;
+            const int mm = m[i] < M ? m[i] : img0 * ohw;
             const int b = mm / ohw, rem = mm - b * ohw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            base[i] = b * p.IH * p.IW;
+            base[i] = (b - img0) * p.IH * p.IW;
             iyx0[i] = (int)((unsigned)(oy * p.stride - p.pad) << 16) | ((ox * p.stride - p.pad) & 0xffff);
             valid |= (m[i] < M) ? (1u << i) : 0u;
+        }
+    }
+    // byte offsets instead of pointers (buffer-descriptor DMA): off[i] relative to the input base, `oob` for rows
+    // that read zeros.  lane_off = (x_co * elem + chunk * 16)
+    unsigned off[NP];
+    __device__ __forceinline__ void tap_off(const onedc_conv_params &p, unsigned lane_off, int pix_bytes, int ky, int kx,
+                                            unsigned oob) {
+        const int ly = p.up ? 2 * p.IH : p.IH, lx = p.up ? 2 * p.IW : p.IW;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int iy = (iyx0[i] >> 16) + ky;
+            int ix = (int)(short)(iyx0[i] & 0xffff) + kx;
+            const bool in = ((valid >> i) & 1) && (unsigned)iy < (unsigned)ly && (unsigned)ix < (unsigned)lx;
+            if (p.up) {
+                iy >>= 1;
+                ix >>= 1;
+            }
+            const unsigned pix = (unsigned)(base[i] + iy * p.IW + ix);
+            off[i] = in ? pix * (unsigned)pix_bytes + lane_off : oob;
         }
     }
     // xb0 = input base + (x_co * elem + chunk * 16) bytes; pix_bytes = x_cs * elem

@@ -29,6 +29,18 @@ constexpr int HALF = 16384;           // bytes of one half-tile (128 rows x 128 
 constexpr int STAGE = 4 * HALF;       // one K-tile: A^0 A^1 B^0 B^1
 constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
 
+// Ablation builds (tools/exp_build.sh): EXP_NOLDSREAD keeps the fragments of the first phase for the whole loop,
+// EXP_NODMA issues no LDS-DMA inside the main loop.  Results are wrong; only the timing is read.
+#ifdef EXP_NOLDSREAD
+#define ABL_READS(x) if (t == 0) { x }
+#else
+#define ABL_READS(x) x
+#endif
+#ifdef EXP_NODMA
+#define ABL_DMA(x)
+#else
+#define ABL_DMA(x) x
+#endif
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
@@ -46,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
 
     const char *xb = (const char *)p.x + (int64_t)blockIdx.z * p.x_bs * 2;
     const char *wb = (const char *)p.w + (int64_t)blockIdx.z * p.w_bs * 2;
-    const char *zeros = (const char *)p.zeros;
+    const int w_rows = tiles_n * 256;              // packed weight rows are padded to the channel tile
 
     // ---- DMA geometry: one wave instruction = 8 LDS rows; a wave stages blocks (wave) and (wave + 8)
     // of every half-tile.  LDS row rho of A^h is tile channel (rho / 64) * 128 + h * 64 + rho % 64,
@@ -55,42 +67,50 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     const int chunk = (lane & 7) ^ lrow;           // swizzle on the source side
     const int t64 = wave * 8 + lrow;               // 0..63: LDS row of block `wave`; block wave + 8 is row t64 + 64
     // weights: row(h, i) = n0 + i * 128 + h * 64 + t64
-    const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;
-    const int64_t wrow64 = (int64_t)64 * Ktot * 2;         // byte stride of 64 weight rows
+    // weights through a buffer descriptor: per-lane byte offset of row n0 + t64, everything else in soffset
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wb, (unsigned)((int64_t)w_rows * Ktot * 2));
+    const unsigned wvoff = (unsigned)((int64_t)(n0 + t64) * Ktot * 2) + chunk * 16;
+    const unsigned wrow64 = (unsigned)(64 * Ktot * 2);     // byte stride of 64 weight rows
     // pixels: pixel(h, i) = m0 + ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
     const ConvPatch patch = conv_patch(p, m0);
+    const int img0 = patch.on ? patch.img : m0 / (p.OH * p.OW);
     ConvPixSrc<4> px;                              // [h * 2 + i]: tile position ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
     {
         int mrow[4];
 #pragma unroll
         for (int hi = 0; hi < 4; ++hi)
             mrow[hi] = conv_tile_pixel(p, patch, m0, ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31));
-        px.init(p, mrow, M);
+        px.init(p, mrow, M, img0);
     }
-    const char *xb0 = xb + p.x_co * 2 + chunk * 16;
+    // input through a buffer descriptor that starts at the first image this tile touches: byte offsets stay far
+    // below 4 GB whatever the batch (a 256-channel 768x768 batch of 16 is 4.8 GB)
+    const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
+    const int64_t rest = (int64_t)(p.B - img0) * img_bytes;
+    const unsigned x_bytes = rest < 0xfffff000ll ? (unsigned)rest : 0xfffff000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(xb + img0 * img_bytes, x_bytes);
+    const unsigned lane_off = (unsigned)(p.x_co * 2 + chunk * 16);
     const int pix_bytes = p.x_cs * 2;
     const int nc = p.Cin >> 6;                     // 64-channel K-tiles per tap
     const int T = p.KH * p.KW * nc;                // K-tiles
 
     auto tap_sources = [&](int tap) {
         const int ky = tap / p.KW;
-        px.tap(p, xb0, pix_bytes, ky, tap - ky * p.KW);
+        px.tap_off(p, lane_off, pix_bytes, ky, tap - ky * p.KW, x_bytes);
     };
 
     // stage half-tile A^h of K-tile t (weights are k-contiguous: K-tile t starts at byte t * 128 of a row)
     auto stage_A = [&](int h, int t, char *stage) {
         char *dst = stage + (h ? OFF_A1 : OFF_A0) + wave * 1024;
-        const char *s = wsrc + (int64_t)t * 128 + (h ? wrow64 : 0);
-        glds16(s, dst);
-        glds16(s + 2 * wrow64, dst + 8192);
+        const unsigned so = (unsigned)t * 128 + (h ? wrow64 : 0);
+        glds16_buf(w_rsrc, wvoff, so, dst);
+        glds16_buf(w_rsrc, wvoff, so + 2 * wrow64, dst + 8192);
     };
     // stage half-tile B^h of the K-tile whose tap is loaded in psrc/pok, channel step ci
     auto stage_B = [&](int h, int ci, char *stage) {
         char *dst = stage + (h ? OFF_B1 : OFF_B0) + wave * 1024;
-        const int cbyte = ci * 128;
-        const char *z = zeros + chunk * 16;
-        glds16(((px.ok >> (2 * h)) & 1) ? px.src[2 * h] + cbyte : z, dst);
-        glds16(((px.ok >> (2 * h + 1)) & 1) ? px.src[2 * h + 1] + cbyte : z, dst + 8192);
+        const unsigned cbyte = (unsigned)ci * 128;
+        glds16_buf(x_rsrc, px.off[2 * h], cbyte, dst);
+        glds16_buf(x_rsrc, px.off[2 * h + 1], cbyte, dst + 8192);
     };
 
     // ---- accumulators: acc[a][i][b][j]: channels wr*128 + a*64 + i*16.., pixels wc*64 + b*32 + j*16.. ----
@@ -166,11 +186,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
         const bool s1 = t + 1 < T, s2 = t + 2 < T;
 
         // phase 0: B-sub0 + A-sub0 reads; stage A^1(t+1)
-        LOAD_B(fb0, cur, 0)
+        ABL_READS(LOAD_B(fb0, cur, 0))
         __builtin_amdgcn_sched_barrier(0);
-        LOAD_A(cur, 0)
+        ABL_READS(LOAD_A(cur, 0))
         __builtin_amdgcn_sched_barrier(0);
-        if (s1) stage_A(1, t + 1, nxt);
+        ABL_DMA(if (s1) stage_A(1, t + 1, nxt);)
         WAIT_LGKMCNT(8);                           // the four B reads (issued first) have returned: B^0 may be restaged next phase
         __builtin_amdgcn_s_barrier();
         WAIT_LGKMCNT(0);
@@ -180,12 +200,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
         __builtin_amdgcn_s_barrier();
 
         // phase 1: B-sub1 reads; stage B^0(t+2)
-        LOAD_B(fb1, cur, 1)
+        ABL_READS(LOAD_B(fb1, cur, 1))
         __builtin_amdgcn_sched_barrier(0);
-        if (s2) {
+        ABL_DMA(if (s2) {
             advance2();
             stage_B(0, ci2, cur);
-        }
+        })
         __builtin_amdgcn_s_barrier();
         WAIT_LGKMCNT(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -194,9 +214,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
         __builtin_amdgcn_s_barrier();
 
         // phase 2: A-sub1 reads; stage A^0(t+2)
-        LOAD_A(cur, 1)
+        ABL_READS(LOAD_A(cur, 1))
         __builtin_amdgcn_sched_barrier(0);
-        if (s2) stage_A(0, t + 2, cur);
+        ABL_DMA(if (s2) stage_A(0, t + 2, cur);)
         __builtin_amdgcn_s_barrier();
         WAIT_LGKMCNT(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -205,12 +225,16 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
         __builtin_amdgcn_s_barrier();
 
         // phase 3: no reads (B-sub0 is still in registers); stage B^1(t+2); K-tile t+1 must have landed
+#ifdef EXP_NODMA
+        WAIT_VMCNT(0);
+#else
         if (s2) {
             stage_B(1, ci2, cur);
             WAIT_VMCNT(6);
         } else {
             WAIT_VMCNT(0);
         }
+#endif
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         MFMA_QUAD(1, 0, fb0)
@@ -320,44 +344,52 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
 
     const char *xb = (const char *)p.x + (int64_t)blockIdx.z * p.x_bs * 2;
     const char *wb = (const char *)p.w + (int64_t)blockIdx.z * p.w_bs * 2;
-    const char *zeros = (const char *)p.zeros;
+    const int w_rows = tiles_n * 128;              // packed weight rows are padded to the channel tile
 
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ lrow;
     const int t64 = wave * 8 + lrow;
-    const char *wsrc = wb + ((int64_t)(n0 + t64) * Ktot) * 2 + chunk * 16;     // weight rows t64 and t64 + 64
-    const int64_t wrow64 = (int64_t)64 * Ktot * 2;
+    // weights through a buffer descriptor: per-lane byte offset of row n0 + t64, everything else in soffset
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wb, (unsigned)((int64_t)w_rows * Ktot * 2));
+    const unsigned wvoff = (unsigned)((int64_t)(n0 + t64) * Ktot * 2) + chunk * 16;
+    const unsigned wrow64 = (unsigned)(64 * Ktot * 2);     // byte stride of 64 weight rows
     const ConvPatch patch = conv_patch(p, m0);
+    const int img0 = patch.on ? patch.img : m0 / (p.OH * p.OW);
     ConvPixSrc<4> px;                              // [h * 2 + i]: tile position ((t64 >> 5) + 2 i) * 64 + h * 32 + (t64 & 31)
     {
         int mrow[4];
 #pragma unroll
         for (int hi = 0; hi < 4; ++hi)
             mrow[hi] = conv_tile_pixel(p, patch, m0, ((t64 >> 5) + 2 * (hi & 1)) * 64 + (hi >> 1) * 32 + (t64 & 31));
-        px.init(p, mrow, M);
+        px.init(p, mrow, M, img0);
     }
-    const char *xb0 = xb + p.x_co * 2 + chunk * 16;
+    // input through a buffer descriptor that starts at the first image this tile touches: byte offsets stay far
+    // below 4 GB whatever the batch (a 256-channel 768x768 batch of 16 is 4.8 GB)
+    const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
+    const int64_t rest = (int64_t)(p.B - img0) * img_bytes;
+    const unsigned x_bytes = rest < 0xfffff000ll ? (unsigned)rest : 0xfffff000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(xb + img0 * img_bytes, x_bytes);
+    const unsigned lane_off = (unsigned)(p.x_co * 2 + chunk * 16);
     const int pix_bytes = p.x_cs * 2;
     const int nc = p.Cin >> 6;                     // 64-channel K-tiles per tap
     const int T = p.KH * p.KW * nc;                // K-tiles
 
     auto tap_sources = [&](int tap) {
         const int ky = tap / p.KW;
-        px.tap(p, xb0, pix_bytes, ky, tap - ky * p.KW);
+        px.tap_off(p, lane_off, pix_bytes, ky, tap - ky * p.KW, x_bytes);
     };
 
     auto stage_A = [&](int t, char *stage) {
         char *dst = stage + O3_A + wave * 1024;
-        const char *s = wsrc + (int64_t)t * 128;
-        glds16(s, dst);
-        glds16(s + wrow64, dst + 8192);
+        const unsigned so = (unsigned)t * 128;
+        glds16_buf(w_rsrc, wvoff, so, dst);
+        glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 8192);
     };
     auto stage_B = [&](int h, int ci, char *stage) {
         char *dst = stage + (h ? O3_B1 : O3_B0) + wave * 1024;
-        const int cbyte = ci * 128;
-        const char *z = zeros + chunk * 16;
-        glds16(((px.ok >> (2 * h)) & 1) ? px.src[2 * h] + cbyte : z, dst);
-        glds16(((px.ok >> (2 * h + 1)) & 1) ? px.src[2 * h + 1] + cbyte : z, dst + 8192);
+        const unsigned cbyte = (unsigned)ci * 128;
+        glds16_buf(x_rsrc, px.off[2 * h], cbyte, dst);
+        glds16_buf(x_rsrc, px.off[2 * h + 1], cbyte, dst + 8192);
     };
 
     f32x4 acc[4][2][2];                            // [i][b][j]: channels wr*64 + i*16.., pixels wc*64 + b*32 + j*16..

@@ -41,3 +41,25 @@ model._decode_after_entropy(ent)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print(f"stage S host enqueue time    {(t1 - t0) * 1e3:8.2f} ms")
+
+# ---- device time per sub-stage of S (events on the current stream, sequential) -----------------------------
+cm = model.codec_model
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+torch.cuda.synchronize()
+ev[0].record()
+h, ysem = cm.synthesis(ent[0], ent[1])
+ev[1].record()
+eps, reduced = model.feedforward_model(h, model.conditioning_timestep, ysem)
+ev[2].record()
+from onedc_amd import kernels as K
+from onedc_amd.kernels import new_view
+x0 = new_view(eps.B, eps.H, eps.W, 4, model.device, torch.float32)
+n = eps.B * eps.H * eps.W * 4
+K.x0_from_noise(reduced.t[:n], eps.t[:n], x0.t[:n], float(model.alphas_cumprod[999].double()))
+img = model.vae_large.decode(x0)
+ev[3].record()
+torch.cuda.synchronize()
+gf = {"codec synthesis": 16 * (11.5 + 222.6), "UNet step": 16 * 2191.7, "VAE decoder": 16 * 5585.2}
+for i, name in enumerate(["codec synthesis", "UNet step", "VAE decoder"]):
+    ms = ev[i].elapsed_time(ev[i + 1])
+    print(f"{name:18s} {ms:8.2f} ms   {gf[name] / ms:8.1f} TFLOP/s (algorithmic)")
