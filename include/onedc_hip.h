@@ -52,8 +52,8 @@ typedef struct onedc_conv_params {
     void *y;             /* bf16 (or f32 when out_f32) output */
     const void *zeros;   /* >= 256 B of zeros in device memory (source of halo / tail rows) */
     float *stats;        /* NULL, or GroupNorm partial sums of the stored output for the consumer's norm:
-                            float2 (sum, sum of squares) per (64-pixel block, 4-channel quad) of the y buffer,
-                            [B*OH*OW/64][y_cs/4]; needs OH*OW % 64 == 0, y_co % 4 == 0, no pixel_shuffle.
+                            float2 (sum, sum of squares) per (64-pixel block, stats_gran channels) of the y buffer,
+                            [B*OH*OW/64][y_cs/stats_gran]; needs OH*OW % 64 == 0, y_co % 4 == 0, no pixel_shuffle.
                             Replaces the statistics pass of nn.GroupNorm (see onedc_gn_from_stats) */
     int32_t B, IH, IW, Cin, x_cs, x_co; /* Cin: channels read, multiple of 64 */
     int32_t OH, OW, Cout, y_cs, y_co;   /* Cout: GEMM columns (before GLU halving / shuffle) */
@@ -66,6 +66,8 @@ typedef struct onedc_conv_params {
                                            128 = 4-wave kernels (128x128 / 64x128 / 16x256 tiles),
                                            256 = 8-wave 256x256 tile, 129 = 8-wave 128(ch)x256(px) tile,
                                            130 = 3x3 window kernel (16x16-pixel patches, stride 1, pad 1) */
+    int32_t stats_gran;                 /* channels per statistics entry: 4 (quads), or 2 (pairs) for buffers whose
+                                           GroupNorm groups are not multiples of 4 channels (320, 960 channels) */
     int32_t patch16;                    /* set by onedc_conv_gemm (callers leave 0): pixel tiles are 16x16 patches */
     int32_t in_f32;                     /* 1: x, w, res are f32 (exact f32 MFMA; Cin multiple of 32): the prior
                                            networks, whose outputs feed integer decisions, and the VAE's conv_in */
@@ -104,10 +106,10 @@ int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *
 int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
                           int y_cs, int y_co, int silu, void *stream);
 /* the statistics step from partial sums left by the producing conv's epilogue (onedc_conv_params.stats):
- * stats [B*HW/64][cs/4] float2 for the whole buffer (cs channels per pixel), normalised channels
- * [co, co + C); C/32 and co multiples of 4.  Writes ab like onedc_gn_stats. */
+ * stats [B*HW/64][cs/gran] float2 for the whole buffer (cs channels per pixel), normalised channels
+ * [co, co + C); C/32 and co multiples of gran (4 or 2).  Writes ab like onedc_gn_stats. */
 int onedc_gn_from_stats(const float *stats, const float *gamma, const float *beta, float *ab, int B, int HW,
-                        int C, int cs, int co, float eps, void *stream);
+                        int C, int cs, int co, float eps, int gran, void *stream);
 
 /* LayerNorm over the last dim of [rows][C] bf16 (BasicTransformerBlock norm1-3). */
 int onedc_layernorm(const void *x, const float *gamma, const float *beta, void *y, int64_t rows,

@@ -229,7 +229,8 @@ __device__ __forceinline__ EpiBias conv_epi_bias(const onedc_conv_params &p, boo
 template <bool F32>
 __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char *yb, bool glu, int cout_store,
                                                 const f32x4 &accv, const f32x4 &accg, const EpiBias &bias,
-                                                const EpiPos &e, const EpiRes<F32> &r, float &ssum, float &ssq) {
+                                                const EpiPos &e, const EpiRes<F32> &r, float &ssum, float &ssq,
+                                                float &ssum_hi, float &ssq_hi) {
     if (!e.store) return;
     float v[4];
     const float bv[4] = {bias.v.x, bias.v.y, bias.v.z, bias.v.w};
@@ -261,8 +262,15 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
         v[3] += bf2f((bf16_t)(r.v.y >> 16));
     }
     if (p.stats) {       // explicit order and explicit fma: identical rounding in every kernel that includes this
-        ssum = (((ssum + v[0]) + v[1]) + v[2]) + v[3];
-        ssq = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq))));
+        if (p.stats_gran == 2) {                   // channel pairs: (ssum, ssq) = channels 0, 1; (_hi) = channels 2, 3
+            ssum = (ssum + v[0]) + v[1];
+            ssq = __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq));
+            ssum_hi = (ssum_hi + v[2]) + v[3];
+            ssq_hi = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], ssq_hi));
+        } else {
+            ssum = (((ssum + v[0]) + v[1]) + v[2]) + v[3];
+            ssq = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq))));
+        }
     }
     const int64_t yo = e.opix * p.y_cs + p.y_co + e.n_out;
 #ifdef EXP_NOSTORE
@@ -295,20 +303,38 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
 // never straddles two images), y_co % 4 == 0, stored channels % 4 == 0, no pixel shuffle.
 // row: index of the wave's 64-pixel block among all blocks of the batch (any numbering that keeps the
 // blocks of one image contiguous: the finalize only sums over an image's rows)
+// stats_gran = 2 (buffers whose group size is not a multiple of 4, e.g. 320 or 960 channels): one entry per channel
+// PAIR, [rows][y_cs / 2]; the (_hi) sums are the lane's second pair.  Only the 4-wave and 128x256 kernels carry it.
 __device__ __forceinline__ void conv_stats_store_row(const onedc_conv_params &p, float ssum, float ssq, int row,
-                                                     int n_out, int cout_store, int lane) {
+                                                     int n_out, int cout_store, int lane, float ssum_hi = 0.f,
+                                                     float ssq_hi = 0.f) {
+    const bool pairs = p.stats_gran == 2;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
         ssum += __shfl_xor(ssum, o);
         ssq += __shfl_xor(ssq, o);
     }
+    if (pairs) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            ssum_hi += __shfl_xor(ssum_hi, o);
+            ssq_hi += __shfl_xor(ssq_hi, o);
+        }
+    }
     if ((lane & 15) == 0 && n_out < cout_store) {
-        float2 *dst = (float2 *)p.stats + (int64_t)row * (p.y_cs >> 2) + ((p.y_co + n_out) >> 2);
-        *dst = make_float2(ssum, ssq);
+        if (pairs) {
+            float2 *dst = (float2 *)p.stats + (int64_t)row * (p.y_cs >> 1) + ((p.y_co + n_out) >> 1);
+            dst[0] = make_float2(ssum, ssq);
+            dst[1] = make_float2(ssum_hi, ssq_hi);
+        } else {
+            float2 *dst = (float2 *)p.stats + (int64_t)row * (p.y_cs >> 2) + ((p.y_co + n_out) >> 2);
+            *dst = make_float2(ssum, ssq);
+        }
     }
 }
 __device__ __forceinline__ void conv_stats_store(const onedc_conv_params &p, float ssum, float ssq, int m_wave,
-                                                 int n_out, int cout_store, int lane, int M) {
+                                                 int n_out, int cout_store, int lane, int M, float ssum_hi = 0.f,
+                                                 float ssq_hi = 0.f) {
     // M % 64 == 0: a block is whole or absent
-    conv_stats_store_row(p, ssum, ssq, m_wave >> 6, m_wave < M ? n_out : cout_store, cout_store, lane);
+    conv_stats_store_row(p, ssum, ssq, m_wave >> 6, m_wave < M ? n_out : cout_store, cout_store, lane, ssum_hi, ssq_hi);
 }

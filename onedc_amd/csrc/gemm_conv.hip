@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * ES : nullptr;
     const int nw = n0 + wn * T::WTN;               // first packed row of this wave
 
-    float ssum[T::FI], ssq[T::FI];
+    float ssum[T::FI], ssq[T::FI], ssum_hi[T::FI], ssq_hi[T::FI];
     EpiBias bias[T::FI];
 #pragma unroll
     for (int i = 0; i < T::FI; ++i) {
-        ssum[i] = ssq[i] = 0.f;
+        ssum[i] = ssq[i] = ssum_hi[i] = ssq_hi[i] = 0.f;
         bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
     }
     // pass 1: positions + residual loads of every tile; pass 2: finish + store
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
             if (glu && (i & 1)) continue;
             const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
             const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
-            conv_epi_finish<F32>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i], ssq[i]);
+            conv_epi_finish<F32>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i], ssq[i],
+                                 ssum_hi[i], ssq_hi[i]);
         }
     }
     if (p.stats) {                                 // wave-uniform
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         for (int i = 0; i < T::FI; ++i) {
             if (glu && (i & 1)) continue;
             const int n_out = (glu ? (nw + i * 16) / 2 : nw + i * 16) + fq * 4;
-            conv_stats_store(p, ssum[i], ssq[i], m0 + wm * T::WTM, n_out, cout_store, lane, M);
+            conv_stats_store(p, ssum[i], ssq[i], m0 + wm * T::WTM, n_out, cout_store, lane, M, ssum_hi[i], ssq_hi[i]);
         }
     }
 }
@@ -262,6 +263,7 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     if (glu && (p.Cout & 31)) return -6;
     if (p.pixel_shuffle && ((p.Cout & 15) || glu)) return -7;
+    if (p.stats && p.stats_gran != 2 && p.stats_gran != 4) return -10;
     if (p.stats && (p.pixel_shuffle || ((p.OH * p.OW) & 63) || (p.y_co & 3) || (p.y_cs & 3) ||
                     ((glu ? p.Cout / 2 : p.Cout) & 3) || p.batch > 1))
         return -10;
@@ -282,7 +284,8 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);         // short K: prologue + epilogue of the one resident block dominate
-    if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 8) || p.tile == 256))
+    if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 8) || p.tile == 256) &&
+        !(p.stats && p.stats_gran == 2))           // the 256x256 kernel only leaves quad statistics
         return onedc_conv_gemm256_launch(p, st);
     // 128 x 256 tiles (8 waves, 3-deep LDS ring): channel counts that are whole 128-row tiles or waste < 20 %
     const int rows128 = (p.Cout + 127) / 128 * 128;

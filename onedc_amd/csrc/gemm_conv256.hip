@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
     const int nw = n0 + wr * 128;
-    float ssum[2][4], ssq[2][4];
+    float ssum[2][4], ssq[2][4], stat_dummy = 0.f;  // quad statistics only (the dispatcher keeps pair buffers away)
     EpiBias bias[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
                     const int i2 = (i + 1 < 4) ? i + 1 : i;
                     const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + a * 64 + i * 16, fq, op, m < M);
                     conv_epi_finish<false>(p, yb, glu, cout_store, acc[a][i][b][j], acc[a][i2][b][j], bias[a][i], e,
-                                           res[j][a][i], ssum[a][i], ssq[a][i]);
+                                           res[j][a][i], ssum[a][i], ssq[a][i], stat_dummy, stat_dummy);
                 }
         }
     }
@@ -513,11 +513,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
     const int nw = n0 + wr * 64;
-    float ssum[4], ssq[4];
+    float ssum[4], ssq[4], ssum_hi[4], ssq_hi[4];
     EpiBias bias[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        ssum[i] = ssq[i] = 0.f;
+        ssum[i] = ssq[i] = ssum_hi[i] = ssq_hi[i] = 0.f;
         bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
     }
     EpiRes<false> res[2][2][4];                    // pass 1: positions + residual loads of all 16 tiles
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
                 const int i2 = (i + 1 < 4) ? i + 1 : i;
                 const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
                 conv_epi_finish<false>(p, yb, glu, cout_store, acc[i][b][j], acc[i2][b][j], bias[i], e, res[b][j][i],
-                                       ssum[i], ssq[i]);
+                                       ssum[i], ssq[i], ssum_hi[i], ssq_hi[i]);
             }
         }
 #ifdef EXP_STAMP
@@ -561,7 +561,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
         for (int i = 0; i < 4; ++i) {
             if (glu && (i & 1)) continue;
             const int n16 = nw + i * 16;
-            conv_stats_store(p, ssum[i], ssq[i], m0 + wc * 64, (glu ? n16 / 2 : n16) + fq * 4, cout_store, lane, M);
+            conv_stats_store(p, ssum[i], ssq[i], m0 + wc * 64, (glu ? n16 / 2 : n16) + fq * 4, cout_store, lane, M,
+                             ssum_hi[i], ssq_hi[i]);
         }
     }
 #endif

@@ -262,11 +262,11 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     char *yb = (char *)p.y;
     const char *rb = (const char *)p.res;
     const int nw = n0 + wr * 64;
-    float ssum[4], ssq[4];
+    float ssum[4], ssq[4], ssum_hi[4], ssq_hi[4];
     EpiBias bias[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        ssum[i] = ssq[i] = 0.f;
+        ssum[i] = ssq[i] = ssum_hi[i] = ssq_hi[i] = 0.f;
         bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
     }
     EpiRes<false> res[4][4];                           // pass 1: positions + residual loads of all 16 tiles
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             const int i2 = (i + 1 < 4) ? i + 1 : i;
             const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, true);
             conv_epi_finish<false>(p, yb, glu, cout_store, acc[i][bj >> 1][bj & 1], acc[i2][bj >> 1][bj & 1], bias[i], e,
-                                   res[bj][i], ssum[i], ssq[i]);
+                                   res[bj][i], ssum[i], ssq[i], ssum_hi[i], ssq_hi[i]);
         }
     }
 #ifdef EXP_STAMP
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         for (int i = 0; i < 4; ++i) {
             if (glu && (i & 1)) continue;
             const int n16 = nw + i * 16;
-            conv_stats_store_row(p, ssum[i], ssq[i], pt * 4 + wc, (glu ? n16 / 2 : n16) + fq * 4, cout_store, lane);
+            conv_stats_store_row(p, ssum[i], ssq[i], pt * 4 + wc, (glu ? n16 / 2 : n16) + fq * 4, cout_store, lane,
+                                 ssum_hi[i], ssq_hi[i]);
         }
     }
 }

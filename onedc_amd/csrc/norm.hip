@@ -97,12 +97,12 @@ __global__ void gn_finalize_kernel(const float *__restrict__ part, const float *
 // t, t+256, ... in fp64, then a fixed-shape tree over the 256 threads.
 __global__ void gn_from_stats_kernel(const float2 *__restrict__ stats, const float *__restrict__ gamma,
                                      const float *__restrict__ beta, float2 *__restrict__ ab, int HW, int C,
-                                     int cs, int co, float eps) {
+                                     int cs, int co, float eps, int gran) {
     __shared__ double red[2][256];
     const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-    const int cpg = C / GN_GROUPS, qpg = cpg >> 2;
-    const int rows = HW >> 6, qs = cs >> 2;
-    const float2 *base = stats + (int64_t)b * rows * qs + ((co + g * cpg) >> 2);
+    const int cpg = C / GN_GROUPS, qpg = cpg / gran;          // gran: channels per statistics entry (4 or 2)
+    const int rows = HW >> 6, qs = cs / gran;
+    const float2 *base = stats + (int64_t)b * rows * qs + (co + g * cpg) / gran;
     double ss = 0.0, qq = 0.0;
     const int n = rows * qpg;
     for (int e = t; e < n; e += 256) {
@@ -287,11 +287,11 @@ int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *
 }
 
 int onedc_gn_from_stats(const float *stats, const float *gamma, const float *beta, float *ab, int B, int HW,
-                        int C, int cs, int co, float eps, void *stream) {
-    if (!stats || !gamma || !beta || !ab) return -1;
-    if (C % 32 || ((C / 32) & 3) || (co & 3) || (cs & 3) || (HW & 63) || C / 32 > 256) return -2;
+                        int C, int cs, int co, float eps, int gran, void *stream) {
+    if (!stats || !gamma || !beta || !ab || (gran != 2 && gran != 4)) return -1;
+    if (C % 32 || ((C / 32) % gran) || (co % gran) || (cs % gran) || (HW & 63) || C / 32 > 256) return -2;
     hipLaunchKernelGGL(gn_from_stats_kernel, dim3(GN_GROUPS, B), dim3(256), 0, as_stream(stream),
-                       (const float2 *)stats, gamma, beta, (float2 *)ab, HW, C, cs, co, eps);
+                       (const float2 *)stats, gamma, beta, (float2 *)ab, HW, C, cs, co, eps, gran);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

@@ -107,7 +107,10 @@ class UNet:
                 cin_total = blk["ins"][j]
                 h_c = cin_total - skip_c[s]
                 lvl = skip_lvl[s]
-                buf = new_view(B, res[lvl][0], res[lvl][1], cin_total, dev, stats=True)
+                # statistics granularity: pairs when the whole buffer or one of its two slices is normalised
+                # with groups that are not multiples of 4 channels (320 -> 10, 960 -> 30 channels per group)
+                gran = 2 if any((c // 32) % 4 for c in (cin_total, h_c, skip_c[s])) else 4
+                buf = new_view(B, res[lvl][0], res[lvl][1], cin_total, dev, stats=gran)
                 cat_bufs[s] = (buf, h_c)
                 order.append(s)
                 s -= 1

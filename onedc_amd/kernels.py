@@ -25,7 +25,8 @@ class ConvParams(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("up", C.c_int32),
         ("epi", C.c_int32), ("out_f32", C.c_int32), ("pixel_shuffle", C.c_int32),
         ("alpha", _F), ("slope", _F),
-        ("batch", C.c_int32), ("tile", C.c_int32), ("patch16", C.c_int32), ("in_f32", C.c_int32),
+        ("batch", C.c_int32), ("tile", C.c_int32), ("stats_gran", C.c_int32), ("patch16", C.c_int32),
+        ("in_f32", C.c_int32),
         ("x_bs", _L), ("w_bs", _L), ("y_bs", _L), ("r_bs", _L),
     ]
 
@@ -48,7 +49,7 @@ SIGNATURES = {
     "onedc_gn_chunks": (_I, [_I]),
     "onedc_gn_stats": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_scale_shift_act": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "onedc_gn_from_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_gn_from_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "onedc_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "onedc_softmax_rows": (_I, [_P, _P, _L, _I, _I, _P]),
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
@@ -115,24 +116,27 @@ def _ptr(t):
 
 class Stats:
     """GroupNorm partial sums of a whole NHWC buffer, written by the epilogues of the convs that
-    produce its channel slices: float2 [B*H*W/64][cs/4].  `have` records which 4-channel quads a
-    producer has filled since the buffer was made."""
-    __slots__ = ("t", "have")
+    produce its channel slices: float2 [B*H*W/64][cs/gran], gran = 4 channels per entry, or 2 when the
+    buffer's GroupNorm groups (cs/32 channels) are not multiples of 4 (320, 960 channels).  `have` records
+    which entries a producer has filled since the buffer was made."""
+    __slots__ = ("t", "have", "gran")
 
-    def __init__(self, B, H, W, cs, device):
-        self.t = torch.empty((B * H * W // 64) * (cs // 4) * 2, dtype=torch.float32, device=device)
-        self.have = [False] * (cs // 4)
+    def __init__(self, B, H, W, cs, device, gran=None):
+        self.gran = gran or (4 if (cs // 32) % 4 == 0 or cs % 32 else 2)
+        self.t = torch.empty((B * H * W // 64) * (cs // self.gran) * 2, dtype=torch.float32, device=device)
+        self.have = [False] * (cs // self.gran)
 
     @staticmethod
     def possible(H, W, cs):
         return (H * W) % 64 == 0 and cs % 4 == 0
 
     def mark(self, co, C):
-        for q in range(co // 4, (co + C) // 4):
+        for q in range(co // self.gran, (co + C) // self.gran):
             self.have[q] = True
 
     def covers(self, co, C):
-        return co % 4 == 0 and C % 4 == 0 and all(self.have[co // 4:(co + C) // 4])
+        g = self.gran
+        return co % 4 == 0 and C % 4 == 0 and all(self.have[co // g:(co + C) // g])
 
 
 class View:
@@ -145,10 +149,11 @@ class View:
         self.co = co
         self.stats = stats         # Stats of the underlying buffer (shared by all its slices) or None
 
-    def want_stats(self):
-        """Attach a Stats holder to this buffer (no-op if the map is not a multiple of 64 pixels)."""
+    def want_stats(self, gran=None):
+        """Attach a Stats holder to this buffer (no-op if the map is not a multiple of 64 pixels).
+        gran: 2 / 4 channels per entry; default: 4 unless this buffer's own group size needs pairs."""
         if self.stats is None and Stats.possible(self.H, self.W, self.cs):
-            self.stats = Stats(self.B, self.H, self.W, self.cs, self.t.device)
+            self.stats = Stats(self.B, self.H, self.W, self.cs, self.t.device, gran)
         return self
 
     @property
@@ -175,7 +180,7 @@ SLACK_ROWS = 128   # a GEMM may read (never use) up to one tile of rows past its
 def new_view(B, H, W, C, device, dtype=torch.bfloat16, cs=None, stats=False):
     cs = C if cs is None else cs
     v = View(torch.empty((B * H * W + SLACK_ROWS) * cs, dtype=dtype, device=device), B, H, W, C, cs, 0)
-    return v.want_stats() if stats else v
+    return v.want_stats(stats if stats in (2, 4) else None) if stats else v
 
 
 def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
@@ -235,6 +240,7 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     p.tile = tile
     if stats and y.stats is not None and not pixel_shuffle and batch <= 1 and y.co % 4 == 0 and y.C % 4 == 0:
         p.stats = y.stats.t.data_ptr()       # the epilogue leaves GroupNorm partial sums for the consumer
+        p.stats_gran = y.stats.gran
         y.stats.mark(y.co, y.C)
     if x.f32 and (w.dtype != torch.float32 or (res is not None and not res.f32)):
         raise KernelError("f32 conv_gemm needs f32 weights and residual")
@@ -295,9 +301,10 @@ def group_norm(x, gamma, beta, y, eps, silu, ws):
     the statistics pass over x is skipped."""
     HW = x.H * x.W
     ab = ws.f32("gn_ab", x.B * x.C * 2)
-    if (USE_EPILOGUE_STATS and x.stats is not None and (x.C // 32) % 4 == 0 and x.stats.covers(x.co, x.C)):
+    if (USE_EPILOGUE_STATS and x.stats is not None and (x.C // 32) % x.stats.gran == 0 and
+            x.co % x.stats.gran == 0 and x.stats.covers(x.co, x.C)):
         _ok(lib().onedc_gn_from_stats(x.stats.t.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ab.data_ptr(),
-                                      x.B, HW, x.C, x.cs, x.co, eps, stream()), "onedc_gn_from_stats")
+                                      x.B, HW, x.C, x.cs, x.co, eps, x.stats.gran, stream()), "onedc_gn_from_stats")
     else:
         part = ws.f32("gn_partial", x.B * gn_chunks(HW) * 64)
         _ok(lib().onedc_gn_stats(x.ptr, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), ab.data_ptr(),

@@ -636,3 +636,28 @@ def test_softmax_rows_long(n, n_pad):
     K.softmax_rows(s.to(DEV), p, 9, n, n_pad)
     close(p[:, :n].float(), torch.softmax(s, -1), what="softmax long rows")
     assert float(p[:, n:].float().abs().max() if n_pad > n else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("tile", [128, 129])
+def test_group_norm_pair_statistics_320_and_960_channels(tile):
+    """Group sizes of 10 / 30 channels (320 / 960-channel buffers of the UNet): the epilogue leaves one entry per
+    channel PAIR; concat buffer 640 + 320 = 960 normalised as a whole, and its 320-channel tail on its own."""
+    B, H, W = 2, 16, 16
+    xa, xb = rnd(B, 128, H, W, seed=161), rnd(B, 64, H, W, seed=162)
+    wa, wb = rnd(640, 128, 3, 3, seed=163, scale=1 / 34), rnd(320, 64, 3, 3, seed=164, scale=1 / 24)
+    cat = new_view(B, H, W, 960, DEV, stats=2)
+    K.conv_gemm(from_nchw(xa.to(DEV)), packed(wa), None, cat.slice(0, 640), KH=3, stats=True, tile=tile)
+    K.conv_gemm(from_nchw(xb.to(DEV)), packed(wb), None, cat.slice(640, 320), KH=3, stats=True, tile=tile)
+    assert cat.stats.gran == 2 and cat.stats.covers(0, 960)
+    ref_cat = torch.cat([F.conv2d(xa, wa, padding=1), F.conv2d(xb, wb, padding=1)], 1)
+    for view, ref in ((cat, ref_cat), (cat.slice(640, 320), ref_cat[:, 640:])):
+        C = view.C
+        g, be = rnd(C, seed=165), rnd(C, seed=166)
+        out = new_view(B, H, W, C, DEV)
+        ws = _WS()
+        K.group_norm(view, g.to(DEV), be.to(DEV), out, 1e-5, True, ws)
+        assert "gn_partial" not in ws.t                       # the statistics pass really was skipped
+        close(out.torch_nchw(), F.silu(F.group_norm(ref, 32, g, be, 1e-5)), rms=6e-3, mx=4e-2, what=f"pair stats C={C}")
+    # a 320-channel buffer of its own picks pairs by itself
+    y = new_view(B, H, W, 320, DEV, stats=True)
+    assert y.stats.gran == 2

@@ -54,6 +54,14 @@ def codec(codec_sd):
 
 
 @pytest.fixture(scope="module")
+def full_model():
+    """The whole codec (decode + encode side) with synthetic weights, built once for the module."""
+    m = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0).load_synthetic_encoder(0)
+    m.codec_model.update(force=True)
+    return m
+
+
+@pytest.fixture(scope="module")
 def codec_bf16(codec_sd):
     m = IntraNoAR(codec_sd, DEV, prior_f32=False)
     m.update(force=True)
@@ -262,12 +270,11 @@ def test_vae_decoder_windowed(h, w):
     check(img.torch_nchw(), ref, 3e-2, f"VAE decoder {h}x{w}")
 
 
-def test_end_to_end_decode_psnr(gaussian_tables):
+def test_end_to_end_decode_psnr(full_model, gaussian_tables):
     """Whole decode of two 128x192 streams (made by the product's own encoder side) against the
     oracle run from the same decoded latents.  Reported: PSNR(product, oracle) on [0,1] pictures
     (reference metric, test_quality.py:234-235).  tol: >= 30 dB (bf16 UNet + x14.65 eps->x0 gain)."""
-    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0)
-    model.codec_model.update(force=True)
+    model = full_model
     rng = np.random.default_rng(9)
     idx = torch.from_numpy(rng.integers(0, 16384, (2, 2, 3)).astype(np.int32)).to(DEV)
     blobs, y_hat = model.codec_model.encode_latents(idx, None, noise_seed=1)
@@ -284,11 +291,10 @@ def test_end_to_end_decode_psnr(gaussian_tables):
     assert p >= 30.0
 
 
-def test_decode_pipeline_matches_sequential_decode():
+def test_decode_pipeline_matches_sequential_decode(full_model):
     """DecodePipeline (entropy stage of batch n+1 on its own stream/thread while batch n is in the
     UNet/VAE) must return bit-identical pictures to back-to-back decode() calls."""
-    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0)
-    model.codec_model.update(force=True)
+    model = full_model
     rng = np.random.default_rng(19)
     batches = []
     for k in range(3):
@@ -406,12 +412,11 @@ def test_analysis_transform_vs_oracle():
     check(y.torch_nchw(), y_ref, 5e-2, "analysis transform: y")
 
 
-def test_model_encode_then_decode_round_trip(tmp_path):
+def test_model_encode_then_decode_round_trip(full_model, tmp_path):
     """model.encode(picture) -> container bytes -> model.decode: the whole codec on HIP.  Checks the container
     (sizes, replicate padding to 64, bpp bookkeeping), that decode reproduces the encoder's latents bit-exactly,
     and that a picture alone encodes to the same bytes as inside a batch."""
-    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0).load_synthetic_encoder(0)
-    model.codec_model.update(force=True)
+    model = full_model
     g = torch.Generator().manual_seed(44)
     img = (torch.rand(2, 3, 120, 180, generator=g) * 2 - 1).to(DEV)          # padded to 128x192
     noise = torch.randn(2, 16, 24, 4, generator=g).to(DEV)
@@ -469,12 +474,11 @@ def test_cli_harness_encode_decode_and_decoder_only(tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / "b2.png")), np.asarray(Image.open(out / "recon" / "b.png")))
 
 
-def test_z_only_harness_forward():
+def test_z_only_harness_forward(full_model):
     """Ex-low-rate harness: reflect padding, indices from the analysis side, picture from the indices alone; the
     252-byte payload at 768x768 (readme: "0.24 KB") = 144 indices x 14 bit, here 6 indices -> 11 bytes."""
     from onedc_amd.entropy.utils import decode_i, unpack_indices
-    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0).load_synthetic_encoder(0)
-    model.codec_model.update(force=True)
+    model = full_model
     img = (torch.rand(1, 3, 100, 170, generator=torch.Generator().manual_seed(61)) * 2 - 1).to(DEV)
     enc, recon = model.forward_z_only(img)
     assert recon.shape == (1, 3, 100, 170) and bool(torch.isfinite(recon).all())
