@@ -270,14 +270,14 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     hipStream_t st = as_stream(stream);
     if (p.in_f32) return launch<Tile<128, 128, 2, 2>, true>(p, st);
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
-    // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per chunk)
+    // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per 64-channel chunk):
+    // 5-27 % faster than the 128x256 / 256x256 kernels on every 3x3 layer it can take (tools/bench_conv.py).  The
+    // choice depends on the layer's shape only, never on the batch: its k order is (chunk, tap), so its sums round
+    // differently from the other kernels, and a picture must decode to the same bits alone and inside a batch.
     {
         const int rows128w = (p.Cout + 127) / 128 * 128;
-        const int64_t blocksw = (rows128w / 128) * (M64 / 256);
-        // measured (tools/bench_conv.py): 3-13 % faster than the 128x256 kernel on the 128 -> 128 layers at
-        // 768x768, 15-25 % slower on the 256 / 512-channel layers, so it is only taken when forced (tile = 130)
-        (void)blocksw;
-        if (p.tile == 130 && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) && rows128w * 5 <= p.Cout * 6)
+        if ((p.tile == 0 || p.tile == 130) && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) &&
+            rows128w * 5 <= p.Cout * 6)
             return onedc_conv_win_launch(p, st);
         if (p.tile == 130) return -11;
     }

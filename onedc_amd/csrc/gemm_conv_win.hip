@@ -34,10 +34,10 @@
 namespace {
 
 constexpr int WIN_A = 16384;                 // one weight tile: 128 rows x 128 B
-constexpr int WIN_NA = 4;                    // weight ring depth
+constexpr int WIN_NA = 3;                    // weight ring depth (9 taps: the slot of a tap is tap % 3)
 constexpr int WIN_ROWS = 328;                // window rows, padded to 41 blocks of 8
 constexpr int WIN_W = WIN_ROWS * 128;        // 41984 B
-constexpr int WIN_LDS = WIN_NA * WIN_A + 2 * WIN_W;   // 149504 B
+constexpr int WIN_LDS = WIN_NA * WIN_A + 2 * WIN_W;   // 133120 B
 
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
@@ -46,25 +46,11 @@ template <bool UP>
 __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_params p, int tiles_n, int tiles_x,
                                                           int tiles_y, int Ktot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef EXP_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#define STAMP(i)                                                     \
-    do {                                                             \
-        __builtin_amdgcn_sched_barrier(0);                           \
-        unsigned long long t__;                                      \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
-        st_acc[i] += t__ - st_last;                                  \
-        st_last = t__;                                               \
-        __builtin_amdgcn_sched_barrier(0);                           \
-    } while (0)
-#else
-#define STAMP(i)
-#endif
     char *const lds_a = smem;
     char *const lds_w = smem + WIN_NA * WIN_A;
     constexpr int WW = UP ? 10 : 18;               // window width (and height)
     constexpr int NWB = (WW * WW + 7) / 8;          // 8-row DMA blocks per window: 41 / 13
+    constexpr int MAXWB = (NWB + 7) / 8;            // blocks per wave: 6 / 2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,52 +66,43 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     const int ty = pin / tiles_x, tx = pin - ty * tiles_x;
     const int y0 = ty * 16, x0 = tx * 16;           // output origin of the patch
 
-    const char *xb = (const char *)p.x;
-    const char *wb = (const char *)p.w;
-    const char *zeros = (const char *)p.zeros;
-
-    // ---- DMA geometry ---------------------------------------------------------------------------------------
+    // ---- DMA geometry: buffer descriptors, per-lane byte offsets fixed for the whole kernel ------------------
     const int lrow = lane >> 3;
     const int chunk = (lane & 7) ^ lrow;            // swizzle on the source side (row & 7 == lrow for every block)
-    // weights: 16 blocks of 8 rows per K-tile, two per wave: rows (wave) * 8 + lrow and + 64
-    const char *wsrc = wb + ((int64_t)(n0 + wave * 8 + lrow) * Ktot) * 2 + chunk * 16;
-    const int64_t wrow64 = (int64_t)64 * Ktot * 2;
-    // window: block k of this wave covers window rows (wave + 8 k) * 8 + lrow
-    const int nwb = (NWB - wave + 7) >> 3;           // blocks this wave stages per window (wave-uniform)
-    constexpr int MAXWB = (NWB + 7) / 8;              // 6 / 2
-    const char *wsrcp[MAXWB];
-    unsigned wok = 0;
+    // weights: 16 blocks of 8 rows per K-tile, two per wave: rows wave * 8 + lrow and + 64
+    const int w_rows = tiles_n * 128;               // packed weight rows are padded to the channel tile
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)((int64_t)w_rows * Ktot * 2));
+    const unsigned wvoff = (unsigned)((int64_t)(n0 + wave * 8 + lrow) * Ktot * 2) + chunk * 16;
+    const unsigned wrow64 = (unsigned)(64 * Ktot * 2);
+    // window: block k of this wave covers window rows (wave + 8 k) * 8 + lrow; rows outside the picture (and the
+    // padding rows of the last block) carry an out-of-range offset: the descriptor's range check returns zeros
+    const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
+    const unsigned x_bytes = img_bytes < 0xfffff000ll ? (unsigned)img_bytes : 0xfffff000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc((const char *)p.x + img * img_bytes, x_bytes);
+    const int nwb = (NWB - wave + 7) >> 3;          // blocks this wave stages per window (wave-uniform)
+    unsigned woff[MAXWB];
     {
         const int wy0 = UP ? (y0 >> 1) - 1 : y0 - 1, wx0 = UP ? (x0 >> 1) - 1 : x0 - 1;
-        const int64_t img_pix = (int64_t)img * p.IH * p.IW;
 #pragma unroll
         for (int k = 0; k < MAXWB; ++k) {
             const int row = (wave + 8 * k) * 8 + lrow;
             const int wy = row / WW, wx = row - wy * WW;
             const int iy = wy0 + wy, ix = wx0 + wx;
             const bool ok = row < WW * WW && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-            wsrcp[k] = xb + ((img_pix + (int64_t)iy * p.IW + ix) * p.x_cs + p.x_co) * 2 + chunk * 16;
-            wok |= ok ? (1u << k) : 0u;
+            woff[k] = ok ? (unsigned)((iy * p.IW + ix) * p.x_cs + p.x_co) * 2u + chunk * 16 : x_bytes;
         }
     }
     const int nc = p.Cin >> 6;                       // 64-channel chunks
-    const int T = 9 * nc;                            // K-tiles
 
-    // K-tile t = (chunk ci, tap): weights are [row][tap][cin] -> byte offset (tap * Cin + ci * 64) * 2
+    // K-tile (chunk ci, tap): weights are [row][tap][cin] -> byte offset (tap * Cin + ci * 64) * 2 inside a row
     auto stage_A = [&](int tap, int ci, int slot) {
         char *dst = lds_a + slot * WIN_A + wave * 1024;
-        const char *s = wsrc + ((int64_t)tap * p.Cin + ci * 64) * 2;
-        glds16(s, dst);
-        glds16(s + wrow64, dst + 8192);
+        const unsigned so = (unsigned)(tap * p.Cin + ci * 64) * 2;
+        glds16_buf(w_rsrc, wvoff, so, dst);
+        glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 8192);
     };
-    auto stage_W = [&](int k, int ci, int wbuf) {      // block k of this wave, window of chunk ci
-        char *dst = lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024;
-        const char *z = zeros + chunk * 16;
-        const char *src = z;
-#pragma unroll
-        for (int kk = 0; kk < MAXWB; ++kk)             // static register indexing
-            if (kk == k) src = ((wok >> kk) & 1) ? wsrcp[kk] + ci * 128 : z;
-        glds16(src, dst);
+    auto stage_W = [&](unsigned off, int k, int ci, int wbuf) {      // block k of this wave, window of chunk ci
+        glds16_buf(x_rsrc, off, (unsigned)ci * 128, lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024);
     };
 
     // ---- accumulators: acc[i][b][j]: channels wr*64 + i*16.., output row 4 wc + 2 b + j, column frow ------
@@ -138,123 +115,120 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             for (int j = 0; j < 2; ++j) acc[i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    const int fo0 = frow * 128 + ((fq ^ (lane & 7)) << 4);           // weight fragments: rows 16 i + frow
-    const int fo1 = frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
-    const int a_off = wr * 64 * 128;
+    // weight fragments: row 16 i + frow of the wave's 64 channels, 16-byte chunk fq (k 0..31) / 4 + fq (k 32..63)
+    const char *const fa0 = lds_a + wr * 64 * 128 + frow * 128 + ((fq ^ (lane & 7)) << 4);
+    const char *const fa1 = lds_a + wr * 64 * 128 + frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    // pixel fragments: output (row 4 wc + bj, column frow) under tap (ky, kx) reads window row
+    //   (4 wc + bj + ky) * 18 + frow + kx        (fused x2 upsample: ((4 wc + bj + ky + 1) >> 1) * 10 + ((frow + kx + 1) >> 1))
+    // which depends on bj + ky only: 6 x 3 LDS addresses per lane, computed once.  k 32..63 is the address ^ 64.
+    int wrd[6][3];                                   // byte offsets into smem
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int w = UP ? ((4 * wc + r + 1) >> 1) * WW + ((frow + kx + 1) >> 1) : (4 * wc + r) * WW + frow + kx;
+            wrd[r][kx] = WIN_NA * WIN_A + w * 128 + ((fq ^ (w & 7)) << 4);
+        }
+    bf16x8 fa[4][2], fb[2][2];
 
-    // window row of output (row 4 wc + bj, column frow) under tap (ky, kx)
-    auto win_row = [&](int bj, int ky, int kx) {
-        const int ly = 4 * wc + bj;
-        if (UP) return ((ly + ky + 1) >> 1) * WW + ((frow + kx + 1) >> 1);
-        return (ly + ky) * WW + frow + kx;
-    };
-    // Fragments of one K-tile: 8 weight + 8 pixel ds_read_b128.  Two register sets: the reads of K-tile
-    // t + 1 are issued BEFORE the 32 MFMAs of K-tile t, so LDS latency (hundreds of cycles under load) is
-    // covered by the wave's own matrix work instead of being waited for between two barriers.
-    struct Frags {
-        bf16x8 a[4][2], b[4][2];
-    };
-    // part 0: the first 15 reads, part 1: the 16th (lgkmcnt is a 4-bit counter: at most 15 reads can be
-    // left in flight by a counted wait, so the last read of K-tile t + 1 is issued after the wait for K-tile t)
-    auto load_frags = [&](Frags &f, int slot, int wbuf, int tap, int part) {
-        if (part == 1) {
-            f.a[3][1] = *(const bf16x8 *)(lds_a + slot * WIN_A + a_off + 3 * 2048 + fo1);
-            return;
-        }
-        const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-        for (int bj = 0; bj < 4; ++bj) {
-            const int w = win_row(bj, ky, kx);
-            const char *rp = lds_w + wbuf * WIN_W + w * 128;
-            f.b[bj][0] = *(const bf16x8 *)(rp + ((fq ^ (w & 7)) << 4));
-            f.b[bj][1] = *(const bf16x8 *)(rp + (((4 + fq) ^ (w & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f.a[i][0] = *(const bf16x8 *)(lds_a + slot * WIN_A + a_off + i * 2048 + fo0);
-            if (i < 3) f.a[i][1] = *(const bf16x8 *)(lds_a + slot * WIN_A + a_off + i * 2048 + fo1);
-        }
-    };
-    auto mfma_tile = [&](const Frags &f) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int bj = 0; bj < 4; ++bj)
-                    acc[i][bj >> 1][bj & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i][ks], f.b[bj][ks],
-                                                                                    acc[i][bj >> 1][bj & 1], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // ---- prologue: window of chunk 0, weights of K-tiles 0..3; fragments of K-tile 0 ---------------------
+    // ---- prologue: window of chunk 0, weights of K-tiles 0 and 1 -------------------------------------------------
 #pragma unroll
     for (int k = 0; k < MAXWB; ++k)
-        if (k < nwb) stage_W(k, 0, 0);
+        if (k < nwb) stage_W(woff[k], k, 0, 0);
     stage_A(0, 0, 0);
-    stage_A(1, 0, 1);                                  // T >= 9 always
-    stage_A(2, 0, 2);
-    stage_A(3, 0, 3);
-    WAIT_VMCNT(4);                                     // window 0, K-tiles 0 and 1 have landed (this wave's part)
+    stage_A(1, 0, 1);
+    WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
-    Frags f0, f1;
-    load_frags(f0, 0, 0, 0, 0);
-    load_frags(f0, 0, 0, 0, 1);
-    STAMP(0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // the two wave rows run one barrier apart
 
-    // ---- main loop: one K-tile (= one tap of one chunk, 32 MFMAs per wave) per barrier ---------------------
-    // iteration t:  issue the fragment reads of K-tile t + 1 | wait for the fragments of K-tile t | 32 MFMAs |
-    //               wait until this wave's part of K-tile t + 2 has landed | barrier | DMA: one window block
-    //               of the next chunk (taps 0..5) and the weights of K-tile t + 4 into the slot K-tile t just left
-    int tap = 0, ci = 0;                               // K-tile t
-    int tap4 = 4, ci4 = 0;                             // K-tile t + 4
-    bool w_prev = false;                               // did iteration t - 1 issue a window block?
-    auto iteration = [&](int t, Frags &cur, Frags &nxt) {
-        int tap1 = tap + 1, ci1 = ci;
-        if (tap1 == 9) {
-            tap1 = 0;
-            ++ci1;
+    // ---- main loop: chunk ci, nine statically unrolled taps; one K-tile = 2 phases of 16 MFMAs ------------------
+    //   phase 0: read the 8 weight fragments and pixel rows 0, 1; DMA the weights of K-tile t + 2
+    //   phase 1: read pixel rows 2, 3; DMA one block of the NEXT chunk's window (taps 0 .. nwb - 1); wait until the
+    //            weights of K-tile t + 1 (and at tap 8 the whole next window) have landed
+    for (int ci = 0; ci < nc; ++ci) {
+        const bool more = ci + 1 < nc;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const char *const a_slot0 = fa0 + (tap % 3) * WIN_A, *const a_slot1 = fa1 + (tap % 3) * WIN_A;
+            // phase 0
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ro = wrd[j + ky][kx];
+                fb[j][0] = *(const bf16x8 *)(smem + ro);
+                fb[j][1] = *(const bf16x8 *)(smem + (ro ^ 64));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][0] = *(const bf16x8 *)(a_slot0 + i * 2048);
+                fa[i][1] = *(const bf16x8 *)(a_slot1 + i * 2048);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap < 7) stage_A(tap + 2, ci, (tap + 2) % 3);
+            else if (more) stage_A(tap - 7, ci + 1, (tap + 2) % 3);
+            __builtin_amdgcn_s_barrier();
+            WAIT_LGKMCNT(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][0][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // phase 1
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ro = wrd[2 + j + ky][kx];
+                fb[j][0] = *(const bf16x8 *)(smem + ro);
+                fb[j][1] = *(const bf16x8 *)(smem + (ro ^ 64));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // DMA issued after the weights of K-tile t + 1: this tap's and the previous tap's window block, and
+            // the weights of K-tile t + 2
+            const bool w_now = tap < MAXWB && tap < nwb && more;
+            const bool w_prev = tap >= 1 && tap - 1 < MAXWB && tap - 1 < nwb && more;
+            if (tap < MAXWB) {
+                if (w_now) stage_W(woff[tap < MAXWB ? tap : 0], tap, ci + 1, (ci & 1) ^ 1);
+            }
+            const bool a_next = tap < 7 || more;     // were weights of K-tile t + 2 issued in phase 0?
+            if (!a_next) {
+                WAIT_VMCNT(0);
+            } else if (w_now && w_prev) {
+                WAIT_VMCNT(4);
+            } else if (w_now || w_prev) {
+                WAIT_VMCNT(3);
+            } else {
+                WAIT_VMCNT(2);
+            }
+            __builtin_amdgcn_s_barrier();
+            WAIT_LGKMCNT(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][1][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
         }
-        if (t + 1 < T) load_frags(nxt, (t + 1) & 3, ci1 & 1, tap1, 0);
-        STAMP(1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T) WAIT_LGKMCNT(15);               // the 15 reads just issued may stay in flight
-        else WAIT_LGKMCNT(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < T) load_frags(nxt, (t + 1) & 3, ci1 & 1, tap1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(3);
-        mfma_tile(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(4);
-        // K-tile t + 2 (weights, and at a chunk seam the window) must be in LDS before the next iteration reads it
-        if (t + 4 < T) {
-            if (w_prev) WAIT_VMCNT(3);
-            else WAIT_VMCNT(2);
-        } else {
-            WAIT_VMCNT(0);
-        }
-        STAMP(6);
-        __builtin_amdgcn_s_barrier();
-        STAMP(5);
-        const bool w_now = tap < nwb && ci + 1 < nc;   // window block `tap` of the next chunk
-        if (w_now) stage_W(tap, ci + 1, (ci & 1) ^ 1);
-        if (t + 4 < T) stage_A(tap4, ci4, t & 3);
-        w_prev = w_now;
-        if (++tap == 9) {
-            tap = 0;
-            ++ci;
-        }
-        if (++tap4 == 9) {
-            tap4 = 0;
-            ++ci4;
-        }
-    };
-    for (int t = 0; t < T; t += 2) {                   // T = 9 nc may be odd: the second half is guarded
-        iteration(t, f0, f1);
-        if (t + 1 < T) iteration(t + 1, f1, f0);
+        // the next chunk reads the other window buffer
+        const int delta = (ci & 1) ? -WIN_W : WIN_W;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) wrd[r][kx] += delta;
     }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
 
     // ---- epilogue -----------------------------------------------------------------------------------------------
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
@@ -296,14 +270,6 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                                    res[bj][i], ssum[i], ssq[i], ssum_hi[i], ssq_hi[i]);
         }
     }
-#ifdef EXP_STAMP
-    STAMP(7);
-    if (lane == 0 && blockIdx.x < 2048) {              // diagnostic build: p.stats is a debug buffer [2048][8 waves][8]
-        unsigned long long *dbg = (unsigned long long *)p.stats + ((int64_t)blockIdx.x * 8 + wave) * 8;
-        for (int i = 0; i < 8; ++i) dbg[i] = st_acc[i];
-    }
-    if (p.alpha != 12345.f) return;
-#endif
     if (p.stats) {                                     // one statistics row per (patch, wave column): 64 pixels
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

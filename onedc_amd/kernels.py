@@ -199,7 +199,7 @@ PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then 
 def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
     """The tile instantiation onedc_conv_gemm picks (mirrors the dispatcher in gemm_conv.hip)."""
     rows128 = (cout + 127) // 128 * 128
-    if tile == 130 and win_ok and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6:
+    if tile in (0, 130) and win_ok and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6:
         return "win3x3"
     if tile != 128 and cout % 256 == 0 and (((cout // 256) * blocks_m256 >= 160 and ktiles >= 8) or tile == 256):
         return "256x256"
@@ -255,8 +255,8 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     e1.record()
     flops = 2.0 * p.B * p.OH * p.OW * p.Cout * (p.KH * p.KW * p.Cin) * max(batch, 1) * flop_scale
     bm = (p.B * p.OH * p.OW + 255) // 256 * max(batch, 1)
-    win_ok = (p.KH == 3 and p.stride == 1 and not pixel_shuffle and batch <= 1 and not p.in_f32 and p.OH % 16 == 0 and
-              p.OW % 16 == 0 and p.Cin % 64 == 0)
+    win_ok = (p.KH == 3 and p.stride == 1 and p.pad == 1 and not pixel_shuffle and batch <= 1 and not p.in_f32 and
+              p.OH % 16 == 0 and p.OW % 16 == 0 and p.Cin % 64 == 0)
     es_in = 4 if p.in_f32 else 2
     es_out = 4 if p.out_f32 else 2
     cout_store = p.Cout // 2 if glu else p.Cout

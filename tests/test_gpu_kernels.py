@@ -616,6 +616,22 @@ def test_conv_win3x3_race_screen_and_batch_invariance():
     assert torch.equal(y1.t[:48 * 48 * 128], ref.view(4, -1)[2])
 
 
+def test_conv_win3x3_is_the_automatic_choice_whatever_the_batch():
+    """tile=0 (automatic) takes the window kernel for every eligible 3x3 layer, for one picture as for sixteen:
+    same bits as the forced window kernel, output and statistics."""
+    x, w, b = rnd(3, 128, 32, 32, seed=171), rnd(256, 128, 3, 3, seed=172, scale=1 / 34), rnd(256, seed=173)
+    for xs in (x, x[1:2]):
+        outs = []
+        for tile in (130, 0):
+            y = new_view(xs.shape[0], 32, 32, 256, DEV, stats=True)
+            K.conv_gemm(from_nchw(xs.to(DEV)), packed(w), b.to(DEV), y, KH=3, tile=tile, stats=True)
+            outs.append((y.t[:xs.shape[0] * 32 * 32 * 256].clone(), y.stats.t.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        if xs.shape[0] == 3:
+            whole = outs[0][0].view(3, -1)[1].clone()
+    assert torch.equal(outs[0][0].view(-1), whole)
+
+
 def test_conv_stats_identical_across_kernel_families():
     """Which conv kernel runs depends on the problem size (hence on the batch size).  Outputs AND the
     GroupNorm partial sums left by the epilogue must not: 4-wave, 128x256 and 256x256 kernels, bit for bit."""
@@ -638,7 +654,7 @@ def test_softmax_rows_long(n, n_pad):
     assert float(p[:, n:].float().abs().max() if n_pad > n else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("tile", [128, 129])
+@pytest.mark.parametrize("tile", [128, 129, 130])
 def test_group_norm_pair_statistics_320_and_960_channels(tile):
     """Group sizes of 10 / 30 channels (320 / 960-channel buffers of the UNet): the epilogue leaves one entry per
     channel PAIR; concat buffer 640 + 320 = 960 normalised as a whole, and its 320-channel tail on its own."""
