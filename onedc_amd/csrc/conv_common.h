@@ -262,15 +262,20 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
         v[3] += bf2f((bf16_t)(r.v.y >> 16));
     }
     if (p.stats) {       // explicit order and explicit fma: identical rounding in every kernel that includes this
-        if (p.stats_gran == 2) {                   // channel pairs: (ssum, ssq) = channels 0, 1; (_hi) = channels 2, 3
-            ssum = (ssum + v[0]) + v[1];
-            ssq = __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq));
-            ssum_hi = (ssum_hi + v[2]) + v[3];
-            ssq_hi = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], ssq_hi));
-        } else {
-            ssum = (((ssum + v[0]) + v[1]) + v[2]) + v[3];
-            ssq = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq))));
-        }
+        // quads:  ssum = (((ssum + v0) + v1) + v2) + v3, ssq likewise with fma
+        // pairs:  (ssum, ssq) take channels 0, 1 and (ssum_hi, ssq_hi) channels 2, 3
+        // written without branches on purpose: stores into different accumulators from two branches make the
+        // compiler select between their ADDRESSES, which pins all of them in scratch memory
+        const bool pairs = p.stats_gran == 2;
+        const float s_lo = (ssum + v[0]) + v[1];
+        const float q_lo = __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq));
+        const float s_in = pairs ? ssum_hi : s_lo, q_in = pairs ? ssq_hi : q_lo;
+        const float s_up = (s_in + v[2]) + v[3];
+        const float q_up = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], q_in));
+        ssum = pairs ? s_lo : s_up;
+        ssq = pairs ? q_lo : q_up;
+        ssum_hi = pairs ? s_up : ssum_hi;
+        ssq_hi = pairs ? q_up : ssq_hi;
     }
     const int64_t yo = e.opix * p.y_cs + p.y_co + e.n_out;
 #ifdef EXP_NOSTORE
@@ -291,6 +296,52 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
             for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = f2bf(v[k]);
         }
     }
+}
+
+// ---- fast epilogue ------------------------------------------------------------------------------------------
+// The general functions above decide per tile between f32 / bf16 output, pixel shuffle, GLU pairs, partial and
+// unaligned channel quads: ~300 instructions per 16x16 tile, microseconds per workgroup.  Almost every launch is
+// the plain case -- bf16 output, no shuffle, no GLU, channel quads whole and 8-byte aligned -- for which one tile
+// is: 4 fma, activation, residual add, statistics, pack, one 8-byte store at a precomputed address.
+// Same operations in the same order as conv_epi_finish: results are bit-identical to the general path.
+__device__ __forceinline__ bool conv_epi_fast_ok(const onedc_conv_params &p, bool glu) {
+    return !p.out_f32 && !p.pixel_shuffle && !glu && ((p.y_cs | p.y_co | p.Cout) & 3) == 0 &&
+           (p.epi == ONEDC_EPI_LINEAR || p.epi == ONEDC_EPI_LEAKY || p.epi == ONEDC_EPI_SILU);
+}
+template <int ACT>   // ONEDC_EPI_LINEAR / _LEAKY / _SILU
+__device__ __forceinline__ void conv_epi_fast(const onedc_conv_params &p, const f32x4 &accv, const float4 &bias,
+                                              const uint2 &res, bf16_t *yp, float &ssum, float &ssq, float &ssum_hi,
+                                              float &ssq_hi) {
+    float v[4];
+    v[0] = __builtin_fmaf(accv[0], p.alpha, bias.x);
+    v[1] = __builtin_fmaf(accv[1], p.alpha, bias.y);
+    v[2] = __builtin_fmaf(accv[2], p.alpha, bias.z);
+    v[3] = __builtin_fmaf(accv[3], p.alpha, bias.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (ACT == ONEDC_EPI_LEAKY) v[k] = leaky(v[k], p.slope);
+        if (ACT == ONEDC_EPI_SILU) v[k] = silu_f(v[k]);
+    }
+    v[0] += bf2f((bf16_t)(res.x & 0xffff));
+    v[1] += bf2f((bf16_t)(res.x >> 16));
+    v[2] += bf2f((bf16_t)(res.y & 0xffff));
+    v[3] += bf2f((bf16_t)(res.y >> 16));
+    if (p.stats) {
+        const bool pairs = p.stats_gran == 2;
+        const float s_lo = (ssum + v[0]) + v[1];
+        const float q_lo = __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq));
+        const float s_in = pairs ? ssum_hi : s_lo, q_in = pairs ? ssq_hi : q_lo;
+        const float s_up = (s_in + v[2]) + v[3];
+        const float q_up = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], q_in));
+        ssum = pairs ? s_lo : s_up;
+        ssq = pairs ? q_lo : q_up;
+        ssum_hi = pairs ? s_up : ssum_hi;
+        ssq_hi = pairs ? q_up : ssq_hi;
+    }
+#ifdef EXP_NOSTORE
+    if (p.alpha != 12345.f) return;
+#endif
+    *(uint2 *)yp = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
 }
 
 // GroupNorm statistics in the producer's epilogue.  A wave covers 64 consecutive output pixels and,

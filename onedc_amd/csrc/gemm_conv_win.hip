@@ -29,6 +29,8 @@
 // Note: the k order is (chunk, tap) here against (tap, chunk) in the generic kernels, so results agree to
 // fp32 summation-order rounding, not bit for bit; each kernel on its own is deterministic and
 // batch-invariant.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace {
@@ -230,6 +232,9 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
+#ifdef EXP_WIN_NOEPI
+    if (p.alpha != 12345.f) return;
+#endif
     // ---- epilogue -----------------------------------------------------------------------------------------------
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     const int cout_store = glu ? p.Cout / 2 : p.Cout;
@@ -237,12 +242,45 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     const char *rb = (const char *)p.res;
     const int nw = n0 + wr * 64;
     float ssum[4], ssq[4], ssum_hi[4], ssq_hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ssum[i] = ssq[i] = ssum_hi[i] = ssq_hi[i] = 0.f;
+    if (conv_epi_fast_ok(p, glu)) {
+        // channels nw + 16 i + 4 fq .. + 3 of pixel (row 4 wc + bj, column frow): one 8-byte store per tile
+        float4 bias[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nw + i * 16 + fq * 4;
+            ok[i] = n < p.Cout;
+            bias[i] = (p.bias && ok[i]) ? *(const float4 *)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int64_t pix0 = ((int64_t)img * p.OH + y0 + 4 * wc) * p.OW + x0 + frow;
+        uint2 res[4][4];
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+            const bf16_t *rp = (const bf16_t *)rb + (pix0 + bj * p.OW) * p.r_cs + p.r_co + nw + fq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[bj][i] = (rb && ok[i]) ? *(const uint2 *)(rp + i * 16) : make_uint2(0u, 0u);
+        }
+        auto finish = [&](auto act) {
+            constexpr int ACT = decltype(act)::value;
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) {
+                bf16_t *yp = (bf16_t *)yb + (pix0 + bj * p.OW) * p.y_cs + p.y_co + nw + fq * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ok[i])
+                        conv_epi_fast<ACT>(p, acc[i][bj >> 1][bj & 1], bias[i], res[bj][i], yp + i * 16, ssum[i], ssq[i],
+                                           ssum_hi[i], ssq_hi[i]);
+            }
+        };
+        if (p.epi == ONEDC_EPI_SILU) finish(std::integral_constant<int, ONEDC_EPI_SILU>());
+        else if (p.epi == ONEDC_EPI_LEAKY) finish(std::integral_constant<int, ONEDC_EPI_LEAKY>());
+        else finish(std::integral_constant<int, ONEDC_EPI_LINEAR>());
+    } else {
     EpiBias bias[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ssum[i] = ssq[i] = ssum_hi[i] = ssq_hi[i] = 0.f;
-        bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
-    }
+    for (int i = 0; i < 4; ++i) bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
     EpiRes<false> res[4][4];                           // pass 1: positions + residual loads of all 16 tiles
 #pragma unroll
     for (int bj = 0; bj < 4; ++bj) {
@@ -269,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             conv_epi_finish<false>(p, yb, glu, cout_store, acc[i][bj >> 1][bj & 1], acc[i2][bj >> 1][bj & 1], bias[i], e,
                                    res[bj][i], ssum[i], ssq[i], ssum_hi[i], ssq_hi[i]);
         }
+    }
     }
     if (p.stats) {                                     // one statistics row per (patch, wave column): 64 pixels
 #pragma unroll
