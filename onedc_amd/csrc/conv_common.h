@@ -308,10 +308,10 @@ __device__ __forceinline__ bool conv_epi_fast_ok(const onedc_conv_params &p, boo
     return !p.out_f32 && !p.pixel_shuffle && !glu && ((p.y_cs | p.y_co | p.Cout) & 3) == 0 &&
            (p.epi == ONEDC_EPI_LINEAR || p.epi == ONEDC_EPI_LEAKY || p.epi == ONEDC_EPI_SILU);
 }
-template <int ACT>   // ONEDC_EPI_LINEAR / _LEAKY / _SILU
-__device__ __forceinline__ void conv_epi_fast(const onedc_conv_params &p, const f32x4 &accv, const float4 &bias,
-                                              const uint2 &res, bf16_t *yp, float &ssum, float &ssq, float &ssum_hi,
-                                              float &ssq_hi) {
+template <int ACT>   // ONEDC_EPI_LINEAR / _LEAKY / _SILU: the four bf16 values of one tile, packed
+__device__ __forceinline__ uint2 conv_epi_fast_value(const onedc_conv_params &p, const f32x4 &accv, const float4 &bias,
+                                                     const uint2 &res, float &ssum, float &ssq, float &ssum_hi,
+                                                     float &ssq_hi) {
     float v[4];
     v[0] = __builtin_fmaf(accv[0], p.alpha, bias.x);
     v[1] = __builtin_fmaf(accv[1], p.alpha, bias.y);
@@ -338,10 +338,17 @@ __device__ __forceinline__ void conv_epi_fast(const onedc_conv_params &p, const 
         ssum_hi = pairs ? s_up : ssum_hi;
         ssq_hi = pairs ? q_up : ssq_hi;
     }
+    return make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+template <int ACT>
+__device__ __forceinline__ void conv_epi_fast(const onedc_conv_params &p, const f32x4 &accv, const float4 &bias,
+                                              const uint2 &res, bf16_t *yp, float &ssum, float &ssq, float &ssum_hi,
+                                              float &ssq_hi) {
+    const uint2 o = conv_epi_fast_value<ACT>(p, accv, bias, res, ssum, ssq, ssum_hi, ssq_hi);
 #ifdef EXP_NOSTORE
     if (p.alpha != 12345.f) return;
 #endif
-    *(uint2 *)yp = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    *(uint2 *)yp = o;
 }
 
 // GroupNorm statistics in the producer's epilogue.  A wave covers 64 consecutive output pixels and,

@@ -262,21 +262,52 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
 #pragma unroll
             for (int i = 0; i < 4; ++i) res[bj][i] = (rb && ok[i]) ? *(const uint2 *)(rp + i * 16) : make_uint2(0u, 0u);
         }
+        // A wave whose 64 channels all exist (and whose channel chunks are 16-byte aligned in y) sends its 64 x 64
+        // outputs through LDS: fragments are written as [pixel][64 channels] rows of 128 bytes (16-byte chunk c of
+        // pixel row r at c ^ (r & 7)), read back 16 bytes per lane and stored as whole 128-byte lines -- 8 store
+        // instructions of full lines instead of 16 of scattered 32-byte pieces, which is what the store path charges
+        // for.  Every LDS read of the main loop is behind the last barrier, and a wave only touches its own 8 KB.
+        const bool rows = nw + 64 <= p.Cout && ((p.y_cs | p.y_co) & 7) == 0;
+        typedef __attribute__((address_space(3))) char lds_char;   // explicit LDS pointers: no generic-pointer merging
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        lds_char *const my = (lds_char *)smem + wave * 8192;
         auto finish = [&](auto act) {
             constexpr int ACT = decltype(act)::value;
 #pragma unroll
             for (int bj = 0; bj < 4; ++bj) {
                 bf16_t *yp = (bf16_t *)yb + (pix0 + bj * p.OW) * p.y_cs + p.y_co + nw + fq * 4;
+                const int px = bj * 16 + frow;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ok[i])
+                for (int i = 0; i < 4; ++i) {
+                    if (rows) {
+                        const uint2 o = conv_epi_fast_value<ACT>(p, acc[i][bj >> 1][bj & 1], bias[i], res[bj][i], ssum[i],
+                                                                 ssq[i], ssum_hi[i], ssq_hi[i]);
+                        const int s8 = i * 4 + fq;             // 8-byte slot of the pixel's 128-byte row
+                        *(__attribute__((address_space(3))) u32x2_t *)(my + px * 128 + (((s8 >> 1) ^ (px & 7)) << 4) + (s8 & 1) * 8) = u32x2_t{o.x, o.y};
+                    } else if (ok[i]) {
                         conv_epi_fast<ACT>(p, acc[i][bj >> 1][bj & 1], bias[i], res[bj][i], yp + i * 16, ssum[i], ssq[i],
                                            ssum_hi[i], ssq_hi[i]);
+                    }
+                }
             }
         };
         if (p.epi == ONEDC_EPI_SILU) finish(std::integral_constant<int, ONEDC_EPI_SILU>());
         else if (p.epi == ONEDC_EPI_LEAKY) finish(std::integral_constant<int, ONEDC_EPI_LEAKY>());
         else finish(std::integral_constant<int, ONEDC_EPI_LINEAR>());
+        if (rows) {
+            const int c = lane & 7;
+#ifdef EXP_NOSTORE
+            if (p.alpha == 12345.f)
+#endif
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int px = it * 8 + (lane >> 3);           // pixel (row 4 wc + (px >> 4), column px & 15) of the patch
+                const u32x4_t o = *(const __attribute__((address_space(3))) u32x4_t *)(my + px * 128 + ((c ^ (px & 7)) << 4));
+                const int64_t pix = ((int64_t)img * p.OH + y0 + 4 * wc + (px >> 4)) * p.OW + x0 + (px & 15);
+                *(u32x4_t *)((bf16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
+            }
+        }
     } else {
     EpiBias bias[4];
 #pragma unroll
