@@ -304,7 +304,7 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
 // the plain case -- bf16 output, no shuffle, no GLU, channel quads whole and 8-byte aligned -- for which one tile
 // is: 4 fma, activation, residual add, statistics, pack, one 8-byte store at a precomputed address.
 // Same operations in the same order as conv_epi_finish: results are bit-identical to the general path.
-__device__ __forceinline__ bool conv_epi_fast_ok(const onedc_conv_params &p, bool glu) {
+__host__ __device__ __forceinline__ bool conv_epi_fast_ok(const onedc_conv_params &p, bool glu) {
     return !p.out_f32 && !p.pixel_shuffle && !glu && ((p.y_cs | p.y_co | p.Cout) & 3) == 0 &&
            (p.epi == ONEDC_EPI_LINEAR || p.epi == ONEDC_EPI_LEAKY || p.epi == ONEDC_EPI_SILU);
 }

@@ -240,6 +240,8 @@ int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st);      
 int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st);  // gemm_conv256.hip
 bool onedc_conv_win_ok(const onedc_conv_params &p);                             // gemm_conv_win.hip
 int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
+bool onedc_conv_ups_ok(const onedc_conv_params &p);                             // gemm_conv_ups.hip
+int onedc_conv_ups_launch(const onedc_conv_params &p, hipStream_t st);
 
 extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (!pp) return -1;
@@ -268,6 +270,8 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
                     ((glu ? p.Cout / 2 : p.Cout) & 3) || p.batch > 1))
         return -10;
     hipStream_t st = as_stream(stream);
+    // up == 2: x2 upsample + 3x3 decomposed into four 2x2 phase convolutions; w is the phase-packed matrix
+    if (p.up == 2) return onedc_conv_ups_ok(p) ? onedc_conv_ups_launch(p, st) : -12;
     if (p.in_f32) return launch<Tile<128, 128, 2, 2>, true>(p, st);
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
     // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per 64-channel chunk):

@@ -57,7 +57,7 @@ class UNet:
             blk = {"res": [ResnetBlock2D(sd, f"up_blocks.{i}.resnets.{j}", device, 1e-5) for j in range(3)],
                    "ins": ins, "c": c}
             blk["attn"] = [Transformer2D(sd, f"up_blocks.{i}.attentions.{j}", device, c) for j in range(3)] if i > 0 else None
-            blk["up"] = Conv(sd, f"up_blocks.{i}.upsamplers.0.conv", device) if i < 3 else None
+            blk["up"] = Conv(sd, f"up_blocks.{i}.upsamplers.0.conv", device, upsample=True) if i < 3 else None
             self.up.append(blk)
         self.norm_out = GroupNorm(sd, "conv_norm_out", device, 1e-5)
         self.conv_out = Conv(sd, "conv_out", device)

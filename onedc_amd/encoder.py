@@ -180,7 +180,7 @@ class AnalysisUNet:
                    "io": [plan[(i, j)] for j in range(3)]}
             blk["attn"] = [GroupNormAttention(sd, f"{p}.up_blocks.{i}.attentions.{j}", device, plan[(i, j)][1])
                            for j in range(3)] if i < 2 else None
-            blk["up"] = Conv(sd, f"{p}.up_blocks.{i}.upsamplers.0.conv", device) if i < 2 else None
+            blk["up"] = Conv(sd, f"{p}.up_blocks.{i}.upsamplers.0.conv", device, upsample=True) if i < 2 else None
             self.up.append(blk)
         self.norm_out = GroupNorm(sd, f"{p}.conv_norm_out", device, 1e-5)
         self.conv_out = Conv(sd, f"{p}.conv_out", device)

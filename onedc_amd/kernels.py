@@ -253,7 +253,8 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     e0.record()
     _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
     e1.record()
-    flops = 2.0 * p.B * p.OH * p.OW * p.Cout * (p.KH * p.KW * p.Cin) * max(batch, 1) * flop_scale
+    # executed multiply-adds: the phase-decomposed upsample conv (up == 2) runs 4 taps per output, not 9
+    flops = 2.0 * p.B * p.OH * p.OW * p.Cout * ((4 if up == 2 else p.KH * p.KW) * p.Cin) * max(batch, 1) * flop_scale
     bm = (p.B * p.OH * p.OW + 255) // 256 * max(batch, 1)
     win_ok = (p.KH == 3 and p.stride == 1 and p.pad == 1 and not pixel_shuffle and batch <= 1 and not p.in_f32 and
               p.OH % 16 == 0 and p.OW % 16 == 0 and p.Cin % 64 == 0)
@@ -263,7 +264,8 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     nbytes = (p.B * p.IH * p.IW * p.Cin * es_in + p.B * p.OH * p.OW * cout_store * es_out +
               p.Cout * p.KH * p.KW * p.Cin * es_in + (p.B * p.OH * p.OW * cout_store * es_in if res is not None else 0)) \
         * max(batch, 1)
-    PROFILE.append(("f32_128x128" if p.in_f32 else conv_tile(p.Cout, glu, bm, tile, p.KH * p.KW * (p.Cin // 64), win_ok),
+    PROFILE.append(("ups2x2" if up == 2 else "f32_128x128" if p.in_f32 else
+                    conv_tile(p.Cout, glu, bm, tile, p.KH * p.KW * (p.Cin // 64), win_ok),
                     flops, e0, e1, float(nbytes)))
     return y
 

@@ -14,7 +14,7 @@ import torch
 
 from . import kernels as K
 from . import pack
-from .kernels import EPI_GEGLU, EPI_GLU_LEAKY, EPI_LEAKY, EPI_LINEAR, View, new_view
+from .kernels import EPI_GEGLU, EPI_GLU_LEAKY, EPI_LEAKY, EPI_LINEAR, EPI_SILU, View, new_view
 
 
 class Workspace:
@@ -38,11 +38,14 @@ class Workspace:
         return self._get(name, n, torch.bfloat16)
 
 
+USE_UPSAMPLE_PHASES = True    # tests switch it off to compare with the plain fused-upsample path
+
+
 class Conv:
     """nn.Conv2d / nn.Linear as one implicit-GEMM launch."""
 
     def __init__(self, sd, name, device, *, perm=None, glu=False, shuffle=False, weight=None, bias=None,
-                 flop_scale=1.0, f32=False):
+                 flop_scale=1.0, f32=False, upsample=False):
         self.flop_scale = flop_scale          # < 1 when rows/cols are zero padding (padded heads)
         self.f32 = f32                        # exact-f32 path: f32 weights, activations, output
         w = sd[f"{name}.weight"] if weight is None else weight
@@ -57,6 +60,11 @@ class Conv:
         self.w = pack.pack_matrix(m, device, perm, torch.float32 if f32 else torch.bfloat16)
         self.b = pack.f32(b, device, perm)
         self.glu, self.shuffle = glu, shuffle
+        # conv behind a nearest x2 upsample: also keep the four 2x2 phase convolutions (2.25x fewer MACs); used
+        # whenever the input map is whole 16x16 patches, the plain fused-upsample path otherwise
+        self.w_ups = None
+        if upsample and self.k == 3 and self.cout % 128 == 0 and self.cin % 64 == 0 and not f32:
+            self.w_ups = pack.pack_matrix(pack.upsample_phase_matrix(w), device)
 
     def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
                  alpha=1.0, stats=False, pad=None):
@@ -78,6 +86,11 @@ class Conv:
             y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else torch.bfloat16)
         if stats:
             y.want_stats()
+        if (up and self.w_ups is not None and USE_UPSAMPLE_PHASES and res is None and x.H % 16 == 0 and
+                x.W % 16 == 0 and not y.f32 and y.cs % 8 == 0 and y.co % 8 == 0 and
+                epi in (EPI_LINEAR, EPI_LEAKY, EPI_SILU)):
+            return K.conv_gemm(x, self.w_ups, self.b, y, KH=3, up=2, epi=epi, slope=slope, alpha=alpha, Cin=self.cin,
+                               Cout=self.cout, stats=stats)
         return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
                            alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
                            Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad)

@@ -52,6 +52,27 @@ def conv_matrix(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
 
 
+def upsample_phase_matrix(w):
+    """(C, Cin, 3, 3) weights of a 3x3 conv that follows a nearest x2 upsample -> [4 C][4 Cin] matrix of the four
+    2x2 phase convolutions on the low-resolution input (csrc/gemm_conv_ups.hip): row (py*2+px)*C + c, column
+    (ty*2+tx)*Cin + cin, W'[py,px][ty,tx] = sum of W[ky,kx] over ky in S(py,ty), kx in S(px,tx) with
+    S(0,0)={0}, S(0,1)={1,2}, S(1,0)={0,1}, S(1,1)={2}.  Sums in f32."""
+    sets = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+    w = w.float()
+    C, Cin = w.shape[0], w.shape[1]
+    out = w.new_zeros(4, C, 4, Cin)
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    acc = w.new_zeros(C, Cin)
+                    for ky in sets[(py, ty)]:
+                        for kx in sets[(px, tx)]:
+                            acc += w[:, :, ky, kx]
+                    out[py * 2 + px, :, ty * 2 + tx, :] = acc
+    return out.reshape(4 * C, 4 * Cin)
+
+
 def glu_perm(n_half):
     """Row order for GLU epilogues: [v0..v15, g0..g15, v16..v31, g16..g31, ...]."""
     assert n_half % 16 == 0

@@ -39,7 +39,7 @@ class VAEDecoder:
         self.up = []
         for i, (cin, cout) in enumerate(arch.VAE_UP):
             blk = {"res": [ResnetBlock2D(sd, f"decoder.up_blocks.{i}.resnets.{j}", device, 1e-6) for j in range(3)]}
-            blk["up"] = Conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", device) if i < 3 else None
+            blk["up"] = Conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", device, upsample=True) if i < 3 else None
             self.up.append(blk)
         self.norm_out = GroupNorm(sd, "decoder.conv_norm_out", device, 1e-6)
         self.conv_out = Conv(sd, "decoder.conv_out", device)

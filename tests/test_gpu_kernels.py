@@ -632,6 +632,54 @@ def test_conv_win3x3_is_the_automatic_choice_whatever_the_batch():
     assert torch.equal(outs[0][0].view(-1), whole)
 
 
+# ---- x2 upsample + 3x3 as four 2x2 phase convolutions (up=2, gemm_conv_ups.hip) -------------------------------
+@pytest.mark.parametrize("B,H,W,Cin,C,epi", [(2, 16, 32, 128, 128, "linear"), (1, 32, 16, 64, 256, "silu"),
+                                             (3, 16, 16, 320, 128, "linear")])
+def test_conv_upsample_phases(B, H, W, Cin, C, epi):
+    """Against F.conv2d(F.interpolate(nearest)); input and output in channel slices, statistics for the consumer's
+    GroupNorm, and agreement with the plain fused-upsample path (up=1)."""
+    from onedc_amd import pack
+    x, w, b = rnd(B, Cin, H, W, seed=181), rnd(C, Cin, 3, 3, seed=182, scale=(9 * Cin) ** -0.5), rnd(C, seed=183)
+    xbuf = from_nchw(torch.cat([rnd(B, 64, H, W, seed=184), x], 1).to(DEV))
+    ybuf = new_view(B, 2 * H, 2 * W, C + 64, DEV, stats=True)
+    ybuf.t.zero_()
+    wp = pack.pack_matrix(pack.upsample_phase_matrix(w), DEV)
+    e = K.EPI_SILU if epi == "silu" else K.EPI_LINEAR
+    K.conv_gemm(xbuf.slice(64, Cin), wp, b.to(DEV), ybuf.slice(64, C), KH=3, up=2, epi=e, Cin=Cin, Cout=C, stats=True)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    if epi == "silu":
+        ref = F.silu(ref)
+    close(ybuf.slice(64, C).torch_nchw(), ref, what="upsample phases")
+    assert float(ybuf.slice(0, 64).torch_nchw().abs().max()) == 0.0
+    g, be = rnd(C, seed=185), rnd(C, seed=186)
+    out = new_view(B, 2 * H, 2 * W, C, DEV)
+    ws = _WS()
+    K.group_norm(ybuf.slice(64, C), g.to(DEV), be.to(DEV), out, 1e-6, True, ws)
+    assert "gn_partial" not in ws.t
+    close(out.torch_nchw(), F.silu(F.group_norm(ref, 32, g, be, 1e-6)), rms=6e-3, mx=4e-2, what="upsample phases stats")
+    y1 = new_view(B, 2 * H, 2 * W, C, DEV)
+    K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), y1, KH=3, up=1, epi=e)
+    close(ybuf.slice(64, C).torch_nchw(), y1.torch_nchw(), rms=4e-3, mx=3e-2, what="phases vs fused upsample")
+
+
+def test_conv_upsample_phases_race_screen_and_batch_invariance():
+    from onedc_amd import pack
+    x, w = rnd(4, 256, 32, 32, seed=191), rnd(128, 256, 3, 3, seed=192, scale=1 / 48)
+    xv, wp = from_nchw(x.to(DEV)), pack.pack_matrix(pack.upsample_phase_matrix(w), DEV)
+    ref = None
+    for it in range(30):
+        y = new_view(4, 64, 64, 128, DEV)
+        K.conv_gemm(xv, wp, None, y, KH=3, up=2, Cin=256, Cout=128)
+        got = y.t[:4 * 64 * 64 * 128].clone()
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"
+    y1 = new_view(1, 64, 64, 128, DEV)
+    K.conv_gemm(from_nchw(x[2:3].to(DEV)), wp, None, y1, KH=3, up=2, Cin=256, Cout=128)
+    assert torch.equal(y1.t[:64 * 64 * 128], ref.view(4, -1)[2])
+
+
 def test_conv_stats_identical_across_kernel_families():
     """Which conv kernel runs depends on the problem size (hence on the batch size).  Outputs AND the
     GroupNorm partial sums left by the epilogue must not: 4-wave, 128x256 and 256x256 kernels, bit for bit."""
