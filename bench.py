@@ -161,7 +161,8 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if os.path.exists(tpath):
-            t = json.load(open(tpath)).get("conv_gemm256_kernel" if dom == "256x256" else dom)
+            t = json.load(open(tpath)).get({"256x256": "conv_gemm256_kernel", "128x256": "conv_gemm128x256_kernel",
+                                            "win3x3": "conv_win_kernel", "ups2x2": "conv_ups_kernel"}.get(dom, dom))
             if t:
                 traffic = t["hbm_bytes_per_launch"]
         all_flops = sum(v[0] for v in by_tile.values())

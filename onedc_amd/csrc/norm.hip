@@ -1,6 +1,8 @@
 // norm.hip — GroupNorm statistics / apply, LayerNorm, row softmax.  All HBM-bound streaming
 // kernels: 16-byte (8 x bf16) accesses per lane, fp32 math, fixed-order reductions (no atomics) so
 // results do not depend on batch size or scheduling.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -157,23 +159,39 @@ __global__ void scale_shift_act_kernel(const bf16_t *__restrict__ x, const float
     }
     const bf16_t *xp = x + ((int64_t)b * HW) * x_cs + x_co + cc * 8;
     bf16_t *yp = y + ((int64_t)b * HW) * y_cs + y_co + cc * 8;
-    if (silu) {
-        for (int p = p0 + pl; p < p1; p += PL) {
+    // four pixels per iteration, all loads issued before the first use: the loop is bound by memory latency
+    auto run = [&](auto silu_c) {
+        constexpr bool SILU = decltype(silu_c)::value;
+        int p = p0 + pl;
+        for (; p + 3 * PL < p1; p += 4 * PL) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const uint4 *)(xp + (int64_t)(p + u * PL) * x_cs);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] = __builtin_fmaf(f[e], a[e], bb[e]);
+                    if (SILU) f[e] = silu_f(f[e]);
+                }
+                *(uint4 *)(yp + (int64_t)(p + u * PL) * y_cs) = pack8(f);
+            }
+        }
+        for (; p < p1; p += PL) {
             float f[8];
             unpack8(*(const uint4 *)(xp + (int64_t)p * x_cs), f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = silu_f(__builtin_fmaf(f[e], a[e], bb[e]));
+            for (int e = 0; e < 8; ++e) {
+                f[e] = __builtin_fmaf(f[e], a[e], bb[e]);
+                if (SILU) f[e] = silu_f(f[e]);
+            }
             *(uint4 *)(yp + (int64_t)p * y_cs) = pack8(f);
         }
-    } else {
-        for (int p = p0 + pl; p < p1; p += PL) {
-            float f[8];
-            unpack8(*(const uint4 *)(xp + (int64_t)p * x_cs), f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = __builtin_fmaf(f[e], a[e], bb[e]);
-            *(uint4 *)(yp + (int64_t)p * y_cs) = pack8(f);
-        }
-    }
+    };
+    if (silu) run(std::true_type());
+    else run(std::false_type());
 }
 
 // LayerNorm: one wave per row, row cached in registers (C <= 8*64*NCH)
