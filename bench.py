@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sequential", action="store_true", help="no pipelining across batches")
+    ap.add_argument("--s-streams", type=int, default=2, help="concurrent synthesis/UNet/VAE stages in the pipeline")
     ap.add_argument("--cpu-sample", type=int, default=768, help="picture size of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline (16 was the fastest of 16/32/64 on the 2x64-core host)")
@@ -120,7 +121,7 @@ def main():
     # One step = one whole decode of one batch.  Default: the two-stage pipeline (the rANS hops of
     # batch n+1 overlap the UNet / VAE of batch n; all K batches start and finish inside the timed
     # region).  --sequential times K back-to-back model.decode() calls instead.
-    pipe = None if args.sequential else model.pipeline()
+    pipe = None if args.sequential else model.pipeline(s_streams=args.s_streams)
 
     def run(k):
         if pipe is None:
@@ -144,6 +145,16 @@ def main():
     assert out.shape == (B, 3, S, S) and bool(torch.isfinite(out).all())
 
     elapsed = max_over_ranks(elapsed, device, world)
+
+    # The timed region runs several batches at once (the pipeline's streams): a kernel's event-bracketed duration
+    # there includes the time it shares the GPU with kernels of other batches.  One more, untimed, sequential decode
+    # gives the same per-launch figures with the GPU to itself ("isolated" in the roofline object).
+    iso = None
+    if rank == 0 and pipe is not None:
+        K.PROFILE = []
+        model.decode(stream=blobs)
+        torch.cuda.synchronize()
+        iso, K.PROFILE = K.PROFILE, None
 
     if rank == 0:
         by_tile = {}
@@ -181,7 +192,8 @@ def main():
                        "stream_bytes_per_image": stream_bytes // B, "host_rans_threads": model.codec_model.host_threads,
                        "timed": "container parse + host rANS + H2D/D2H + all device kernels + crop",
                        "schedule": "sequential decode() calls" if args.sequential else
-                                   "2-stage pipeline over batches (entropy stage of batch n+1 || UNet+VAE of batch n)"},
+                                   f"pipeline over batches: entropy stage of batch n+1 on its own stream || synthesis+UNet+VAE "
+                                   f"of {args.s_streams} batches on {args.s_streams} streams"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(dom_bytes / launches),
@@ -199,6 +211,14 @@ def main():
                          "conv_gemm_share_of_step": round(all_secs / elapsed, 3),
                          "whole_path_tflops": round(value / world * GFLOP_PER_IMAGE.get(S, 0) / 1e3, 2)},
         }
+        if iso:
+            it = [(f, e0.elapsed_time(e1) * 1e-3) for tile, f, e0, e1, _ in iso if tile == dom]
+            if it:
+                f_iso, s_iso = sum(f for f, _ in it), sum(t for _, t in it)
+                line["roofline"]["isolated"] = {
+                    "achieved": round(f_iso / s_iso / 1e12, 2), "frac": round(f_iso / s_iso / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "avg_launch_us": round(s_iso / len(it) * 1e6, 2), "launches": len(it),
+                    "how": "same kernel, one untimed sequential decode after the timed region (no other batch on the GPU)"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_threads, sds[1], sds[0], sds[2])
         print(json.dumps(line), flush=True)

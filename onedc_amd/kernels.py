@@ -196,6 +196,9 @@ def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
 PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then bracketed by HIP events
 
 
+PROFILE_EVENT_KW = {}     # {"external": True} when the profiled launches are captured into a HIP graph
+
+
 def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
     """The tile instantiation onedc_conv_gemm picks (mirrors the dispatcher in gemm_conv.hip)."""
     rows128 = (cout + 127) // 128 * 128
@@ -249,7 +252,7 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     if PROFILE is None:
         _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
         return y
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True, **PROFILE_EVENT_KW), torch.cuda.Event(enable_timing=True, **PROFILE_EVENT_KW)
     e0.record()
     _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
     e1.record()

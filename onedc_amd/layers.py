@@ -18,17 +18,19 @@ from .kernels import EPI_GEGLU, EPI_GLU_LEAKY, EPI_LEAKY, EPI_LINEAR, EPI_SILU, 
 
 
 class Workspace:
-    """Named scratch tensors that only ever grow (stable addresses -> graph friendly)."""
+    """Named scratch tensors that only ever grow (stable addresses).  One set per HIP stream: the pipeline runs
+    several batches at once, each on its own stream, through the same layers."""
 
     def __init__(self, device):
         self.device = device
         self._t = {}
 
     def _get(self, name, n, dtype):
-        t = self._t.get(name)
+        key = (torch.cuda.current_stream(self.device).cuda_stream, name)
+        t = self._t.get(key)
         if t is None or t.numel() < n or t.dtype != dtype:
             t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
-            self._t[name] = t
+            self._t[key] = t
         return t
 
     def f32(self, name, n):
