@@ -40,7 +40,7 @@ GFLOP_PER_IMAGE = {768: 8046.7, 512: 3419.5, 256: 831.4}   # SURVEY.md 8(d), alg
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=768)

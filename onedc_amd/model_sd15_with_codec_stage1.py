@@ -235,7 +235,7 @@ class DecodePipeline:
             self.stream_e = torch.cuda.Stream(device=self.dev, priority=-1)
             self.streams_s = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, s_streams))]
         self._in = queue.Queue()
-        self._mid = queue.Queue(maxsize=max(1, depth))
+        self._mid = queue.Queue(maxsize=max(1, depth, s_streams))
         self._worker = threading.Thread(target=self._entropy_loop, daemon=True)
         self._worker.start()
         self._s_workers = [threading.Thread(target=self._synthesis_loop, args=(st,), daemon=True)
