@@ -72,8 +72,16 @@ typedef struct onedc_conv_params {
     int32_t in_f32;                     /* 1: x, w, res are f32 (exact f32 MFMA; Cin multiple of 32): the prior
                                            networks, whose outputs feed integer decisions, and the VAE's conv_in */
     int64_t x_bs, w_bs, y_bs, r_bs;     /* element strides between batches */
+    const float *gn_ab;                 /* NULL, or float2 (a, b) [B][Cin] from onedc_gn_from_stats / onedc_gn_stats: x is the
+                                           RAW tensor in front of nn.GroupNorm (+SiLU when gn_silu) and the conv reads
+                                           silu(a*x + b) -- the normalisation is applied while the operand is staged
+                                           (only the 3x3 window kernel does it: ask onedc_conv_win_takes first) */
+    int32_t gn_silu;
+    int32_t reserved0;
 } onedc_conv_params;
 int onedc_conv_gemm(const onedc_conv_params *p, void *stream);
+/* 1 if onedc_conv_gemm would run p on the 3x3 window kernel (the one that can fuse the GroupNorm in front, gn_ab) */
+int onedc_conv_win_takes(const onedc_conv_params *p);
 
 /* Small-channel direct convolution (Cin < 64: VAE conv_in / post_quant_conv, HyperDecoder.feat_in
  * codec_module.py:149-152).  w: f32 [Cout][KH][KW][Cin]; x bf16 or f32 (x_f32). */

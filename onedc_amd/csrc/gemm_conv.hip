@@ -284,6 +284,7 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
             rows128w * 5 <= p.Cout * 6)
             return onedc_conv_win_launch(p, st);
         if (p.tile == 130) return -11;
+        if (p.gn_ab) return -13;                   // only the window kernel normalises on load
     }
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
@@ -300,4 +301,13 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (p.Cout <= 16 && !glu) return launch<Tile<16, 256, 1, 4>>(p, st);
     if ((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) return launch<Tile<64, 128, 2, 2>>(p, st);
     return launch<Tile<128, 128, 2, 2>>(p, st);
+}
+
+extern "C" int onedc_conv_win_takes(const onedc_conv_params *pp) {
+    if (!pp) return 0;
+    const onedc_conv_params &p = *pp;
+    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
+    const int rows128w = (p.Cout + 127) / 128 * 128;
+    return (p.tile == 0 || p.tile == 130) && p.up != 2 && !p.in_f32 && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) &&
+           rows128w * 5 <= p.Cout * 6;
 }

@@ -44,7 +44,7 @@ constexpr int WIN_LDS = WIN_NA * WIN_A + 2 * WIN_W;   // 133120 B
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
-template <bool UP>
+template <bool UP, bool NORM>
 __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_params p, int tiles_n, int tiles_x,
                                                           int tiles_y, int Ktot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,6 +96,46 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     }
     const int nc = p.Cin >> 6;                       // 64-channel chunks
 
+    // NORM: the input is the raw tensor in front of a GroupNorm (+SiLU); the window is staged through registers and
+    // normalised on the way: v = silu(a[c] * x + b[c]) with (a, b) per (image, channel) from onedc_gn_from_stats, the
+    // same operations in the same order as onedc_scale_shift_act, so the conv sees bit-identical operands -- and the
+    // normalised tensor never exists in HBM (it was 10 % of the device time to write and re-read it).  (a, b) of the
+    // image sit in LDS behind the window buffers; halo rows stay zero (the conv pads the NORMALISED tensor).
+    float2 *const lds_ab = (float2 *)(smem + WIN_LDS);
+    const char *const xb_img = (const char *)p.x + img * img_bytes;
+    float na[8], nb[8];                              // (a, b) of this lane's 8 channels of the chunk being staged
+    auto load_ab = [&](int ci) {
+        const float4 *q = (const float4 *)(lds_ab + ci * 64 + chunk * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float4 v = q[e];
+            na[2 * e] = v.x;
+            nb[2 * e] = v.y;
+            na[2 * e + 1] = v.z;
+            nb[2 * e + 1] = v.w;
+        }
+    };
+    auto load_raw = [&](unsigned off, int ci) {      // 8 channels of one window row (zeros for halo / padding rows)
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (off != x_bytes) r = *(const uint4 *)(xb_img + off + ci * 128);
+        return r;
+    };
+    auto norm_store = [&](const uint4 &raw, unsigned off, int k, int wbuf) {
+        const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float lo = __builtin_fmaf(bf2f((bf16_t)(w4[e] & 0xffff)), na[2 * e], nb[2 * e]);
+            float hi = __builtin_fmaf(bf2f((bf16_t)(w4[e] >> 16)), na[2 * e + 1], nb[2 * e + 1]);
+            if (p.gn_silu) {
+                lo = silu_f(lo);
+                hi = silu_f(hi);
+            }
+            o4[e] = off != x_bytes ? pack_bf2(lo, hi) : 0u;
+        }
+        *(uint4 *)(lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024 + lane * 16) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    };
+
     // K-tile (chunk ci, tap): weights are [row][tap][cin] -> byte offset (tap * Cin + ci * 64) * 2 inside a row
     auto stage_A = [&](int tap, int ci, int slot) {
         char *dst = lds_a + slot * WIN_A + wave * 1024;
@@ -134,12 +174,27 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     bf16x8 fa[4][2], fb[2][2];
 
     // ---- prologue: window of chunk 0, weights of K-tiles 0 and 1 -------------------------------------------------
+    if (NORM) {
+        for (int c = tid; c < p.Cin; c += 512) lds_ab[c] = ((const float2 *)p.gn_ab)[(int64_t)img * p.Cin + c];
+        stage_A(0, 0, 0);
+        stage_A(1, 0, 1);
+        uint4 raw[MAXWB];
 #pragma unroll
-    for (int k = 0; k < MAXWB; ++k)
-        if (k < nwb) stage_W(woff[k], k, 0, 0);
-    stage_A(0, 0, 0);
-    stage_A(1, 0, 1);
+        for (int k = 0; k < MAXWB; ++k) raw[k] = k < nwb ? load_raw(woff[k], 0) : make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();                             // (a, b) of the image are in LDS
+        load_ab(0);
+#pragma unroll
+        for (int k = 0; k < MAXWB; ++k)
+            if (k < nwb) norm_store(raw[k], woff[k], k, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < MAXWB; ++k)
+            if (k < nwb) stage_W(woff[k], k, 0, 0);
+        stage_A(0, 0, 0);
+        stage_A(1, 0, 1);
+    }
     WAIT_VMCNT(0);
+    WAIT_LGKMCNT(0);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();       // the two wave rows run one barrier apart
 
@@ -147,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     //   phase 0: read the 8 weight fragments and pixel rows 0, 1; DMA the weights of K-tile t + 2
     //   phase 1: read pixel rows 2, 3; DMA one block of the NEXT chunk's window (taps 0 .. nwb - 1); wait until the
     //            weights of K-tile t + 1 (and at tap 8 the whole next window) have landed
+    uint4 nraw = make_uint4(0u, 0u, 0u, 0u);       // NORM: the window block in flight
     for (int ci = 0; ci < nc; ++ci) {
         const bool more = ci + 1 < nc;
 #pragma unroll
@@ -195,7 +251,17 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             // the weights of K-tile t + 2
             const bool w_now = tap < MAXWB && tap < nwb && more;
             const bool w_prev = tap >= 1 && tap - 1 < MAXWB && tap - 1 < nwb && more;
-            if (tap < MAXWB) {
+            if (NORM) {
+                // block tap - 1 was loaded one tap ago: normalise it into the next window; then fetch block tap
+                // (the compiler's own vmcnt for `nraw` also covers the weights of K-tile t + 1, which are older)
+                if (tap == 0 && more) load_ab(ci + 1);
+                if (tap >= 1 && tap - 1 < MAXWB) {
+                    if (w_prev) norm_store(nraw, woff[tap - 1 < MAXWB ? tap - 1 : 0], tap - 1, (ci & 1) ^ 1);
+                }
+                if (tap < MAXWB) {
+                    if (w_now) nraw = load_raw(woff[tap < MAXWB ? tap : 0], ci + 1);
+                }
+            } else if (tap < MAXWB) {
                 if (w_now) stage_W(woff[tap < MAXWB ? tap : 0], tap, ci + 1, (ci & 1) ^ 1);
             }
             const bool a_next = tap < 7 || more;     // were weights of K-tile t + 2 issued in phase 0?
@@ -364,8 +430,9 @@ bool onedc_conv_win_ok(const onedc_conv_params &p) {
 int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void *)conv_win_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
-        (void)hipFuncSetAttribute((const void *)conv_win_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        (void)hipFuncSetAttribute((const void *)conv_win_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        (void)hipFuncSetAttribute((const void *)conv_win_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
+        (void)hipFuncSetAttribute((const void *)conv_win_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         configured = true;
     }
     const int tiles_n = (p.Cout + 127) / 128;
@@ -373,12 +440,17 @@ int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st) {
     const int Ktot = 9 * p.Cin;
     const int64_t blocks = (int64_t)tiles_n * tiles_x * tiles_y * p.B;
     if (blocks > 0x7fffffff) return -1;
-    if (p.up)
-        hipLaunchKernelGGL(conv_win_kernel<true>, dim3((unsigned)blocks), dim3(512), WIN_LDS, st, p, tiles_n, tiles_x,
+    if (p.gn_ab) {
+        if (p.up || WIN_LDS + p.Cin * 8 > 160 * 1024) return -13;
+        hipLaunchKernelGGL((conv_win_kernel<false, true>), dim3((unsigned)blocks), dim3(512), WIN_LDS + p.Cin * 8, st, p,
+                           tiles_n, tiles_x, tiles_y, Ktot);
+    } else if (p.up) {
+        hipLaunchKernelGGL((conv_win_kernel<true, false>), dim3((unsigned)blocks), dim3(512), WIN_LDS, st, p, tiles_n, tiles_x,
                            tiles_y, Ktot);
-    else
-        hipLaunchKernelGGL(conv_win_kernel<false>, dim3((unsigned)blocks), dim3(512), WIN_LDS, st, p, tiles_n, tiles_x,
+    } else {
+        hipLaunchKernelGGL((conv_win_kernel<false, false>), dim3((unsigned)blocks), dim3(512), WIN_LDS, st, p, tiles_n, tiles_x,
                            tiles_y, Ktot);
+    }
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

@@ -28,6 +28,7 @@ class ConvParams(C.Structure):
         ("batch", C.c_int32), ("tile", C.c_int32), ("stats_gran", C.c_int32), ("patch16", C.c_int32),
         ("in_f32", C.c_int32),
         ("x_bs", _L), ("w_bs", _L), ("y_bs", _L), ("r_bs", _L),
+        ("gn_ab", _P), ("gn_silu", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -43,6 +44,7 @@ class DirectConvParams(C.Structure):
 
 SIGNATURES = {
     "onedc_conv_gemm": (_I, [C.POINTER(ConvParams), _P]),
+    "onedc_conv_win_takes": (_I, [C.POINTER(ConvParams)]),
     "onedc_direct_conv": (_I, [C.POINTER(DirectConvParams), _P]),
     "onedc_dwconv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_dwconv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -219,8 +221,11 @@ def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
               pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0,
-              tile=0, stats=False, pad=None):
-    """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None."""
+              tile=0, stats=False, pad=None, gn=None):
+    """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None.
+    gn = (gamma, beta, eps, silu, ws): the conv reads GroupNorm(x) (+SiLU).  On the 3x3 window kernel the
+    normalisation is applied while the operand is staged (x is read raw, the normalised tensor never exists);
+    any other kernel gets it from the separate scale/shift pass, with identical values."""
     p = ConvParams()
     p.x, p.w, p.bias, p.res, p.y = x.ptr, w.data_ptr(), _ptr(bias), (res.ptr if res is not None else None), y.ptr
     p.zeros = zeros_page(x.t.device).data_ptr()
@@ -249,6 +254,16 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
         raise KernelError("f32 conv_gemm needs f32 weights and residual")
     p.alpha, p.slope = alpha, slope
     p.batch, p.x_bs, p.w_bs, p.y_bs, p.r_bs = batch, x_bs, w_bs, y_bs, r_bs
+    if gn is not None:
+        gamma, beta, eps, silu, ws = gn
+        # every 128-channel output tile normalises the window again: only worth it while there is one tile
+        if USE_GN_FUSION and x.C == p.Cin and p.Cout <= GN_FUSION_MAX_COUT and lib().onedc_conv_win_takes(C.byref(p)):
+            p.gn_ab = group_norm_ab(x, gamma, beta, eps, ws).data_ptr()
+            p.gn_silu = int(silu)
+        else:
+            xn = new_view(x.B, x.H, x.W, x.C, x.t.device)
+            group_norm(x, gamma, beta, xn, eps, silu, ws)
+            p.x, p.x_cs, p.x_co = xn.ptr, xn.cs, xn.co
     if PROFILE is None:
         _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
         return y
@@ -300,9 +315,13 @@ def gn_chunks(HW):
 USE_EPILOGUE_STATS = True    # False: always run the separate statistics pass (tests, A/B)
 
 
-def group_norm(x, gamma, beta, y, eps, silu, ws):
-    """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors.  When the convs that
-    produced x left partial sums (x.stats covers the normalised channels and a group is whole quads),
+GN_FUSION_MAX_COUT = 128
+USE_GN_FUSION = True         # False: GroupNorm in front of a conv always runs as its own scale/shift pass (tests, A/B)
+
+
+def group_norm_ab(x, gamma, beta, eps, ws):
+    """Per (image, channel) scale and shift of GroupNorm(32): float2 [B][C] in ws.  When the convs that
+    produced x left partial sums (x.stats covers the normalised channels and a group is whole quads / pairs),
     the statistics pass over x is skipped."""
     HW = x.H * x.W
     ab = ws.f32("gn_ab", x.B * x.C * 2)
@@ -314,7 +333,13 @@ def group_norm(x, gamma, beta, y, eps, silu, ws):
         part = ws.f32("gn_partial", x.B * gn_chunks(HW) * 64)
         _ok(lib().onedc_gn_stats(x.ptr, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), ab.data_ptr(),
                                  x.B, HW, x.C, x.cs, x.co, eps, stream()), "onedc_gn_stats")
-    _ok(lib().onedc_scale_shift_act(x.ptr, ab.data_ptr(), y.ptr, x.B, HW, x.C, x.cs, x.co, y.cs, y.co,
+    return ab
+
+
+def group_norm(x, gamma, beta, y, eps, silu, ws):
+    """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors."""
+    ab = group_norm_ab(x, gamma, beta, eps, ws)
+    _ok(lib().onedc_scale_shift_act(x.ptr, ab.data_ptr(), y.ptr, x.B, x.H * x.W, x.C, x.cs, x.co, y.cs, y.co,
                                     int(silu), stream()), "onedc_scale_shift_act")
     return y
 

@@ -69,8 +69,10 @@ class Conv:
             self.w_ups = pack.pack_matrix(pack.upsample_phase_matrix(w), device)
 
     def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
-                 alpha=1.0, stats=False, pad=None):
-        """stats: the output feeds a GroupNorm -- leave its partial sums in the epilogue."""
+                 alpha=1.0, stats=False, pad=None, gn=None):
+        """stats: the output feeds a GroupNorm -- leave its partial sums in the epilogue.
+        gn = (GroupNorm layer, workspace, silu): the conv reads that norm of x (fused into the operand staging
+        where the kernel can, kernels.conv_gemm)."""
         if y is None:
             oh, ow = x.H, x.W
             if stride == 2:
@@ -93,9 +95,11 @@ class Conv:
                 epi in (EPI_LINEAR, EPI_LEAKY, EPI_SILU)):
             return K.conv_gemm(x, self.w_ups, self.b, y, KH=3, up=2, epi=epi, slope=slope, alpha=alpha, Cin=self.cin,
                                Cout=self.cout, stats=stats)
+        if gn is not None:
+            gn = (gn[0].g, gn[0].b, gn[0].eps, gn[2], gn[1])
         return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
                            alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
-                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad)
+                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad, gn=gn)
 
 
 _Conv = Conv
@@ -157,8 +161,8 @@ class VQResnetBlock:
         self.c2 = Conv(sd, f"{p}.conv2", device)
 
     def __call__(self, x, ws, y=None):
-        h = self.c1(self.n1(x, ws, True), stats=True)
-        return self.c2(self.n2(h, ws, True), y, res=x, stats=True)
+        h = self.c1(x, stats=True, gn=(self.n1, ws, True))
+        return self.c2(h, y, res=x, stats=True, gn=(self.n2, ws, True))
 
 
 class SingleHeadAttention:
@@ -234,10 +238,9 @@ class ResnetBlock2D:
             self.c1.b = (self._c1_bias + self._tw @ temb_act.to(self._tw.device) + self._tb).contiguous().to(self.device)
 
     def __call__(self, x, ws, y=None):
-        h = self.c1(self.n1(x, ws, True), stats=True)
-        h = self.n2(h, ws, True)
+        h = self.c1(x, stats=True, gn=(self.n1, ws, True))
         res = self.short(x) if self.short is not None else x
-        return self.c2(h, y, res=res, stats=True)
+        return self.c2(h, y, res=res, stats=True, gn=(self.n2, ws, True))
 
 
 class MultiHeadAttention:

@@ -680,6 +680,42 @@ def test_conv_upsample_phases_race_screen_and_batch_invariance():
     assert torch.equal(y1.t[:64 * 64 * 128], ref.view(4, -1)[2])
 
 
+# ---- GroupNorm (+SiLU) applied while the window kernel stages its operand (gn=...) --------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,silu", [(2, 32, 16, 128, 128, True), (1, 16, 48, 320, 128, True),
+                                                 (2, 16, 16, 64, 128, False), (1, 48, 48, 512, 128, True)])
+def test_conv_win3x3_groupnorm_on_load(B, H, W, Cin, Cout, silu):
+    """conv(act(GroupNorm(x))) + residual: the fused path against F.conv2d(F.group_norm), and bit for bit against
+    the unfused path (separate scale/shift pass, same kernel) -- halo pixels must stay zero, not act(b)."""
+    x, w, b = rnd(B, Cin, H, W, seed=201), rnd(Cout, Cin, 3, 3, seed=202, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=203)
+    g, be, r = 1 + 0.2 * rnd(Cin, seed=204), 0.5 * rnd(Cin, seed=205), rnd(B, Cout, H, W, seed=206)
+    xbuf = from_nchw(torch.cat([rnd(B, 64, H, W, seed=207), x], 1).to(DEV))        # input is a channel slice
+    outs = []
+    for fuse in (True, False):
+        K.USE_GN_FUSION = fuse
+        try:
+            y = new_view(B, H, W, Cout, DEV, stats=True)
+            ws = _WS()
+            K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), y, KH=3, res=from_nchw(r.to(DEV)), stats=True,
+                        gn=(g.to(DEV), be.to(DEV), 1e-6, silu, ws))
+        finally:
+            K.USE_GN_FUSION = True
+        outs.append((y.t[:B * H * W * Cout].clone(), y.stats.t.clone()))
+    n = F.group_norm(x, 32, g, be, 1e-6)
+    ref = F.conv2d(F.silu(n) if silu else n, w, b, padding=1) + r
+    close(y.torch_nchw(), ref, rms=6e-3, mx=4e-2, what="gn on load (unfused)")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_conv_groupnorm_argument_on_other_kernels():
+    """gn= on a layer the window kernel cannot take (1x1): falls back to the separate pass, same result."""
+    B, H, W, Cin, Cout = 2, 12, 12, 128, 256
+    x, w = rnd(B, Cin, H, W, seed=211), rnd(Cout, Cin, 1, 1, seed=212, scale=Cin ** -0.5)
+    g, be = 1 + 0.2 * rnd(Cin, seed=213), 0.5 * rnd(Cin, seed=214)
+    y = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), None, y, KH=1, gn=(g.to(DEV), be.to(DEV), 1e-5, True, _WS()))
+    close(y.torch_nchw(), F.conv2d(F.silu(F.group_norm(x, 32, g, be, 1e-5)), w), rms=6e-3, mx=4e-2, what="gn fallback")
+
+
 def test_conv_stats_identical_across_kernel_families():
     """Which conv kernel runs depends on the problem size (hence on the batch size).  Outputs AND the
     GroupNorm partial sums left by the epilogue must not: 4-wave, 128x256 and 256x256 kernels, bit for bit."""
