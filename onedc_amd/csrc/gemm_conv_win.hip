@@ -120,20 +120,30 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         if (off != x_bytes) r = *(const uint4 *)(xb_img + off + ci * 128);
         return r;
     };
-    auto norm_store = [&](const uint4 &raw, unsigned off, int k, int wbuf) {
-        const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
-        uint32_t o4[4];
+    // two of the four 32-bit words (4 of the 8 channels) of a block: the main loop spreads a block over two phases so
+    // that the work of a phase fits under the other wave row's MFMA segment
+    auto norm_half = [&](const uint4 &raw, unsigned off, int half, uint32_t &o0, uint32_t &o1) {
+        const uint32_t w2[2] = {half ? raw.z : raw.x, half ? raw.w : raw.y};
+        uint32_t o2[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float lo = __builtin_fmaf(bf2f((bf16_t)(w4[e] & 0xffff)), na[2 * e], nb[2 * e]);
-            float hi = __builtin_fmaf(bf2f((bf16_t)(w4[e] >> 16)), na[2 * e + 1], nb[2 * e + 1]);
+        for (int e = 0; e < 2; ++e) {
+            const int c = 4 * half + 2 * e;
+            float lo = __builtin_fmaf(bf2f((bf16_t)(w2[e] & 0xffff)), na[c], nb[c]);
+            float hi = __builtin_fmaf(bf2f((bf16_t)(w2[e] >> 16)), na[c + 1], nb[c + 1]);
             if (p.gn_silu) {
                 lo = silu_f(lo);
                 hi = silu_f(hi);
             }
-            o4[e] = off != x_bytes ? pack_bf2(lo, hi) : 0u;
+            o2[e] = off != x_bytes ? pack_bf2(lo, hi) : 0u;
         }
-        *(uint4 *)(lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024 + lane * 16) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        o0 = o2[0];
+        o1 = o2[1];
+    };
+    auto norm_store = [&](const uint4 &raw, unsigned off, int k, int wbuf) {
+        uint32_t o[4];
+        norm_half(raw, off, 0, o[0], o[1]);
+        norm_half(raw, off, 1, o[2], o[3]);
+        *(uint4 *)(lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024 + lane * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     };
 
     // K-tile (chunk ci, tap): weights are [row][tap][cin] -> byte offset (tap * Cin + ci * 64) * 2 inside a row
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     //   phase 1: read pixel rows 2, 3; DMA one block of the NEXT chunk's window (taps 0 .. nwb - 1); wait until the
     //            weights of K-tile t + 1 (and at tap 8 the whole next window) have landed
     uint4 nraw = make_uint4(0u, 0u, 0u, 0u);       // NORM: the window block in flight
+    uint32_t nout0 = 0, nout1 = 0;                   // ... and its first two normalised words
     for (int ci = 0; ci < nc; ++ci) {
         const bool more = ci + 1 < nc;
 #pragma unroll
@@ -225,6 +236,9 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             __builtin_amdgcn_sched_barrier(0);
             if (tap < 7) stage_A(tap + 2, ci, (tap + 2) % 3);
             else if (more) stage_A(tap - 7, ci + 1, (tap + 2) % 3);
+            if (NORM && tap >= 1 && tap - 1 < MAXWB) {   // first half of the window block fetched one tap ago
+                if (tap - 1 < nwb && more) norm_half(nraw, woff[tap - 1 < MAXWB ? tap - 1 : 0], 0, nout0, nout1);
+            }
             __builtin_amdgcn_s_barrier();
             WAIT_LGKMCNT(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -256,7 +270,12 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                 // (the compiler's own vmcnt for `nraw` also covers the weights of K-tile t + 1, which are older)
                 if (tap == 0 && more) load_ab(ci + 1);
                 if (tap >= 1 && tap - 1 < MAXWB) {
-                    if (w_prev) norm_store(nraw, woff[tap - 1 < MAXWB ? tap - 1 : 0], tap - 1, (ci & 1) ^ 1);
+                    if (w_prev) {                    // second half, then the whole 16 bytes go to the next window
+                        uint32_t o2, o3;
+                        norm_half(nraw, woff[tap - 1 < MAXWB ? tap - 1 : 0], 1, o2, o3);
+                        *(uint4 *)(lds_w + ((ci & 1) ^ 1) * WIN_W + (wave + 8 * (tap - 1)) * 1024 + lane * 16) =
+                            make_uint4(nout0, nout1, o2, o3);
+                    }
                 }
                 if (tap < MAXWB) {
                     if (w_now) nraw = load_raw(woff[tap < MAXWB ? tap : 0], ci + 1);

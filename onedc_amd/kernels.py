@@ -315,7 +315,7 @@ def gn_chunks(HW):
 USE_EPILOGUE_STATS = True    # False: always run the separate statistics pass (tests, A/B)
 
 
-GN_FUSION_MAX_COUT = 128
+GN_FUSION_MAX_COUT = int(__import__("os").environ.get("ONEDC_GN_FUSION_MAX_COUT", "128"))
 USE_GN_FUSION = True         # False: GroupNorm in front of a conv always runs as its own scale/shift pass (tests, A/B)
 
 
