@@ -159,9 +159,35 @@ struct EpiPos {
     bool full;        // all four channels exist (vector access allowed if aligned)
 };
 
+// Compile-time description of the epilogue of a launch.  EpiGeneric decides everything at run time (f32 / bf16
+// output, pixel shuffle, GLU pairs, partial or unaligned channel quads: ~300 instructions per 16x16 tile).
+// EpiMode<true, ACT> is the common case -- bf16 output, no shuffle, whole 8-byte-aligned channel quads, activation
+// ACT known -- where a tile is ~25 instructions.  Same arithmetic in the same order: results are bit-identical.
+template <bool FAST, int ACT>
+struct EpiMode {
+    static constexpr bool fast = FAST;
+    static constexpr int act = ACT;
+    static constexpr bool glu = FAST && (ACT == ONEDC_EPI_GLU_LEAKY || ACT == ONEDC_EPI_GEGLU);
+};
+typedef EpiMode<false, 0> EpiGeneric;
+__host__ __device__ __forceinline__ bool conv_epi_mode_fast(const onedc_conv_params &p) {
+    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
+    const int cout_store = glu ? p.Cout / 2 : p.Cout;
+    return !p.out_f32 && !p.in_f32 && !p.pixel_shuffle && ((p.y_cs | p.y_co | cout_store) & 3) == 0 &&
+           (!p.res || ((p.r_cs | p.r_co) & 3) == 0) && p.epi >= ONEDC_EPI_LINEAR && p.epi <= ONEDC_EPI_GEGLU;
+}
+
+template <class M = EpiGeneric>
 __device__ __forceinline__ EpiPos conv_epi_pos(const onedc_conv_params &p, bool glu, int cout_store, int nrow16,
                                                int fq, const ConvOutPix &op, bool pixel_ok) {
     EpiPos e;
+    if (M::fast) {
+        e.n_out = (M::glu ? nrow16 / 2 : nrow16) + fq * 4;
+        e.store = pixel_ok && e.n_out < cout_store;
+        e.opix = op.m;
+        e.full = true;
+        return e;
+    }
     int n_out = (glu ? nrow16 / 2 : nrow16) + fq * 4;
     e.store = pixel_ok && n_out < cout_store;
     e.opix = op.m;
@@ -182,11 +208,17 @@ struct EpiRes {
     uint4 v;
 };
 
-template <bool F32>
+template <bool F32, class M = EpiGeneric>
 __device__ __forceinline__ void conv_epi_load_res(const onedc_conv_params &p, const char *rb, int cout_store,
                                                   const EpiPos &e, EpiRes<F32> &r) {
     r.v = make_uint4(0, 0, 0, 0);
     if (!rb || !e.store) return;
+    if (M::fast && !F32) {
+        const uint2 t = *(const uint2 *)((const bf16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out);
+        r.v.x = t.x;
+        r.v.y = t.y;
+        return;
+    }
     if (F32) {
         const float *rp = (const float *)rb + e.opix * p.r_cs + p.r_co + e.n_out;
         if (e.full) {
@@ -226,7 +258,7 @@ __device__ __forceinline__ EpiBias conv_epi_bias(const onedc_conv_params &p, boo
 
 // ssum / ssq: running sum and sum of squares of the four stored values (GroupNorm statistics of the
 // consumer, see conv_stats_store); untouched when the lane stores nothing.
-template <bool F32>
+template <bool F32, class M = EpiGeneric>
 __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char *yb, bool glu, int cout_store,
                                                 const f32x4 &accv, const f32x4 &accg, const EpiBias &bias,
                                                 const EpiPos &e, const EpiRes<F32> &r, float &ssum, float &ssq,
@@ -236,17 +268,18 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
     const float bv[4] = {bias.v.x, bias.v.y, bias.v.z, bias.v.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(accv[k], p.alpha, bv[k]);
-    if (glu) {
+    const int epi = M::fast ? M::act : p.epi;      // compile-time in the fast modes
+    if (M::fast ? M::glu : glu) {
         const float bg[4] = {bias.g.x, bias.g.y, bias.g.z, bias.g.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float g = __builtin_fmaf(accg[k], p.alpha, bg[k]);
-            v[k] = p.epi == ONEDC_EPI_GLU_LEAKY ? leaky(v[k], 0.1f) + leaky(g, 0.01f) : v[k] * gelu_f(g);
+            v[k] = epi == ONEDC_EPI_GLU_LEAKY ? leaky(v[k], 0.1f) + leaky(g, 0.01f) : v[k] * gelu_f(g);
         }
-    } else if (p.epi == ONEDC_EPI_LEAKY) {
+    } else if (epi == ONEDC_EPI_LEAKY) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = leaky(v[k], p.slope);
-    } else if (p.epi == ONEDC_EPI_SILU) {
+    } else if (epi == ONEDC_EPI_SILU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = silu_f(v[k]);
     }
@@ -281,6 +314,10 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
 #ifdef EXP_NOSTORE
     if (p.alpha != 12345.f) return;
 #endif
+    if (M::fast) {
+        *(uint2 *)((bf16_t *)yb + yo) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        return;
+    }
     if (p.out_f32) {
         float *yp = (float *)yb + yo;
         if (e.full && ((p.y_cs | p.y_co) & 3) == 0) {
@@ -350,6 +387,22 @@ __device__ __forceinline__ void conv_epi_fast(const onedc_conv_params &p, const 
 #endif
     *(uint2 *)yp = o;
 }
+
+// Run `body(mode)` with the epilogue mode of this launch (body: generic lambda taking an EpiMode value).
+#define ONEDC_EPI_DISPATCH(p, allow_fast, body)                                                   \
+    do {                                                                                          \
+        if ((allow_fast) && conv_epi_mode_fast(p)) {                                              \
+            switch ((p).epi) {                                                                    \
+                case ONEDC_EPI_LEAKY: body(EpiMode<true, ONEDC_EPI_LEAKY>()); break;              \
+                case ONEDC_EPI_SILU: body(EpiMode<true, ONEDC_EPI_SILU>()); break;                \
+                case ONEDC_EPI_GLU_LEAKY: body(EpiMode<true, ONEDC_EPI_GLU_LEAKY>()); break;      \
+                case ONEDC_EPI_GEGLU: body(EpiMode<true, ONEDC_EPI_GEGLU>()); break;              \
+                default: body(EpiMode<true, ONEDC_EPI_LINEAR>()); break;                          \
+            }                                                                                     \
+        } else {                                                                                  \
+            body(EpiGeneric());                                                                   \
+        }                                                                                         \
+    } while (0)
 
 // GroupNorm statistics in the producer's epilogue.  A wave covers 64 consecutive output pixels and,
 // per 16-row accumulator tile, 4 x 4 consecutive channels ("quads", one per lane quarter fq).  After

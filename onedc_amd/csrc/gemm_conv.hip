@@ -14,6 +14,8 @@
 // up with 4 consecutive channels of one pixel -> 8-byte NHWC stores and lane-local epilogues.
 //
 // Replaces nn.Conv2d / nn.Linear everywhere on the reference decode path (see onedc_hip.h).
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace {
@@ -178,31 +180,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
     }
     // pass 1: positions + residual loads of every tile; pass 2: finish + store
-    EpiRes<F32> res[T::FI][T::FJ];
+    auto epilogue = [&](auto mode) {
+        typedef decltype(mode) EM;
+        EpiRes<F32> res[T::FI][T::FJ];
 #pragma unroll
-    for (int j = 0; j < T::FJ; ++j) {
-        const int m = m0 + wm * T::WTM + j * 16 + frow;
-        const ConvOutPix op = conv_out_pix(p, m);
+        for (int j = 0; j < T::FJ; ++j) {
+            const int m = m0 + wm * T::WTM + j * 16 + frow;
+            const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
-        for (int i = 0; i < T::FI; ++i) {
-            if (glu && (i & 1)) continue;          // odd tiles are the gate halves, consumed with their value tile
-            const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
-            conv_epi_load_res<F32>(p, rb, cout_store, e, res[i][j]);
+            for (int i = 0; i < T::FI; ++i) {
+                if (glu && (i & 1)) continue;          // odd tiles are the gate halves, consumed with their value tile
+                const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_load_res<F32, EM>(p, rb, cout_store, e, res[i][j]);
+            }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < T::FJ; ++j) {
-        const int m = m0 + wm * T::WTM + j * 16 + frow;
-        const ConvOutPix op = conv_out_pix(p, m);
+        for (int j = 0; j < T::FJ; ++j) {
+            const int m = m0 + wm * T::WTM + j * 16 + frow;
+            const ConvOutPix op = conv_out_pix(p, m);
 #pragma unroll
-        for (int i = 0; i < T::FI; ++i) {
-            if (glu && (i & 1)) continue;
-            const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
-            const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
-            conv_epi_finish<F32>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i], ssq[i],
-                                 ssum_hi[i], ssq_hi[i]);
+            for (int i = 0; i < T::FI; ++i) {
+                if (glu && (i & 1)) continue;
+                const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
+                const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_finish<F32, EM>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i],
+                                         ssq[i], ssum_hi[i], ssq_hi[i]);
+            }
         }
-    }
+    };
+    ONEDC_EPI_DISPATCH(p, !F32, epilogue);
     if (p.stats) {                                 // wave-uniform
         static_assert(T::WTM == 64, "a wave covers one 64-pixel statistics block");
 #pragma unroll
@@ -288,15 +294,17 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     }
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
-    const int ktiles = p.KH * p.KW * (p.Cin >> 6);         // short K: prologue + epilogue of the one resident block dominate
-    if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 8) || p.tile == 256) &&
+    // short K (< 16 K-tiles: 1x1 layers up to 960 channels): the 4-wave kernels win, two workgroups per CU hide each
+    // other's prologue and epilogue (tools/bench_1x1.py); all three families give identical bits
+    const int ktiles = p.KH * p.KW * (p.Cin >> 6);
+    if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 16) || p.tile == 256) &&
         !(p.stats && p.stats_gran == 2))           // the 256x256 kernel only leaves quad statistics
         return onedc_conv_gemm256_launch(p, st);
     // 128 x 256 tiles (8 waves, 3-deep LDS ring): channel counts that are whole 128-row tiles or waste < 20 %
     const int rows128 = (p.Cout + 127) / 128 * 128;
     const int64_t blocks128 = (rows128 / 128) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
     if (p.tile != 128 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
-        ((blocks128 >= 160 && ktiles >= 6) || p.tile == 129))
+        ((blocks128 >= 160 && ktiles >= 16) || p.tile == 129))
         return onedc_conv_gemm128x256_launch(p, st);
     if (p.Cout <= 16 && !glu) return launch<Tile<16, 256, 1, 4>>(p, st);
     if ((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) return launch<Tile<64, 128, 2, 2>>(p, st);

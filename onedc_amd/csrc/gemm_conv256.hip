@@ -21,6 +21,8 @@
 //
 // Used by onedc_conv_gemm for the layers with >= 256 output rows and enough pixels to fill the chip
 // (all VAE up-block convolutions with 256/512 channels, the UNet's 1280-channel layers, the FF GEMMs).
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace {
@@ -258,6 +260,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
             ssum[a][i] = ssq[a][i] = 0.f;
             bias[a][i] = conv_epi_bias(p, glu, nw + a * 64 + i * 16, fq);
         }
+    auto epilogue = [&](auto mode) {
+        typedef decltype(mode) EM;
     // two pixel halves (b), each: pass 1 = positions + residual loads of its 16 tiles, pass 2 = finish + store
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (glu && (i & 1)) continue;
-                    const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + a * 64 + i * 16, fq, op, m < M);
-                    conv_epi_load_res<false>(p, rb, cout_store, e, res[j][a][i]);
+                    const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + a * 64 + i * 16, fq, op, m < M);
+                    conv_epi_load_res<false, EM>(p, rb, cout_store, e, res[j][a][i]);
                 }
         }
 #pragma unroll
@@ -285,12 +289,16 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
                 for (int i = 0; i < 4; ++i) {
                     if (glu && (i & 1)) continue;
                     const int i2 = (i + 1 < 4) ? i + 1 : i;
-                    const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + a * 64 + i * 16, fq, op, m < M);
-                    conv_epi_finish<false>(p, yb, glu, cout_store, acc[a][i][b][j], acc[a][i2][b][j], bias[a][i], e,
+                    const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + a * 64 + i * 16, fq, op, m < M);
+                    conv_epi_finish<false, EM>(p, yb, glu, cout_store, acc[a][i][b][j], acc[a][i2][b][j], bias[a][i], e,
                                            res[j][a][i], ssum[a][i], ssq[a][i], stat_dummy, stat_dummy);
                 }
         }
     }
+    };
+    // (run-time epilogue only: this kernel sits at 256 VGPRs and a second instantiation of the epilogue spills; launches
+    // with a plain epilogue are sent to the 128x256 kernel instead, see onedc_conv_gemm)
+    epilogue(EpiGeneric());
     if (p.stats) {                                 // wave-uniform
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -520,6 +528,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
         ssum[i] = ssq[i] = ssum_hi[i] = ssq_hi[i] = 0.f;
         bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
     }
+    auto epilogue = [&](auto mode) {
+        typedef decltype(mode) EM;
     EpiRes<false> res[2][2][4];                    // pass 1: positions + residual loads of all 16 tiles
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -530,8 +540,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (glu && (i & 1)) continue;
-                const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
-                conv_epi_load_res<false>(p, rb, cout_store, e, res[b][j][i]);
+                const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_load_res<false, EM>(p, rb, cout_store, e, res[b][j][i]);
             }
         }
 #pragma unroll
@@ -544,11 +554,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
             for (int i = 0; i < 4; ++i) {
                 if (glu && (i & 1)) continue;
                 const int i2 = (i + 1 < 4) ? i + 1 : i;
-                const EpiPos e = conv_epi_pos(p, glu, cout_store, nw + i * 16, fq, op, m < M);
-                conv_epi_finish<false>(p, yb, glu, cout_store, acc[i][b][j], acc[i2][b][j], bias[i], e, res[b][j][i],
+                const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_finish<false, EM>(p, yb, glu, cout_store, acc[i][b][j], acc[i2][b][j], bias[i], e, res[b][j][i],
                                        ssum[i], ssq[i], ssum_hi[i], ssq_hi[i]);
             }
         }
+    };
+    ONEDC_EPI_DISPATCH(p, true, epilogue);
 #ifdef EXP_STAMP
     STAMP(7);
     if (lane == 0 && blockIdx.x < 2048) {          // diagnostic build: p.stats is a debug buffer [2048][8 waves][8]

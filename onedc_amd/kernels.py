@@ -206,11 +206,11 @@ def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
     rows128 = (cout + 127) // 128 * 128
     if tile in (0, 130) and win_ok and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6:
         return "win3x3"
-    if tile != 128 and cout % 256 == 0 and (((cout // 256) * blocks_m256 >= 160 and ktiles >= 8) or tile == 256):
+    if tile != 128 and cout % 256 == 0 and (((cout // 256) * blocks_m256 >= 160 and ktiles >= 16) or tile == 256):
         return "256x256"
     rows128 = (cout + 127) // 128 * 128
     if (tile not in (128, 256) and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6 and
-            (((rows128 // 128) * blocks_m256 >= 160 and ktiles >= 6) or tile == 129)):
+            (((rows128 // 128) * blocks_m256 >= 160 and ktiles >= 16) or tile == 129)):
         return "128x256"
     if cout <= 16 and not glu:
         return "16x256"

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Per-layer-shape device time of the conv launches of one UNet step (B=16): where the generic kernels' time goes."""
+import collections
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from onedc_amd import kernels as K
+from onedc_amd import synth
+from onedc_amd.decoder_unet import UNet
+from onedc_amd.kernels import new_view
+
+DEV = "cuda:0"
+unet = UNet(synth.unet_state_dict(0), DEV)
+g = torch.Generator(device=DEV).manual_seed(0)
+x = new_view(16, 96, 96, 320, DEV)
+x.t.copy_(torch.randn(x.t.numel(), generator=g, device=DEV).to(torch.bfloat16))
+ctx = new_view(16, 12, 12, 768, DEV)
+ctx.t.copy_(torch.randn(ctx.t.numel(), generator=g, device=DEV).to(torch.bfloat16))
+unet(x, 999, ctx)
+torch.cuda.synchronize()
+rec = []
+orig = K.conv_gemm
+
+
+def wrapped(x, w, bias, y, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = orig(x, w, bias, y, **kw)
+    e1.record()
+    cout = kw.get("Cout") or y.C
+    rec.append(((kw.get("KH", 1), x.H, kw.get("Cin") or x.C, cout, kw.get("epi", 0), kw.get("batch", 1),
+                 "res" if kw.get("res") is not None else ""), e0, e1,
+                2.0 * x.B * y.H * y.W * cout * kw.get("KH", 1) ** 2 * (kw.get("Cin") or x.C) * max(1, kw.get("batch", 1))))
+    return r
+
+
+K.conv_gemm = wrapped
+import onedc_amd.layers as L
+L.K.conv_gemm = wrapped
+unet(x, 999, ctx)
+torch.cuda.synchronize()
+agg = collections.OrderedDict()
+for key, e0, e1, fl in rec:
+    d = agg.setdefault(key, [0, 0.0, 0.0])
+    d[0] += 1
+    d[1] += e0.elapsed_time(e1)
+    d[2] += fl
+tot = sum(v[1] for v in agg.values())
+print(f"conv launches {len(rec)}, {tot:.2f} ms")
+for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+    print(f"k{key[0]} {key[1]:3d}x{key[1]:<3d} {key[2]:5d}->{key[3]:<5d} epi{key[4]} batch{key[5]:<3d} {key[6]:3s} x{n:3d} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF")
