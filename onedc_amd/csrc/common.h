@@ -32,6 +32,21 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ?
 __device__ __forceinline__ float silu_f(float v) {
     return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 }
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+// exact-erf GELU (the reference's F.gelu).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
+// rounding of the result): one v_rcp_f32, one v_exp_f32 and a degree-5 Horner chain instead of libm's ~40-instruction erff.
+__device__ __forceinline__ float gelu_f(float v) {
+#ifdef ONEDC_GELU_LIBM
+    return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+#else
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.f));
+    float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    q = __builtin_fmaf(q, t, 1.421413741f);
+    q = __builtin_fmaf(q, t, -0.284496736f);
+    q = __builtin_fmaf(q, t, 0.254829592f);
+    const float e = 1.f - q * t * __builtin_amdgcn_exp2f(x * x * -1.4426950408889634f);      // erf(|v| / sqrt 2)
+    return 0.5f * v * (1.f + (v < 0.f ? -e : e));
+#endif
+}
 
 static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }

@@ -307,7 +307,11 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         ((blocks128 >= 160 && ktiles >= 16) || p.tile == 129))
         return onedc_conv_gemm128x256_launch(p, st);
     if (p.Cout <= 16 && !glu) return launch<Tile<16, 256, 1, 4>>(p, st);
-    if ((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) return launch<Tile<64, 128, 2, 2>>(p, st);
+    // 64-row tiles: channel counts that leave <= 64 rows in the last 128-row tile, and grids of fewer than 256
+    // 128x128 tiles (the 12x12 maps of the UNet: 180 tiles for 256 CUs)
+    const int64_t blocks4w = (rows128 / 128) * ((M64 + 127) / 128) * (p.batch > 1 ? p.batch : 1);
+    if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))
+        return launch<Tile<64, 128, 2, 2>>(p, st);
     return launch<Tile<128, 128, 2, 2>>(p, st);
 }
 

@@ -214,7 +214,7 @@ def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
         return "128x256"
     if cout <= 16 and not glu:
         return "16x256"
-    if cout % 128 != 0 and cout % 128 <= 64:
+    if (cout % 128 != 0 and cout % 128 <= 64) or ((rows128 // 128) * blocks_m256 * 2 < 256 and cout % 64 == 0 and cout >= 128):
         return "64x128"
     return "128x128"
 
