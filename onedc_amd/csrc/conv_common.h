@@ -173,7 +173,8 @@ typedef EpiMode<false, 0> EpiGeneric;
 __host__ __device__ __forceinline__ bool conv_epi_mode_fast(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     const int cout_store = glu ? p.Cout / 2 : p.Cout;
-    return !p.out_f32 && !p.in_f32 && !p.pixel_shuffle && ((p.y_cs | p.y_co | cout_store) & 3) == 0 &&
+    // bf16 in / bf16 out, or the exact-f32 path with f32 output (16-byte stores: same 4-element alignment rule)
+    return (p.out_f32 != 0) == (p.in_f32 != 0) && !p.pixel_shuffle && ((p.y_cs | p.y_co | cout_store) & 3) == 0 &&
            (!p.res || ((p.r_cs | p.r_co) & 3) == 0) && p.epi >= ONEDC_EPI_LINEAR && p.epi <= ONEDC_EPI_GEGLU;
 }
 
@@ -213,10 +214,14 @@ __device__ __forceinline__ void conv_epi_load_res(const onedc_conv_params &p, co
                                                   const EpiPos &e, EpiRes<F32> &r) {
     r.v = make_uint4(0, 0, 0, 0);
     if (!rb || !e.store) return;
-    if (M::fast && !F32) {
-        const uint2 t = *(const uint2 *)((const bf16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out);
-        r.v.x = t.x;
-        r.v.y = t.y;
+    if (M::fast) {
+        if (F32) {
+            r.v = *(const uint4 *)((const float *)rb + e.opix * p.r_cs + p.r_co + e.n_out);
+        } else {
+            const uint2 t = *(const uint2 *)((const bf16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out);
+            r.v.x = t.x;
+            r.v.y = t.y;
+        }
         return;
     }
     if (F32) {
@@ -315,7 +320,8 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
     if (p.alpha != 12345.f) return;
 #endif
     if (M::fast) {
-        *(uint2 *)((bf16_t *)yb + yo) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        if (F32) *(float4 *)((float *)yb + yo) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(uint2 *)((bf16_t *)yb + yo) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
         return;
     }
     if (p.out_f32) {

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
             }
         }
     };
-    ONEDC_EPI_DISPATCH(p, !F32, epilogue);
+    ONEDC_EPI_DISPATCH(p, true, epilogue);
     if (p.stats) {                                 // wave-uniform
         static_assert(T::WTM == 64, "a wave covers one 64-pixel statistics block");
 #pragma unroll
