@@ -286,11 +286,13 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                 if (w_now) stage_W(woff[tap < MAXWB ? tap : 0], tap, ci + 1, (ci & 1) ^ 1);
             }
             const bool a_next = tap < 7 || more;     // were weights of K-tile t + 2 issued in phase 0?
+            // (NORM: the previous tap's block was consumed before this point -- it is not in flight any more)
+            const bool w_prev_dma = w_prev && !NORM;
             if (!a_next) {
                 WAIT_VMCNT(0);
-            } else if (w_now && w_prev) {
+            } else if (w_now && w_prev_dma) {
                 WAIT_VMCNT(4);
-            } else if (w_now || w_prev) {
+            } else if (w_now || w_prev_dma) {
                 WAIT_VMCNT(3);
             } else {
                 WAIT_VMCNT(2);
