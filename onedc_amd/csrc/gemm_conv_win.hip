@@ -252,9 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                         acc[i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][0][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef EXP_WIN_HALFBAR
             __builtin_amdgcn_s_barrier();
-#endif
             // phase 1
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -310,9 +308,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                         acc[i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][1][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef EXP_WIN_HALFBAR
             __builtin_amdgcn_s_barrier();
-#endif
         }
         // the next chunk reads the other window buffer
         const int delta = (ci & 1) ? -WIN_W : WIN_W;
