@@ -130,10 +130,12 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             const int c = 4 * half + 2 * e;
             float lo = __builtin_fmaf(bf2f((bf16_t)(w2[e] & 0xffff)), na[c], nb[c]);
             float hi = __builtin_fmaf(bf2f((bf16_t)(w2[e] >> 16)), na[c + 1], nb[c + 1]);
+#ifndef EXP_NORM_NOSILU
             if (p.gn_silu) {
                 lo = silu_f(lo);
                 hi = silu_f(hi);
             }
+#endif
             o2[e] = off != x_bytes ? pack_bf2(lo, hi) : 0u;
         }
         o0 = o2[0];
@@ -212,8 +214,15 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     //   phase 0: read the 8 weight fragments and pixel rows 0, 1; DMA the weights of K-tile t + 2
     //   phase 1: read pixel rows 2, 3; DMA one block of the NEXT chunk's window (taps 0 .. nwb - 1); wait until the
     //            weights of K-tile t + 1 (and at tap 8 the whole next window) have landed
-    uint4 nraw = make_uint4(0u, 0u, 0u, 0u);       // NORM: the window block in flight
-    uint32_t nout0 = 0, nout1 = 0;                   // ... and its first two normalised words
+    // NORM: window block k of the next chunk is fetched at tap k (phase 1), its first half is normalised at tap k + 2
+    // (phase 1) and the second half at tap k + 3 (phase 0), where the 16 bytes go to LDS -- BEFORE that tap's weight
+    // DMA is issued: the compiler drains every DMA in flight in front of an LDS write it can see, and at that point
+    // only DMA issued a whole K-tile earlier is left.  Three taps between fetch and use cover the HBM latency (the raw
+    // tensor streams from HBM; with one tap the load latency was exposed on every block: +0.65 us per block).
+    uint4 nraw[MAXWB];
+#pragma unroll
+    for (int k = 0; k < MAXWB; ++k) nraw[k] = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t nout0 = 0, nout1 = 0;                   // first two normalised words of the block being converted
     for (int ci = 0; ci < nc; ++ci) {
         const bool more = ci + 1 < nc;
 #pragma unroll
@@ -234,11 +243,26 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                 fa[i][1] = *(const bf16x8 *)(a_slot1 + i * 2048);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (NORM && tap >= 3 && tap - 3 < MAXWB) {   // second half of block tap - 3, and its LDS write
+                if (tap - 3 < nwb && more) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int kb = tap - 3 < MAXWB ? tap - 3 : 0;
+                    uint32_t o2, o3;
+                    norm_half(nraw[kb], woff[kb], 1, o2, o3);
+                    // (inline asm: in front of an LDS write it can see, the compiler waits for vmcnt(0) -- it cannot
+                    // prove that the LDS-DMA in flight does not alias it -- which here would also wait for the register
+                    // loads issued one and two taps ago and undo their prefetch distance)
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    const u32x4_t ov = {nout0, nout1, o2, o3};
+                    char *const dstp = lds_w + ((ci & 1) ^ 1) * WIN_W + (wave + 8 * kb) * 1024 + lane * 16;
+                    asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dstp),
+                                 "v"(ov)
+                                 : "memory");
+                }
+            }
             if (tap < 7) stage_A(tap + 2, ci, (tap + 2) % 3);
             else if (more) stage_A(tap - 7, ci + 1, (tap + 2) % 3);
-            if (NORM && tap >= 1 && tap - 1 < MAXWB) {   // first half of the window block fetched one tap ago
-                if (tap - 1 < nwb && more) norm_half(nraw, woff[tap - 1 < MAXWB ? tap - 1 : 0], 0, nout0, nout1);
-            }
             __builtin_amdgcn_s_barrier();
             WAIT_LGKMCNT(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -263,29 +287,28 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             __builtin_amdgcn_sched_barrier(0);
             // DMA issued after the weights of K-tile t + 1: this tap's and the previous tap's window block, and
             // the weights of K-tile t + 2
+#ifdef EXP_NORM_NOLOOP
+            const bool w_now = false, w_prev = false;
+#else
             const bool w_now = tap < MAXWB && tap < nwb && more;
             const bool w_prev = tap >= 1 && tap - 1 < MAXWB && tap - 1 < nwb && more;
+#endif
             if (NORM) {
-                // block tap - 1 was loaded one tap ago: normalise it into the next window; then fetch block tap
-                // (the compiler's own vmcnt for `nraw` also covers the weights of K-tile t + 1, which are older)
                 if (tap == 0 && more) load_ab(ci + 1);
-                if (tap >= 1 && tap - 1 < MAXWB) {
-                    if (w_prev) {                    // second half, then the whole 16 bytes go to the next window
-                        uint32_t o2, o3;
-                        norm_half(nraw, woff[tap - 1 < MAXWB ? tap - 1 : 0], 1, o2, o3);
-                        *(uint4 *)(lds_w + ((ci & 1) ^ 1) * WIN_W + (wave + 8 * (tap - 1)) * 1024 + lane * 16) =
-                            make_uint4(nout0, nout1, o2, o3);
+                if (tap >= 2 && tap - 2 < MAXWB) {   // first half of block tap - 2
+                    if (tap - 2 < nwb && more) {
+                        const int kb = tap - 2 < MAXWB ? tap - 2 : 0;
+                        norm_half(nraw[kb], woff[kb], 0, nout0, nout1);
                     }
                 }
                 if (tap < MAXWB) {
-                    if (w_now) nraw = load_raw(woff[tap < MAXWB ? tap : 0], ci + 1);
+                    if (w_now) nraw[tap < MAXWB ? tap : 0] = load_raw(woff[tap < MAXWB ? tap : 0], ci + 1);
                 }
             } else if (tap < MAXWB) {
                 if (w_now) stage_W(woff[tap < MAXWB ? tap : 0], tap, ci + 1, (ci & 1) ^ 1);
             }
             const bool a_next = tap < 7 || more;     // were weights of K-tile t + 2 issued in phase 0?
-            // (NORM: the previous tap's block was consumed before this point -- it is not in flight any more)
-            const bool w_prev_dma = w_prev && !NORM;
+            const bool w_prev_dma = w_prev;          // (NORM: the register loads of this and the previous tap)
             if (!a_next) {
                 WAIT_VMCNT(0);
             } else if (w_now && w_prev_dma) {
