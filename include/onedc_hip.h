@@ -58,7 +58,11 @@ typedef struct onedc_conv_params {
     int32_t B, IH, IW, Cin, x_cs, x_co; /* Cin: channels read, multiple of 64 */
     int32_t OH, OW, Cout, y_cs, y_co;   /* Cout: GEMM columns (before GLU halving / shuffle) */
     int32_t r_cs, r_co;
-    int32_t KH, KW, stride, pad, up;    /* up=1: nearest x2 upsample of the input fused in */
+    int32_t KH, KW, stride, pad, up;    /* up=1: nearest x2 upsample of the input fused in (any kernel);
+                                           up=2: the same layer (3x3, stride 1, pad 1) as four 2x2 phase convolutions on
+                                           the low-resolution input: w is [4 Cout rows][4 taps x Cin] from
+                                           pack.upsample_phase_matrix, 4/9 of the multiply-adds (gemm_conv_ups.hip;
+                                           needs Cout % 128 == 0, IH, IW % 16 == 0, plain bf16 epilogue, no residual) */
     int32_t epi, out_f32, pixel_shuffle;
     float alpha, slope;
     int32_t batch;                      /* >1: batched GEMM over blockIdx.z */
