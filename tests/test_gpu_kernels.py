@@ -706,6 +706,26 @@ def test_conv_win3x3_groupnorm_on_load(B, H, W, Cin, Cout, silu):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_conv_win3x3_groupnorm_on_load_race_screen():
+    """The fused path mixes register loads, LDS writes and LDS-DMA under hand-counted waits: same bits 40 times,
+    on a shape with several chunk transitions and many workgroups."""
+    B, H, W, Cin, Cout = 4, 48, 48, 256, 128
+    x, w = rnd(B, Cin, H, W, seed=241), rnd(Cout, Cin, 3, 3, seed=242, scale=(9 * Cin) ** -0.5)
+    g, be = 1 + 0.2 * rnd(Cin, seed=243), 0.5 * rnd(Cin, seed=244)
+    xv, wp, ws = from_nchw(x.to(DEV)), packed(w), _WS()
+    ref = None
+    for it in range(40):
+        y = new_view(B, H, W, Cout, DEV)
+        K.conv_gemm(xv, wp, None, y, KH=3, gn=(g.to(DEV), be.to(DEV), 1e-6, True, ws))
+        got = y.t[:B * H * W * Cout].clone()
+        if ref is None:
+            ref = got
+            close(y.torch_nchw(), F.conv2d(F.silu(F.group_norm(x, 32, g, be, 1e-6)), w, padding=1), rms=6e-3, mx=4e-2,
+                  what="gn on load race ref")
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"
+
+
 def test_conv_groupnorm_argument_on_other_kernels():
     """gn= on a layer the window kernel cannot take (1x1): falls back to the separate pass, same result."""
     B, H, W, Cin, Cout = 2, 12, 12, 128, 256
