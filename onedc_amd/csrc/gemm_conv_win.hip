@@ -48,6 +48,13 @@ template <bool UP, bool NORM>
 __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_params p, int tiles_n, int tiles_x,
                                                           int tiles_y, int Ktot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef EXP_WIN_TIMELINE
+    unsigned long long tl[6];
+    tl[0] = __builtin_amdgcn_s_memtime();
+#define TL(i) tl[i] = __builtin_amdgcn_s_memtime()
+#else
+#define TL(i)
+#endif
     char *const lds_a = smem;
     char *const lds_w = smem + WIN_NA * WIN_A;
     constexpr int WW = UP ? 10 : 18;               // window width (and height)
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     WAIT_VMCNT(0);
     WAIT_LGKMCNT(0);
     __builtin_amdgcn_s_barrier();
+    TL(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();       // the two wave rows run one barrier apart
 
     // ---- main loop: chunk ci, nine statically unrolled taps; one K-tile = 2 phases of 16 MFMAs ------------------
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             for (int kx = 0; kx < 3; ++kx) wrd[r][kx] += delta;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    TL(2);
 
 #ifdef EXP_WIN_NOEPI
     if (p.alpha != 12345.f) return;
@@ -405,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         if (p.epi == ONEDC_EPI_SILU) finish(std::integral_constant<int, ONEDC_EPI_SILU>());
         else if (p.epi == ONEDC_EPI_LEAKY) finish(std::integral_constant<int, ONEDC_EPI_LEAKY>());
         else finish(std::integral_constant<int, ONEDC_EPI_LINEAR>());
+        TL(4);
         if (rows) {
             const int c = lane & 7;
 #ifdef EXP_NOSTORE
@@ -450,6 +460,21 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         }
     }
     }
+#ifdef EXP_WIN_TIMELINE
+    TL(3);
+    if (lane == 0) {     // diagnostic build: p.stats is a debug buffer [blocks][8 waves][6] of int64
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+        unsigned long long *dbg = (unsigned long long *)p.stats + ((int64_t)blockIdx.x * 8 + wave) * 6;
+        dbg[0] = ((unsigned long long)xcc << 32) | hwid;
+        dbg[1] = tl[0];
+        dbg[2] = tl[1];
+        dbg[3] = tl[2];
+        dbg[4] = tl[3];
+        dbg[5] = tl[4];
+    }
+    return;
+#endif
     if (p.stats) {                                     // one statistics row per (patch, wave column): 64 pixels
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
