@@ -169,6 +169,11 @@ class View:
     def slice(self, co, C):
         return View(self.t, self.B, self.H, self.W, C, self.cs, self.co + co, self.stats)
 
+    def batch_slice(self, b0, b1):
+        """Images [b0, b1) of this view (same buffer, no copy; the statistics side array does not carry over)."""
+        off = b0 * self.H * self.W * self.cs
+        return View(self.t[off:], b1 - b0, self.H, self.W, self.C, self.cs, self.co, None)
+
     def torch_nchw(self):
         """fp32 NCHW copy, for tests."""
         n = self.B * self.H * self.W * self.cs

@@ -251,15 +251,27 @@ class DecodePipeline:
                 for _ in self._s_workers:
                     self._mid.put(None)
                 return
-            blobs, job = item
+            blobs, job, split = item
             try:
                 with torch.cuda.stream(self.stream_e), torch.no_grad():
                     out = self.model.codec_model.decode_entropy(stream=blobs)
                     ev = torch.cuda.Event()
                     ev.record(self.stream_e)
-                self._mid.put((out, ev, None, job))
+                if split:
+                    # the odd batch at the end of a call would run its stage S alone on one stream: its two halves go
+                    # to the two streams instead (every kernel is batch-invariant: same bits as the whole batch)
+                    y_hat, z_sem, orig_hw, pad_hw, pad_size = out
+                    h = y_hat.B // 2
+                    slot, results, unit_range, done = job
+                    for part, (b0, b1) in enumerate(((0, h), (h, y_hat.B))):
+                        sub = (y_hat.batch_slice(b0, b1), z_sem.batch_slice(b0, b1), orig_hw[b0:b1], pad_hw, pad_size)
+                        self._mid.put((sub, ev, None, ((slot, part), results, unit_range, done)))
+                else:
+                    self._mid.put((out, ev, None, job))
             except BaseException as e:      # surfaced on the caller's thread
                 self._mid.put((None, None, e, job))
+                if split:
+                    self._mid.put((None, None, e, job))
 
     def _synthesis_loop(self, stream):
         torch.cuda.set_device(self.dev)
@@ -278,9 +290,13 @@ class DecodePipeline:
                     res = self.model._decode_after_entropy(out, unit_range)
                     ev_done = torch.cuda.Event()
                     ev_done.record(stream)
-                results[slot] = (res, ev_done, stream, None)
+                entry = (res, ev_done, stream, None)
             except BaseException as e:
-                results[slot] = (None, None, None, e)
+                entry = (None, None, None, e)
+            if isinstance(slot, tuple):                  # half of a split batch
+                results[slot[0]][slot[1]] = entry
+            else:
+                results[slot] = entry
             done.release()
 
     def map(self, batches, unit_range=False):
@@ -288,18 +304,28 @@ class DecodePipeline:
         import threading
         results = [None] * len(batches)
         done = threading.Semaphore(0)
+        n_jobs = 0
         for i, b in enumerate(batches):
-            self._in.put((b, (i, results, unit_range, done)))
-        for _ in batches:
+            split = (i == len(batches) - 1 and len(batches) % 2 == 1 and len(self.streams_s) == 2 and len(b) >= 2 and
+                     len(b) % 2 == 0)
+            if split:
+                results[i] = [None, None]
+            self._in.put((b, (i, results, unit_range, done), split))
+            n_jobs += 2 if split else 1
+        for _ in range(n_jobs):
             done.acquire()
         cur = torch.cuda.current_stream(self.dev)
         outs = []
-        for res, ev_done, stream, err in results:
-            if err is not None:
-                raise err
-            cur.wait_event(ev_done)
-            res.record_stream(cur)
-            outs.append(res)
+        for entry in results:
+            parts = entry if isinstance(entry, list) else [entry]
+            tensors = []
+            for res, ev_done, stream, err in parts:
+                if err is not None:
+                    raise err
+                cur.wait_event(ev_done)
+                res.record_stream(cur)
+                tensors.append(res)
+            outs.append(tensors[0] if len(tensors) == 1 else torch.cat(tensors, 0))
         return outs
 
     def close(self):

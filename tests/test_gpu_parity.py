@@ -302,16 +302,26 @@ def test_decode_pipeline_matches_sequential_decode(full_model):
         blobs, _ = model.codec_model.encode_latents(idx, None, noise_seed=20 + k)
         batches.append(blobs)
     seq = [model.decode(stream=b) for b in batches]
-    pipe = model.pipeline()
+    pipe = model.pipeline()                 # two stage-S streams; an odd last batch is split over them
     try:
         got = pipe.map(batches)
         got2 = pipe.map(batches[::-1])
+        got3 = pipe.map(batches[:2])        # even number of batches: no split
     finally:
         pipe.close()
+    pipe1 = model.pipeline(s_streams=1)
+    try:
+        got4 = pipe1.map(batches)
+    finally:
+        pipe1.close()
     torch.cuda.synchronize()
     for a, b in zip(seq, got):
         assert torch.equal(a, b)
     for a, b in zip(seq[::-1], got2):
+        assert torch.equal(a, b)
+    for a, b in zip(seq[:2], got3):
+        assert torch.equal(a, b)
+    for a, b in zip(seq, got4):
         assert torch.equal(a, b)
 
 
