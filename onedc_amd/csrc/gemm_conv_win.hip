@@ -253,8 +253,6 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             __builtin_amdgcn_sched_barrier(0);
             if (NORM && tap >= 3 && tap - 3 < MAXWB) {   // second half of block tap - 3, and its LDS write
                 if (tap - 3 < nwb && more) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int kb = tap - 3 < MAXWB ? tap - 3 : 0;
                     uint32_t o2, o3;
                     norm_half(nraw[kb], woff[kb], 1, o2, o3);
