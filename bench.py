@@ -191,6 +191,7 @@ def main():
                        "images_per_gpu_per_step": B, "picture": f"{S}x{S}", "parallelism": f"dp{world}",
                        "stream_bytes_per_image": stream_bytes // B, "host_rans_threads": model.codec_model.host_threads,
                        "timed": "container parse + host rANS + H2D/D2H + all device kernels + crop",
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
                        "schedule": "sequential decode() calls" if args.sequential else
                                    f"pipeline over batches: entropy stage of batch n+1 on its own stream || synthesis+UNet+VAE "
                                    f"of {args.s_streams} batches on {args.s_streams} streams"},
