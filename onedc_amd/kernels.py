@@ -46,6 +46,7 @@ SIGNATURES = {
     "onedc_conv_gemm": (_I, [C.POINTER(ConvParams), _P]),
     "onedc_conv_win_takes": (_I, [C.POINTER(ConvParams)]),
     "onedc_direct_conv": (_I, [C.POINTER(DirectConvParams), _P]),
+    "onedc_conv3x3_few_out": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_dwconv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_dwconv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_gn_chunks": (_I, [_I]),
@@ -300,6 +301,17 @@ def direct_conv(x, w, bias, y, *, K, epi=EPI_LINEAR, slope=0.01, in_scale=1.0):
     p.Cout, p.y_cs, p.y_co, p.K = y.C, y.cs, y.co, K
     p.x_f32, p.out_f32, p.epi, p.slope, p.in_scale = int(x.f32), int(y.f32), epi, slope, in_scale
     _ok(lib().onedc_direct_conv(C.byref(p), stream()), "onedc_direct_conv")
+    return y
+
+
+def conv3x3_few_out(x, w, bias, y, gn=None):
+    """3x3 conv to y.C <= 4 channels; gn = (gamma, beta, eps, silu, ws): GroupNorm (+SiLU) of x applied on load."""
+    ab, silu = None, False
+    if gn is not None:
+        gamma, beta, eps, silu, ws = gn
+        ab = group_norm_ab(x, gamma, beta, eps, ws)
+    _ok(lib().onedc_conv3x3_few_out(x.ptr, w.data_ptr(), _ptr(bias), _ptr(ab), y.ptr, x.B, x.H, x.W, x.C, x.cs, x.co,
+                                    y.C, y.cs, y.co, int(y.f32), int(silu), stream()), "onedc_conv3x3_few_out")
     return y
 
 

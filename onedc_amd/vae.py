@@ -68,5 +68,10 @@ class VAEDecoder:
                 h = r(h, ws)
             if blk["up"] is not None:
                 h = blk["up"](h, up=1, stats=True)
+        if h.H % 16 == 0 and h.W % 16 == 0 and h.C % 32 == 0 and K.USE_GN_FUSION:
+            # conv_norm_out + SiLU + conv_out in one pass over the 128-channel picture-resolution tensor
+            y = new_view(h.B, h.H, h.W, 3, dev, torch.float32)
+            return K.conv3x3_few_out(h, self.conv_out.w, self.conv_out.b, y,
+                                     gn=(self.norm_out.g, self.norm_out.b, self.norm_out.eps, True, ws))
         h = self.norm_out(h, ws, True)
         return self.conv_out(h, out_f32=True)

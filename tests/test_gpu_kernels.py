@@ -726,6 +726,20 @@ def test_conv_win3x3_groupnorm_on_load_race_screen():
             assert torch.equal(got, ref), f"run {it} differs"
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,gn,f32", [(2, 32, 48, 128, 3, True, True), (1, 16, 16, 64, 4, False, False),
+                                                    (3, 48, 16, 32, 1, True, True)])
+def test_conv3x3_few_out(B, H, W, Cin, Cout, gn, f32):
+    """conv_out-style layer (<= 4 output channels, dot2 accumulation), with and without the GroupNorm+SiLU on load,
+    input in a channel slice."""
+    x, w, b = rnd(B, Cin, H, W, seed=271), rnd(Cout, Cin, 3, 3, seed=272, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=273)
+    g, be = 1 + 0.2 * rnd(Cin, seed=274), 0.5 * rnd(Cin, seed=275)
+    xbuf = from_nchw(torch.cat([rnd(B, 32, H, W, seed=276), x], 1).to(DEV))
+    y = new_view(B, H, W, Cout, DEV, torch.float32 if f32 else torch.bfloat16)
+    K.conv3x3_few_out(xbuf.slice(32, Cin), packed(w), b.to(DEV), y, gn=(g.to(DEV), be.to(DEV), 1e-6, True, _WS()) if gn else None)
+    xin = F.silu(F.group_norm(x, 32, g, be, 1e-6)) if gn else x
+    close(y.torch_nchw(), F.conv2d(xin, w, b, padding=1), rms=6e-3, mx=4e-2, what="few-out conv")
+
+
 def test_conv_groupnorm_argument_on_other_kernels():
     """gn= on a layer the window kernel cannot take (1x1): falls back to the separate pass, same result."""
     B, H, W, Cin, Cout = 2, 12, 12, 128, 256
