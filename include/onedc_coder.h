@@ -82,6 +82,13 @@ int onedc_rans_dec_set_stream(onedc_rans_dec *dec, const uint8_t *stream, int64_
 int onedc_rans_dec_decode_stream(onedc_rans_dec *dec, const int16_t *indexes, int64_t n,
                                  int group, int16_t *out);
 
+/* Extension (no reference counterpart): has the decoder consumed its stream EXACTLY -- every byte read, none
+ * missing, state back at the encoder's initial state (1 << 23, rans.cpp:161-187 writes the final state of a coder
+ * that started there)?  ONEDC_OK, or ONEDC_ERR_STREAM when the symbols pulled so far do not account for the stream:
+ * a scale index or symbol decision differed from the encoder's somewhere (or the stream is corrupt).  The reference
+ * has no such check: a desynchronised decode returns a wrong picture silently.  Call after the last decode_stream. */
+int onedc_rans_dec_finished(onedc_rans_dec *dec);
+
 /* Extension (no reference counterpart; the reference is batch=1): decode the
  * next `n` symbols of `batch` independent decoders concurrently on
  * `n_threads` host threads.  indexes/out are [batch][n] contiguous.

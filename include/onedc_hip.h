@@ -84,8 +84,23 @@ typedef struct onedc_conv_params {
     int32_t reserved0;
 } onedc_conv_params;
 int onedc_conv_gemm(const onedc_conv_params *p, void *stream);
-/* 1 if onedc_conv_gemm would run p on the 3x3 window kernel (the one that can fuse the GroupNorm in front, gn_ab) */
+/* 1 if onedc_conv_gemm would run p on the 3x3 window kernel AND that kernel can apply a GroupNorm in front of the conv
+ * while it stages the operand (gn_ab; p->gn_ab itself may still be NULL when asking): same conditions as the launch */
 int onedc_conv_win_takes(const onedc_conv_params *p);
+/* The kernel family onedc_conv_gemm runs p on (the dispatcher's own decision, without launching), or the negative
+ * status it would return.  bench.py labels its per-kernel timings with this. */
+enum {
+    ONEDC_KERNEL_WIN3X3 = 1,       /* conv_win_kernel: 16x16-pixel patches x 128 channels, window staged once per chunk */
+    ONEDC_KERNEL_UPS2X2 = 2,       /* conv_ups_kernel: x2 upsample + 3x3 as four 2x2 phase convolutions */
+    ONEDC_KERNEL_256X256 = 3,      /* conv_gemm256_kernel */
+    ONEDC_KERNEL_128X256 = 4,      /* conv_gemm128x256_kernel */
+    ONEDC_KERNEL_16X256 = 5,       /* conv_gemm_kernel<Tile<16,256>> */
+    ONEDC_KERNEL_64X128 = 6,       /* conv_gemm_kernel<Tile<64,128>> */
+    ONEDC_KERNEL_128X128 = 7,      /* conv_gemm_kernel<Tile<128,128>> */
+    ONEDC_KERNEL_F32_128X128 = 8   /* conv_gemm_kernel<Tile<128,128>, f32> (exact-f32 path) */
+};
+int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
+const char *onedc_conv_kernel_name(int kernel_id);
 
 /* Small-channel direct convolution (Cin < 64: VAE conv_in / post_quant_conv, HyperDecoder.feat_in
  * codec_module.py:149-152).  w: f32 [Cout][KH][KW][Cin]; x bf16 or f32 (x_f32). */

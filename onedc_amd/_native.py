@@ -62,6 +62,7 @@ def coder():
         "onedc_rans_dec_empty_cdf_buffer": (_I, [_P]),
         "onedc_rans_dec_set_stream": (_I, [_P, _P, _L]),
         "onedc_rans_dec_decode_stream": (_I, [_P, _P, _L, _I, _P]),
+        "onedc_rans_dec_finished": (_I, [_P]),
         "onedc_rans_dec_decode_batch": (_I, [_P, _I, _P, _L, _I, _P, _I, _P]),
         "onedc_rans_enc_encode_batch": (_I, [_P, _I, _P, _P, _L, _I, _I]),
         "onedc_pmf_to_quantized_cdf": (_I, [_P, _I, _I, _P]),
@@ -87,7 +88,7 @@ CODER_SYMBOLS = [
     "onedc_rans_enc_encode_with_indexes", "onedc_rans_enc_flush", "onedc_rans_enc_stream_size",
     "onedc_rans_enc_get_stream", "onedc_rans_dec_create", "onedc_rans_dec_destroy",
     "onedc_rans_dec_add_cdf", "onedc_rans_dec_empty_cdf_buffer", "onedc_rans_dec_set_stream",
-    "onedc_rans_dec_decode_stream", "onedc_rans_dec_decode_batch", "onedc_rans_enc_encode_batch",
+    "onedc_rans_dec_decode_stream", "onedc_rans_dec_finished", "onedc_rans_dec_decode_batch", "onedc_rans_enc_encode_batch",
     "onedc_pmf_to_quantized_cdf", "onedc_container_parse", "onedc_container_write",
     "onedc_pack_indices", "onedc_unpack_indices", "onedc_coder_version",
 ]

@@ -52,13 +52,17 @@ def build_hip(force=False, extra_flags=()):
     if not srcs:
         raise RuntimeError("no HIP sources found")
     if force or _stale(_native.HIP_SO, deps):
-        objs = []
+        objs, jobs = [], []
         for s in srcs:
             o = s[:-4] + ".o"
             if force or _stale(o, [s] + [d for d in deps if d.endswith(".h")]):
-                _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-                      "-Wno-unused-result", *FILE_FLAGS.get(os.path.basename(s), ()), *extra_flags, "-o", o, s])
+                jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+                             "-Wno-unused-result", *FILE_FLAGS.get(os.path.basename(s), ()), *extra_flags, "-o", o, s])
             objs.append(o)
+        if jobs:          # one hipcc per file, a few at a time (each is single-threaded and needs ~1-2 GB)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, min(6, (os.cpu_count() or 2) - 1)))) as pool:
+                list(pool.map(_run, jobs))
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _native.HIP_SO, *objs])
     return _native.HIP_SO
 

@@ -24,6 +24,20 @@ from .kernels import View, new_view
 from .layers import (Conv, DepthConvBlock4, ResidualBlockUpsample, VQAttnBlock, VQResnetBlock, Workspace)
 
 
+class StreamDesyncError(RuntimeError):
+    """The y stream of one or more pictures was not consumed exactly by the four rANS hops: somewhere a scale index
+    (build_indexes truncation, reference entropy_models.py:355-362) or an earlier symbol differed from the ENCODER's.
+    From the first such position on the decoded symbols are garbage, so no picture is returned.  Typical cause: the
+    stream was written by a producer whose prior networks round differently (reference on another device or under
+    bf16 autocast -- see `IntraNoAR.prior_f32` and INTEGRATION.md section 4), or the file is corrupt.
+    `.images` lists the offending batch positions."""
+
+    def __init__(self, images):
+        self.images = list(images)
+        super().__init__(f"rANS desynchronisation: the y stream of picture(s) {self.images} of the batch was not consumed "
+                         "exactly (scale-index or symbol decisions differ from the encoder's, or the stream is corrupt)")
+
+
 class HyperDecoder:
     def __init__(self, sd, device, p="hyper_dec", f32=False):
         self.f32 = f32
@@ -154,6 +168,10 @@ class IntraNoAR:
         self.ds = 64
         self.cond_ds = 8
         self.debug = False
+        # after the fourth hop every decoder must stand on the encoder's initial state with all bytes consumed
+        # (onedc_rans_dec_finished); False restores the reference's behaviour: a desynchronised stream decodes to a
+        # wrong picture without any error
+        self.check_stream_end = True
         self.ws = Workspace(device)
         self.host_threads = host_threads or min(16, os.cpu_count() or 1)
         self.gaussian_encoder = GaussianEncoder()
@@ -229,9 +247,16 @@ class IntraNoAR:
             K.prior_indexes(params, idx_dev, B, H, W, N, k)
             idx_host.copy_(idx_dev.view(B, n), non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            sym_host.numpy()[...] = rans.decode_batch(decoders, idx_host.numpy(), 0, self.host_threads)
+            try:
+                sym_host.numpy()[...] = rans.decode_batch(decoders, idx_host.numpy(), 0, self.host_threads)
+            except rans.RansStreamError as e:       # a stream ran dry in hop k: the same desynchronisation, seen early
+                raise StreamDesyncError([b for b, st in enumerate(e.status) if st != 0]) from e
             sym_dev.view(B, n).copy_(sym_host, non_blocking=True)
             K.prior_update_dec(params, sym_dev, y_hat, k)
+        if self.check_stream_end:
+            bad = [b for b, d in enumerate(decoders) if not d.finished()]
+            if bad:
+                raise StreamDesyncError(bad)
         return y_hat, z_semantic
 
     def _pinned(self, B, n):

@@ -585,12 +585,8 @@ extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, vo
     hipLaunchKernelGGL((flash_attn_kernel<dq, dv, ones, pre>), grid, block, 0, st, (const bf16_t *)q,          \
                        (const bf16_t *)k, (const bf16_t *)vt, (bf16_t *)o, H, Nq, Nk, Nk_pad, c, dreal)
     if (DQ == 64 && DV == 48 && Nk >= 64) {
-        static bool configured = false;
-        if (!configured) {
-            (void)hipFuncSetAttribute((const void *)flash_attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      FA64_NST * FA64_STAGE);
-            configured = true;
-        }
+        static OnedcLdsAttrOnce once;
+        once.ensure({{(const void *)flash_attn64_kernel, FA64_NST * FA64_STAGE}});
         hipLaunchKernelGGL(flash_attn64_kernel, dim3(((Nq + 255) / 256) * H * B), block, FA64_NST * FA64_STAGE, st,
                            (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)vt, (bf16_t *)o, H, Nq, Nk, Nk_pad, c,
                            40);

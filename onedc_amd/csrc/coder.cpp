@@ -42,8 +42,16 @@ struct TableGroup {
     int load(const int32_t *cdfs, int n, int len, const int32_t *sizes, const int32_t *offsets,
              bool with_lut) {
         if (!cdfs || !sizes || !offsets || n <= 0 || len < 2) return ONEDC_ERR_ARG;
-        for (int t = 0; t < n; ++t)
+        for (int t = 0; t < n; ++t) {
             if (sizes[t] < 2 || sizes[t] > len) return ONEDC_ERR_ARG;
+            // a usable row starts at 0, rises strictly (every symbol has a non-zero frequency: the encoder divides by
+            // it, the decoder's search stops on it) and ends at 2^16 -- otherwise `while (c[s + 1] <= cum) ++s` below
+            // could walk past the row on input nobody validated
+            const int32_t *c = cdfs + (size_t)t * len;
+            if (c[0] != 0 || c[sizes[t] - 1] != (int32_t)(1u << kProbBits)) return ONEDC_ERR_ARG;
+            for (int k = 0; k + 1 < sizes[t]; ++k)
+                if (c[k] >= c[k + 1]) return ONEDC_ERR_ARG;
+        }
         n_tables = n;
         row_len = len;
         cdf.assign(cdfs, cdfs + (size_t)n * len);
@@ -150,6 +158,7 @@ struct DecPart {
     uint32_t x = 0;
     bool ready = false;
     bool overrun = false;
+    bool malformed = false;   // an escape announced more bypass digits than an int16 symbol can need
 
     inline uint32_t next_byte() {
         if (pos < bytes.size()) return bytes[pos++];
@@ -161,6 +170,7 @@ struct DecPart {
         bytes.assign(p, p + n);
         pos = 0;
         overrun = false;
+        malformed = false;
         x = next_byte();
         x |= next_byte() << 8;
         x |= next_byte() << 16;
@@ -193,9 +203,16 @@ struct DecPart {
             if (v == escape) {
                 uint32_t d = raw_bits();
                 int32_t digits = (int32_t)d;
-                while (d == kBypassMax) {
+                while (d == kBypassMax && digits <= 16) {
                     d = raw_bits();
                     digits += (int32_t)d;
+                }
+                // int16 symbols need at most 9 two-bit digits; 16 digits fill the 32-bit word (a larger count would
+                // shift by >= 32: undefined) -- anything beyond is a corrupt or desynchronised stream
+                if (digits > 16) {
+                    malformed = true;
+                    for (int64_t r = i; r < n; ++r) out[r] = 0;
+                    return;
                 }
                 uint32_t raw = 0;
                 for (int32_t k = 0; k < digits; ++k) raw |= raw_bits() << (k * kBypassBits);
@@ -403,9 +420,21 @@ int onedc_rans_dec_decode_stream(onedc_rans_dec *dec, const int16_t *indexes, in
     for (int p = 0; p < np; ++p) {
         const int64_t cnt = p < np - 1 ? each : n - each * (np - 1);
         dec->parts[p].pull(g, indexes + p * each, cnt, out + p * each);
-        overrun |= dec->parts[p].overrun;
+        overrun |= dec->parts[p].overrun | dec->parts[p].malformed;
     }
     return overrun ? ONEDC_ERR_STREAM : ONEDC_OK;
+}
+
+int onedc_rans_dec_finished(onedc_rans_dec *dec) {
+    if (!dec) return ONEDC_ERR_ARG;
+    for (const DecPart &part : dec->parts) {
+        if (!part.ready) return ONEDC_ERR_STATE;
+        // the decoder walks the encoder's states backwards: after the last symbol it stands on the encoder's initial
+        // state with every byte consumed.  Anything else means some (index, symbol) decision differed from the encoder's.
+        if (part.overrun || part.malformed || part.pos != part.bytes.size() || part.x != kStateLow)
+            return ONEDC_ERR_STREAM;
+    }
+    return ONEDC_OK;
 }
 
 int onedc_rans_dec_decode_batch(onedc_rans_dec *const *decs, int batch, const int16_t *indexes,

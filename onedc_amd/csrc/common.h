@@ -50,3 +50,21 @@ __device__ __forceinline__ float gelu_f(float v) {
 }
 
 static inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel and launches come from several host
+// threads (DecodePipeline): one bit per device ordinal in an atomic mask, set after the (idempotent) attribute calls.
+#include <atomic>
+#include <initializer_list>
+#include <utility>
+struct OnedcLdsAttrOnce {
+    std::atomic<uint64_t> done[4] = {};
+    void ensure(std::initializer_list<std::pair<const void *, int>> kernels) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        std::atomic<uint64_t> &word = done[(dev >> 6) & 3];
+        if (word.load(std::memory_order_acquire) & bit) return;
+        for (const auto &k : kernels) (void)hipFuncSetAttribute(k.first, hipFuncAttributeMaxDynamicSharedMemorySize, k.second);
+        word.fetch_or(bit, std::memory_order_release);
+    }
+};

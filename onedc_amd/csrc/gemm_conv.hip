@@ -222,12 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
 
 template <class T, bool F32 = false>
 int launch(const onedc_conv_params &p, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)conv_gemm_kernel<T, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * T::BUF);
-        configured = true;
-    }
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_gemm_kernel<T, F32>, 2 * T::BUF}});
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
     if (M64 > 0x7fffffff) return -1;
     const int M = (int)M64;
@@ -246,12 +242,14 @@ int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st);      
 int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st);  // gemm_conv256.hip
 bool onedc_conv_win_ok(const onedc_conv_params &p);                             // gemm_conv_win.hip
 int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
+bool onedc_conv_win_gn_ok(const onedc_conv_params &p);                          // gn_ab (if set) can be honoured
 bool onedc_conv_ups_ok(const onedc_conv_params &p);                             // gemm_conv_ups.hip
 int onedc_conv_ups_launch(const onedc_conv_params &p, hipStream_t st);
 
-extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
-    if (!pp) return -1;
-    onedc_conv_params p = *pp;
+// Which kernel family a launch goes to.  ONE function decides (onedc_conv_gemm launches what it returns, and
+// onedc_conv_gemm_kernel_id reports it to callers such as bench.py), so the report cannot drift from the dispatch.
+//   < 0: the parameters are rejected with that status
+static int conv_validate(onedc_conv_params &p) {
     // 2-D pixel tiles for the 8-wave kernels (conv_common.h: ConvPatch) are OFF: they were speed-neutral, and they
     // regroup the pixels of a 64-pixel statistics block, so the GroupNorm partial sums of an 8-wave launch would
     // round differently from a 4-wave launch of the same layer -- and which kernel runs depends on the batch size.
@@ -275,23 +273,29 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     if (p.stats && (p.pixel_shuffle || ((p.OH * p.OW) & 63) || (p.y_co & 3) || (p.y_cs & 3) ||
                     ((glu ? p.Cout / 2 : p.Cout) & 3) || p.batch > 1))
         return -10;
-    hipStream_t st = as_stream(stream);
+    return 0;
+}
+
+// the window kernel takes the layer (shape only, never the batch size: its k order is (chunk, tap), so its sums round
+// differently from the other kernels, and a picture must decode to the same bits alone and inside a batch)
+static bool conv_win_wanted(const onedc_conv_params &p) {
+    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
+    const int rows128w = (p.Cout + 127) / 128 * 128;
+    return (p.tile == 0 || p.tile == 130) && p.up != 2 && !p.in_f32 && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) &&
+           rows128w * 5 <= p.Cout * 6;
+}
+
+static int conv_choose(const onedc_conv_params &p) {
+    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     // up == 2: x2 upsample + 3x3 decomposed into four 2x2 phase convolutions; w is the phase-packed matrix
-    if (p.up == 2) return onedc_conv_ups_ok(p) ? onedc_conv_ups_launch(p, st) : -12;
-    if (p.in_f32) return launch<Tile<128, 128, 2, 2>, true>(p, st);
+    if (p.up == 2) return onedc_conv_ups_ok(p) ? ONEDC_KERNEL_UPS2X2 : -12;
+    if (p.in_f32) return ONEDC_KERNEL_F32_128X128;
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
     // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per 64-channel chunk):
-    // 5-27 % faster than the 128x256 / 256x256 kernels on every 3x3 layer it can take (tools/bench_conv.py).  The
-    // choice depends on the layer's shape only, never on the batch: its k order is (chunk, tap), so its sums round
-    // differently from the other kernels, and a picture must decode to the same bits alone and inside a batch.
-    {
-        const int rows128w = (p.Cout + 127) / 128 * 128;
-        if ((p.tile == 0 || p.tile == 130) && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) &&
-            rows128w * 5 <= p.Cout * 6)
-            return onedc_conv_win_launch(p, st);
-        if (p.tile == 130) return -11;
-        if (p.gn_ab) return -13;                   // only the window kernel normalises on load
-    }
+    // 5-27 % faster than the 128x256 / 256x256 kernels on every 3x3 layer it can take (tools/bench_conv.py)
+    if (conv_win_wanted(p)) return onedc_conv_win_gn_ok(p) ? ONEDC_KERNEL_WIN3X3 : -13;
+    if (p.tile == 130) return -11;
+    if (p.gn_ab) return -13;                       // only the window kernel normalises on load
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
     // short K (< 16 K-tiles: 1x1 layers up to 960 channels): the 4-wave kernels win, two workgroups per CU hide each
@@ -299,27 +303,71 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);
     if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 16) || p.tile == 256) &&
         !(p.stats && p.stats_gran == 2))           // the 256x256 kernel only leaves quad statistics
-        return onedc_conv_gemm256_launch(p, st);
+        return ONEDC_KERNEL_256X256;
     // 128 x 256 tiles (8 waves, 3-deep LDS ring): channel counts that are whole 128-row tiles or waste < 20 %
     const int rows128 = (p.Cout + 127) / 128 * 128;
     const int64_t blocks128 = (rows128 / 128) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
     if (p.tile != 128 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
         ((blocks128 >= 160 && ktiles >= 16) || p.tile == 129))
-        return onedc_conv_gemm128x256_launch(p, st);
-    if (p.Cout <= 16 && !glu) return launch<Tile<16, 256, 1, 4>>(p, st);
+        return ONEDC_KERNEL_128X256;
+    if (p.Cout <= 16 && !glu) return ONEDC_KERNEL_16X256;
     // 64-row tiles: channel counts that leave <= 64 rows in the last 128-row tile, and grids of fewer than 256
     // 128x128 tiles (the 12x12 maps of the UNet: 180 tiles for 256 CUs)
     const int64_t blocks4w = (rows128 / 128) * ((M64 + 127) / 128) * (p.batch > 1 ? p.batch : 1);
     if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))
-        return launch<Tile<64, 128, 2, 2>>(p, st);
-    return launch<Tile<128, 128, 2, 2>>(p, st);
+        return ONEDC_KERNEL_64X128;
+    return ONEDC_KERNEL_128X128;
 }
 
+extern "C" int onedc_conv_gemm_kernel_id(const onedc_conv_params *pp) {
+    if (!pp) return -1;
+    onedc_conv_params p = *pp;
+    const int rc = conv_validate(p);
+    return rc < 0 ? rc : conv_choose(p);
+}
+
+extern "C" const char *onedc_conv_kernel_name(int id) {
+    switch (id) {
+        case ONEDC_KERNEL_WIN3X3: return "win3x3";
+        case ONEDC_KERNEL_UPS2X2: return "ups2x2";
+        case ONEDC_KERNEL_256X256: return "256x256";
+        case ONEDC_KERNEL_128X256: return "128x256";
+        case ONEDC_KERNEL_16X256: return "16x256";
+        case ONEDC_KERNEL_64X128: return "64x128";
+        case ONEDC_KERNEL_128X128: return "128x128";
+        case ONEDC_KERNEL_F32_128X128: return "f32_128x128";
+        default: return "?";
+    }
+}
+
+extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
+    if (!pp) return -1;
+    onedc_conv_params p = *pp;
+    const int rc = conv_validate(p);
+    if (rc < 0) return rc;
+    hipStream_t st = as_stream(stream);
+    const int id = conv_choose(p);
+    switch (id) {
+        case ONEDC_KERNEL_WIN3X3: return onedc_conv_win_launch(p, st);
+        case ONEDC_KERNEL_UPS2X2: return onedc_conv_ups_launch(p, st);
+        case ONEDC_KERNEL_256X256: return onedc_conv_gemm256_launch(p, st);
+        case ONEDC_KERNEL_128X256: return onedc_conv_gemm128x256_launch(p, st);
+        case ONEDC_KERNEL_16X256: return launch<Tile<16, 256, 1, 4>>(p, st);
+        case ONEDC_KERNEL_64X128: return launch<Tile<64, 128, 2, 2>>(p, st);
+        case ONEDC_KERNEL_128X128: return launch<Tile<128, 128, 2, 2>>(p, st);
+        case ONEDC_KERNEL_F32_128X128: return launch<Tile<128, 128, 2, 2>, true>(p, st);
+        default: return id < 0 ? id : -14;
+    }
+}
+
+// Would the window kernel take this layer INCLUDING a GroupNorm-on-load request (p.gn_ab may still be null: the caller
+// asks before it computes the (a, b) pairs)?  False = use the separate scale/shift pass.
 extern "C" int onedc_conv_win_takes(const onedc_conv_params *pp) {
     if (!pp) return 0;
-    const onedc_conv_params &p = *pp;
-    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
-    const int rows128w = (p.Cout + 127) / 128 * 128;
-    return (p.tile == 0 || p.tile == 130) && p.up != 2 && !p.in_f32 && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) &&
-           rows128w * 5 <= p.Cout * 6;
+    onedc_conv_params p = *pp;
+    if (conv_validate(p) < 0) return 0;
+    if (!conv_win_wanted(p)) return 0;
+    static const float2 dummy = {0.f, 0.f};
+    if (!p.gn_ab) p.gn_ab = (const float *)&dummy; // the question is about the normalising variant
+    return onedc_conv_win_gn_ok(p) ? 1 : 0;
 }

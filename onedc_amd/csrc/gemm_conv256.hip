@@ -584,11 +584,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
 
 // called by onedc_conv_gemm (gemm_conv.hip) for the shapes this tile suits; same contract
 int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        configured = true;
-    }
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_gemm256_kernel, 2 * STAGE}});
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
     if (M64 > 0x7fffffff) return -1;
     const int M = (int)M64;
@@ -602,12 +599,8 @@ int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st) {
 }
 
 int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)conv_gemm128x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  3 * STAGE3);
-        configured = true;
-    }
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_gemm128x256_kernel, 3 * STAGE3}});
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
     if (M64 > 0x7fffffff) return -1;
     const int M = (int)M64;

@@ -298,11 +298,8 @@ bool onedc_conv_ups_ok(const onedc_conv_params &p) {
 }
 
 int onedc_conv_ups_launch(const onedc_conv_params &p, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)conv_ups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UPS_LDS);
-        configured = true;
-    }
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_ups_kernel, UPS_LDS}});
     const int tiles_n = 4 * p.Cout / 128;
     const int tiles_x = p.IW / 16, tiles_y = p.IH / 16;
     const int Ktot = 4 * p.Cin;

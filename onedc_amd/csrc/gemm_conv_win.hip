@@ -20,10 +20,8 @@
 //                next K-tile's weights), raw s_barrier, the two wave rows one barrier apart
 //   fragments    ds_read_b128; 16-byte chunk c of LDS row r sits at c ^ (r & 7): conflict-free for ANY 16
 //                consecutive rows, which is what a tap-shifted window read is
-// STATUS: experimental, correct (tests/test_gpu_kernels.py::test_conv_win3x3_*), not auto-dispatched.
-// Measured on MI355X against the 128x256 kernel (random data, B = 16): 128->128 @768x768 758-818 vs 720-730
-// TFLOP/s, but 875-1010 vs 1080-1290 on the 256 / 512-channel layers: cutting the LDS-DMA bytes did not move
-// the bound of those layers ("what did not work").
+// STATUS: auto-dispatched by onedc_conv_gemm for every 3x3 / stride 1 / pad 1 layer it can take (conv_choose in
+// gemm_conv.hip); tests/test_gpu_kernels.py::test_conv_win3x3_*.  Measured numbers: DESIGN.md section 3 / 4.
 // Same operand layout, accumulation order per output (tap-major inside a chunk, chunks outer -- see note
 // below), epilogues and statistics as the other kernels.
 // Note: the k order is (chunk, tap) here against (tap, chunk) in the generic kernels, so results agree to
@@ -494,21 +492,24 @@ bool onedc_conv_win_ok(const onedc_conv_params &p) {
            (int64_t)p.B * p.IH * p.IW * p.x_cs < (int64_t)1 << 40;
 }
 
+// With gn_ab set the launch needs the plain (not upsampled) variant and room for the image's (a, b) pairs behind the
+// window buffers.  conv_choose / onedc_conv_win_takes ask this BEFORE a caller commits to the fused normalisation.
+bool onedc_conv_win_gn_ok(const onedc_conv_params &p) {
+    return !p.gn_ab || (!p.up && WIN_LDS + (int64_t)p.Cin * 8 <= 160 * 1024);
+}
+
 int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute((const void *)conv_win_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
-        (void)hipFuncSetAttribute((const void *)conv_win_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WIN_LDS);
-        (void)hipFuncSetAttribute((const void *)conv_win_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        configured = true;
-    }
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_win_kernel<false, false>, WIN_LDS},
+                 {(const void *)conv_win_kernel<true, false>, WIN_LDS},
+                 {(const void *)conv_win_kernel<false, true>, 160 * 1024}});
     const int tiles_n = (p.Cout + 127) / 128;
     const int tiles_x = p.OW / 16, tiles_y = p.OH / 16;
     const int Ktot = 9 * p.Cin;
     const int64_t blocks = (int64_t)tiles_n * tiles_x * tiles_y * p.B;
     if (blocks > 0x7fffffff) return -1;
     if (p.gn_ab) {
-        if (p.up || WIN_LDS + p.Cin * 8 > 160 * 1024) return -13;
+        if (!onedc_conv_win_gn_ok(p)) return -13;
         hipLaunchKernelGGL((conv_win_kernel<false, true>), dim3((unsigned)blocks), dim3(512), WIN_LDS + p.Cin * 8, st, p,
                            tiles_n, tiles_x, tiles_y, Ktot);
     } else if (p.up) {

@@ -279,6 +279,28 @@ __global__ void softmax_rows_kernel(const float *__restrict__ s, bf16_t *__restr
     }
 }
 
+// any row length: one wave per row, three sweeps over the row (max, sum of exponentials, write); the second and third
+// sweep hit L2.  Same operations per element as the register-resident kernel above (max-subtracted __expf, one
+// reciprocal), the wave reduction order differs only in how many elements a lane folds before the shuffles.
+__global__ void softmax_rows_any_kernel(const float *__restrict__ s, bf16_t *__restrict__ p, int64_t rows, int n,
+                                        int n_pad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *sr = s + row * n;
+    float mx = -3.0e38f;
+    for (int c = lane; c < n; c += 64) mx = fmaxf(mx, sr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int c = lane; c < n; c += 64) sum += __expf(sr[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+    bf16_t *pr = p + row * n_pad;
+    for (int c = lane; c < n_pad; c += 64) pr[c] = c < n ? f2bf(__expf(sr[c] - mx) * inv) : (bf16_t)0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,9 +369,12 @@ int onedc_layernorm(const void *x, const float *gamma, const float *beta, void *
 }
 
 int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, void *stream) {
-    if (!s || !p || n < 1 || n_pad < n || n_pad > 2560) return -1;
+    if (!s || !p || n < 1 || n_pad < n || rows < 0 || (rows + 3) / 4 > 0x7fffffff) return -1;
     const int blocks = (int)((rows + 3) / 4);
-    if (n_pad <= 256)
+    if (n_pad > 2560)              // larger pictures (1024x1024 and up on the encode side): streaming kernel, any n
+        hipLaunchKernelGGL(softmax_rows_any_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p, rows, n,
+                           n_pad);
+    else if (n_pad <= 256)
         hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
                            rows, n, n_pad);
     else if (n_pad <= 1024)        // the analysis transform's single-head attention at 1/16 resolution (512x512 pictures)

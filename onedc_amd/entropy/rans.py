@@ -16,6 +16,15 @@ _ERR = {-1: "bad argument", -2: "call order violated", -3: "bitstream too short 
         -4: "output buffer too small"}
 
 
+class RansStreamError(RuntimeError):
+    """decode_batch: one or more streams ran out of bytes or carried a malformed escape; `.status` has the per-stream
+    status codes (0 = ok, -3 = ONEDC_ERR_STREAM)."""
+
+    def __init__(self, status):
+        self.status = list(status)
+        super().__init__(f"decode_batch: bitstream too short or malformed (per-stream status {self.status})")
+
+
 def _check(rc, what):
     if rc < 0:
         exc = ValueError if rc == -1 else RuntimeError
@@ -106,6 +115,14 @@ class RansDecoder:
             "decode_stream")
         return out
 
+    def finished(self):
+        """Extension: True when every byte of the stream has been consumed and the coder state is back at the
+        encoder's initial state -- i.e. the (index, symbol) decisions made while decoding account for the stream."""
+        rc = self._lib.onedc_rans_dec_finished(self._h)
+        if rc == -2:
+            raise RuntimeError("finished: call order violated (no stream set)")
+        return rc == 0
+
     def add_cdf(self, cdfs, cdfs_sizes, offsets):
         c, s, o = _cdf_args(cdfs, cdfs_sizes, offsets)
         return _check(self._lib.onedc_rans_dec_add_cdf(
@@ -131,6 +148,8 @@ def decode_batch(decoders, indexes, cdf_group_index, n_threads=8):
     status = (C.c_int * B)()
     rc = lib.onedc_rans_dec_decode_batch(handles, B, idx.ctypes.data, n, int(cdf_group_index),
                                          out.ctypes.data, int(n_threads), status)
+    if rc == -3:
+        raise RansStreamError(status)
     _check(rc, f"decode_batch (per-stream status {list(status)})")
     return out
 

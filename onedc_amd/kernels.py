@@ -45,6 +45,8 @@ class DirectConvParams(C.Structure):
 SIGNATURES = {
     "onedc_conv_gemm": (_I, [C.POINTER(ConvParams), _P]),
     "onedc_conv_win_takes": (_I, [C.POINTER(ConvParams)]),
+    "onedc_conv_gemm_kernel_id": (_I, [C.POINTER(ConvParams)]),
+    "onedc_conv_kernel_name": (C.c_char_p, [_I]),
     "onedc_direct_conv": (_I, [C.POINTER(DirectConvParams), _P]),
     "onedc_conv3x3_few_out": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_dwconv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -207,22 +209,12 @@ PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then 
 PROFILE_EVENT_KW = {}     # {"external": True} when the profiled launches are captured into a HIP graph
 
 
-def conv_tile(cout, glu, blocks_m256=0, tile=0, ktiles=0, win_ok=False):
-    """The tile instantiation onedc_conv_gemm picks (mirrors the dispatcher in gemm_conv.hip)."""
-    rows128 = (cout + 127) // 128 * 128
-    if tile in (0, 130) and win_ok and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6:
-        return "win3x3"
-    if tile != 128 and cout % 256 == 0 and (((cout // 256) * blocks_m256 >= 160 and ktiles >= 16) or tile == 256):
-        return "256x256"
-    rows128 = (cout + 127) // 128 * 128
-    if (tile not in (128, 256) and not (cout <= 16 and not glu) and rows128 * 5 <= cout * 6 and
-            (((rows128 // 128) * blocks_m256 >= 160 and ktiles >= 16) or tile == 129)):
-        return "128x256"
-    if cout <= 16 and not glu:
-        return "16x256"
-    if (cout % 128 != 0 and cout % 128 <= 64) or ((rows128 // 128) * blocks_m256 * 2 < 256 and cout % 64 == 0 and cout >= 128):
-        return "64x128"
-    return "128x128"
+def conv_kernel_name(p):
+    """The kernel family onedc_conv_gemm runs these parameters on: the C dispatcher's own answer."""
+    kid = lib().onedc_conv_gemm_kernel_id(C.byref(p))
+    if kid < 0:
+        raise KernelError(f"onedc_conv_gemm would reject these parameters with status {kid}")
+    return lib().onedc_conv_kernel_name(kid).decode()
 
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
@@ -279,18 +271,13 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     e1.record()
     # executed multiply-adds: the phase-decomposed upsample conv (up == 2) runs 4 taps per output, not 9
     flops = 2.0 * p.B * p.OH * p.OW * p.Cout * ((4 if up == 2 else p.KH * p.KW) * p.Cin) * max(batch, 1) * flop_scale
-    bm = (p.B * p.OH * p.OW + 255) // 256 * max(batch, 1)
-    win_ok = (p.KH == 3 and p.stride == 1 and p.pad == 1 and not pixel_shuffle and batch <= 1 and not p.in_f32 and
-              p.OH % 16 == 0 and p.OW % 16 == 0 and p.Cin % 64 == 0)
     es_in = 4 if p.in_f32 else 2
     es_out = 4 if p.out_f32 else 2
     cout_store = p.Cout // 2 if glu else p.Cout
     nbytes = (p.B * p.IH * p.IW * p.Cin * es_in + p.B * p.OH * p.OW * cout_store * es_out +
               p.Cout * p.KH * p.KW * p.Cin * es_in + (p.B * p.OH * p.OW * cout_store * es_in if res is not None else 0)) \
         * max(batch, 1)
-    PROFILE.append(("ups2x2" if up == 2 else "f32_128x128" if p.in_f32 else
-                    conv_tile(p.Cout, glu, bm, tile, p.KH * p.KW * (p.Cin // 64), win_ok),
-                    flops, e0, e1, float(nbytes)))
+    PROFILE.append((conv_kernel_name(p), flops, e0, e1, float(nbytes)))
     return y
 
 

@@ -222,7 +222,7 @@ class DecodePipeline:
     `s_streams` further worker threads, each with its own stream.  Two S streams are the default: the ~700
     kernels of one stage S form a dependent chain, and between two dependent kernels the GPU idles for the
     dispatch latency (5-10 us, 13 % of a step; a captured HIP graph replays with exactly the same gaps).  A
-    second, independent chain fills them: 152 -> 142 ms per batch of 16 (tools/two_stream_test.py).
+    second, independent chain fills them: 152 -> 142 ms per batch of 16 (tools/two_stream.py).
     Hand-overs are HIP events; results are bit-identical to `decode` (same kernels, same order per batch;
     scratch buffers are per stream, layers.Workspace).  No inter-GPU traffic: one pipeline per process / GPU."""
 

@@ -209,3 +209,102 @@ def test_container_errors():
         utils.decode_i(blob[:-2], 14, 64)                       # payload cut short
     with pytest.raises(ValueError):
         utils.pack_indices([1 << 14], 14)                       # index does not fit 14 bits
+
+
+# ---- decoder hardening + end-of-stream check (no reference counterpart: extensions of the boundary) ----------
+def test_decoder_finished_accepts_exact_decode_and_flags_desync(gaussian_tables):
+    """After the last symbol the decoder must stand on the encoder's initial state with every byte consumed
+    (onedc_rans_dec_finished).  One wrong table index anywhere (what a rounding flip of build_indexes does) must be
+    reported -- by the end check or, earlier, by the stream running dry -- never pass silently."""
+    g = golden("g2_rans_streams.npz")
+    sym, idx, stream = g["escape_skip.symbols"], g["escape_skip.indexes"], g["escape_skip.stream"].tobytes()
+    d = rans.RansDecoder(1)
+    d.add_cdf(*gaussian_tables)
+    d.set_stream(stream)
+    assert not d.finished()                       # nothing decoded yet: bytes left
+    assert np.array_equal(d.decode_stream(idx, 0), np.where(idx < 0, 0, sym))
+    assert d.finished()
+    # the codec's usage: four pushes decoded in four calls, checked once at the end
+    d.set_stream(g["four_calls.stream"].tobytes())
+    q = len(idx) // 4
+    for k in range(4):
+        d.decode_stream(idx[k * q:(k + 1) * q], 0)
+        assert d.finished() == (k == 3)
+    # desynchronise: move one table index by one at several positions
+    flagged = 0
+    for pos in (0, 17, len(idx) // 2, len(idx) - 5):
+        bad = idx.copy()
+        if bad[pos] < 0:
+            continue
+        bad[pos] = bad[pos] + 1 if bad[pos] < 255 else bad[pos] - 1
+        d.set_stream(stream)
+        try:
+            d.decode_stream(bad, 0)
+            flagged += not d.finished()
+        except RuntimeError:
+            flagged += 1
+    assert flagged >= 3
+    # a truncated stream is an error, not garbage
+    d.set_stream(stream[:len(stream) // 2])
+    with pytest.raises(RuntimeError):
+        d.decode_stream(idx, 0)
+    assert not d.finished()
+    with pytest.raises(RuntimeError):
+        rans.RansDecoder(1).finished()            # no stream set
+
+
+def test_add_cdf_rejects_malformed_tables(gaussian_tables):
+    cdf, length, offset = (np.array(a) for a in gaussian_tables)
+    for mutate in ("first", "last", "flat", "descending"):
+        c = cdf.copy()
+        n = int(length[3])
+        if mutate == "first":
+            c[3, 0] = 1
+        elif mutate == "last":
+            c[3, n - 1] = 65535
+        elif mutate == "flat":
+            c[3, 2] = c[3, 1]
+        else:
+            c[3, 2], c[3, 3] = c[3, 3], c[3, 2]
+        for coder in (rans.RansDecoder(1), rans.RansEncoder(False, 1)):
+            with pytest.raises(ValueError):
+                coder.add_cdf(c, length, offset)
+
+
+def test_malformed_escape_is_an_error_not_undefined_behaviour(gaussian_tables):
+    """A stream of 0xff bytes lands on the escape symbol and then announces an endless run of bypass digits: the
+    decoder stops at 16 digits (an int16 needs 9) with ONEDC_ERR_STREAM instead of shifting by >= 32."""
+    d = rans.RansDecoder(1)
+    d.add_cdf(*gaussian_tables)
+    d.set_stream(bytes([0x01]) + bytes([0xff]) * 4096)
+    with pytest.raises(RuntimeError):
+        d.decode_stream(np.full(64, 200, np.int16), 0)
+    assert not d.finished()
+    out = None
+    d.set_stream(bytes([0x01]) + bytes([0xff]) * 4096)
+    with pytest.raises(rans.RansStreamError) as e:
+        out = rans.decode_batch([d], np.full((1, 64), 200, np.int16), 0, 2)
+    assert e.value.status == [-3] and out is None
+
+
+def test_gaussian_table_builder_pieces(gaussian_tables):
+    """The vectorised table builder: half widths are the smallest i in [2, 50] with Phi(i / sigma) > 0.9999, every row
+    is a valid 16-bit CDF of its own length, and pmf_to_cdf pads with zeros."""
+    ge = GaussianEncoder()
+    cdf, length, offset = ge.build_tables()
+    cdf, length, offset = cdf.numpy(), length.numpy(), offset.numpy()
+    assert np.array_equal(cdf, gaussian_tables[0])
+    sig = ge.scale_table.double().numpy()
+    from math import erf, sqrt
+    for t in (0, 40, 128, 200, 255):
+        c = -int(offset[t])
+        phi = lambda x: 0.5 * (1 + erf(x / sig[t] / sqrt(2)))       # noqa: E731
+        assert c == 50 or phi(c) > 0.9999
+        assert c == 2 or phi(c - 1) <= 0.9999 + 1e-6
+        n = int(length[t])
+        assert n == 2 * c + 3 and cdf[t, 0] == 0 and cdf[t, n - 1] == 65536
+        assert (np.diff(cdf[t, :n]) > 0).all() and (cdf[t, n:] == 0).all()
+    idx = ge.build_indexes(ge.scale_table.clone())
+    assert abs(int(idx[0]) - 0) <= 1 and abs(int(idx[255]) - 255) <= 1 and (np.diff(idx.numpy()) >= 0).all()
+    assert int(ge.build_indexes(ge.scale_table[:4] * 0)[0]) == 0           # floored at 1e-5 -> clamped to table 0
+    assert ge.build_indexes(ge.scale_table[:4], skip_thres=1.0).tolist() == [-1, -1, -1, -1]
