@@ -1,7 +1,8 @@
 """ctypes loaders for the two in-tree shared libraries.
 
 * ``libonedc_coder.so``  — host entropy coder, C ABI in ``include/onedc_coder.h``
-* ``libonedc_hip.so``    — gfx950 HIP kernels, C ABI in ``include/onedc_hip.h``
+* ``libonedc_hip.so``    — gfx950 HIP kernels, C ABI in ``include/onedc_hip.h``; 16-bit activations are bf16
+* ``libonedc_hip_f16.so`` — the same sources built with IEEE-half activations (``-DONEDC_ACT_F16``)
 
 There is deliberately no fallback: a missing library raises ``NativeLibraryError``
 so that a product path can never silently run on something else.
@@ -14,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 CODER_SO = os.path.join(CSRC, "libonedc_coder.so")
 # ONEDC_HIP_SO: developer override for A/B experiment builds of the same sources (tools/exp_build.sh)
 HIP_SO = os.environ.get("ONEDC_HIP_SO") or os.path.join(CSRC, "libonedc_hip.so")
+HIP_F16_SO = os.environ.get("ONEDC_HIP_F16_SO") or os.path.join(CSRC, "libonedc_hip_f16.so")
 
 
 class NativeLibraryError(RuntimeError):
@@ -31,6 +33,7 @@ class Container(C.Structure):
 
 _coder = None
 _hip = None
+_hip_f16 = None
 
 _P = C.c_void_p
 _I = C.c_int
@@ -94,14 +97,23 @@ CODER_SYMBOLS = [
 ]
 
 
-def hip():
-    """The HIP kernel library; signatures are attached by ``onedc_amd.kernels``."""
-    global _hip
-    if _hip is not None:
-        return _hip
-    if not os.path.exists(HIP_SO):
+def hip(act="bf16"):
+    """The HIP kernel library for the given 16-bit activation format ("bf16" or "f16"); signatures are attached by
+    ``onedc_amd.kernels``."""
+    global _hip, _hip_f16
+    if act not in ("bf16", "f16"):
+        raise ValueError(f"unknown activation format {act!r}")
+    cached = _hip if act == "bf16" else _hip_f16
+    if cached is not None:
+        return cached
+    path = HIP_SO if act == "bf16" else HIP_F16_SO
+    if not os.path.exists(path):
         raise NativeLibraryError(
-            f"{HIP_SO} is missing: the HIP extension must be built "
+            f"{path} is missing: the HIP extension must be built "
             "(`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
-    _hip = C.CDLL(HIP_SO)
-    return _hip
+    lib = C.CDLL(path)
+    if act == "bf16":
+        _hip = lib
+    else:
+        _hip_f16 = lib
+    return lib

@@ -46,24 +46,31 @@ def hip_sources():
 
 
 def build_hip(force=False, extra_flags=()):
+    """Both builds of the kernel sources: bf16 activations (libonedc_hip.so) and IEEE-half activations
+    (libonedc_hip_f16.so, -DONEDC_ACT_F16; csrc/common.h)."""
     srcs = hip_sources()
-    deps = srcs + glob.glob(os.path.join(_native.CSRC, "*.h")) + \
-        [os.path.join(ROOT, "include", "onedc_hip.h")]
+    headers = glob.glob(os.path.join(_native.CSRC, "*.h")) + [os.path.join(ROOT, "include", "onedc_hip.h")]
     if not srcs:
         raise RuntimeError("no HIP sources found")
-    if force or _stale(_native.HIP_SO, deps):
-        objs, jobs = [], []
+    variants = ((_native.HIP_SO, ".o", ()), (_native.HIP_F16_SO, ".f16.o", ("-DONEDC_ACT_F16",)))
+    jobs, links = [], []
+    for so, suffix, defs in variants:
+        if not (force or _stale(so, srcs + headers)):
+            continue
+        objs = []
         for s in srcs:
-            o = s[:-4] + ".o"
-            if force or _stale(o, [s] + [d for d in deps if d.endswith(".h")]):
-                jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-                             "-Wno-unused-result", *FILE_FLAGS.get(os.path.basename(s), ()), *extra_flags, "-o", o, s])
+            o = s[:-4] + suffix
+            if force or _stale(o, [s] + headers):
+                jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-result",
+                             *FILE_FLAGS.get(os.path.basename(s), ()), *defs, *extra_flags, "-o", o, s])
             objs.append(o)
-        if jobs:          # one hipcc per file, a few at a time (each is single-threaded and needs ~1-2 GB)
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, min(6, (os.cpu_count() or 2) - 1)))) as pool:
-                list(pool.map(_run, jobs))
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _native.HIP_SO, *objs])
+        links.append([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs])
+    if jobs:              # one hipcc per file, a few at a time (each is single-threaded and needs ~1-2 GB)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, min(6, (os.cpu_count() or 2) - 1)))) as pool:
+            list(pool.map(_run, jobs))
+    for cmd in links:
+        _run(cmd)
     return _native.HIP_SO
 
 

@@ -56,7 +56,7 @@ class HyperDecoder:
     def __call__(self, codes):
         """codes: f32 View (B, h, w, 8) -> (params View, z_semantic View (bf16: it feeds the synthesis))."""
         dev = codes.t.device
-        z = new_view(codes.B, codes.H, codes.W, self.n, dev, torch.float32 if self.f32 else torch.bfloat16)
+        z = new_view(codes.B, codes.H, codes.W, self.n, dev, torch.float32 if self.f32 else K.a16())
         K.direct_conv(codes, self.feat_w, self.feat_b, z, K=1, epi=K.EPI_LEAKY, slope=0.01)
         h = self.b4(self.u3(self.b2(self.u1(self.b0(z)))))
         if self.f32:
@@ -153,6 +153,7 @@ class IntraNoAR:
         in exact f32 on the f32 matrix-core path, like the reference's CPU path; False = bf16 MFMA
         like the reference under GPU autocast (SURVEY hard part 2)."""
         self.device = device
+        self.act = K.act()                 # the format the weights below are packed in
         self.N = N = bottleneck_ch
         self.prior_f32 = f32 = bool(prior_f32)
         self.hyper_dec = HyperDecoder(sd, device, f32=f32)
@@ -180,12 +181,14 @@ class IntraNoAR:
         self._pinned_bufs = {}
 
     # reference CompressionModel.update (compression_model.py:169-171)
+    @K.in_own_format
     def update(self, force=False):
         self.entropy_coder = EntropyCoder(False, 1)
         self.gaussian_encoder.update(force=force, entropy_coder=self.entropy_coder)
         self._tables = self.gaussian_encoder.get_cdf_info()
 
     # ------------------------------------------------------------------ prior nets
+    @K.in_own_format
     def _params_from_indices(self, indices):
         """indices: int32 device tensor (B, h, w) -> (fused params f32 View (B,4h,4w,2N), z_semantic)."""
         B, h, w = indices.shape
@@ -196,6 +199,7 @@ class IntraNoAR:
         fused = self.y_prior_fusion[1](fused, out_f32=True)
         return fused, z_semantic
 
+    @K.in_own_format
     def _next_params(self, k, y_hat, common_cat):
         """(scales, means) of step k >= 1 from y_hat_so_far and the reduced common params."""
         if not self.prior_f32:
@@ -205,6 +209,7 @@ class IntraNoAR:
         a = self.y_spatial_prior[1](a)
         return self.y_spatial_prior[2](a, out_f32=True)
 
+    @K.in_own_format
     def _prior_setup(self, fused):
         B, H, W, N = fused.B, fused.H, fused.W, self.N
         if self.prior_f32:
@@ -222,10 +227,13 @@ class IntraNoAR:
         return common_cat, y_hat
 
     # ------------------------------------------------------------------ decode
+    @K.in_own_format
     @torch.no_grad()
-    def decompress(self, streams_y, indices):
+    def decompress(self, streams_y, indices, trace=None):
         """decompress_four_part_prior (compression_model.py:369-407) for a batch.
-        streams_y: list of B rANS byte strings; indices: int32 (B,h,w) device tensor."""
+        streams_y: list of B rANS byte strings; indices: int32 (B,h,w) device tensor.
+        trace: optional list; receives per hop (table indexes, symbols) as int16 arrays [B, 32, H, W] (what crossed
+        the host boundary), also for the hops completed before a StreamDesyncError."""
         B = len(streams_y)
         fused, z_semantic = self._params_from_indices(indices)
         common_cat, y_hat = self._prior_setup(fused)
@@ -251,6 +259,9 @@ class IntraNoAR:
                 sym_host.numpy()[...] = rans.decode_batch(decoders, idx_host.numpy(), 0, self.host_threads)
             except rans.RansStreamError as e:       # a stream ran dry in hop k: the same desynchronisation, seen early
                 raise StreamDesyncError([b for b, st in enumerate(e.status) if st != 0]) from e
+            if trace is not None:
+                trace.append((idx_host.numpy().reshape(B, N // 4, H, W).copy(),
+                              sym_host.numpy().reshape(B, N // 4, H, W).copy()))
             sym_dev.view(B, n).copy_(sym_host, non_blocking=True)
             K.prior_update_dec(params, sym_dev, y_hat, k)
         if self.check_stream_end:
@@ -269,6 +280,7 @@ class IntraNoAR:
             self._pinned_bufs[key] = bufs
         return bufs
 
+    @K.in_own_format
     @torch.no_grad()
     def recon_with_z(self, indices):
         """z-only model: forward_four_part_prior_recon_with_z (compression_model.py:421-465)."""
@@ -281,6 +293,7 @@ class IntraNoAR:
             K.prior_update_zonly(params, y_hat, k)
         return y_hat, z_semantic
 
+    @K.in_own_format
     @torch.no_grad()
     def synthesis(self, y_hat, z_semantic):
         """codec_module.py:452-453: y_semantic = semantic_adaptor(z_semantic); x_hat = dec(y_hat, y_semantic)."""
@@ -290,6 +303,7 @@ class IntraNoAR:
         x_hat = self.dec(y_bf, y_semantic, self.ws)
         return x_hat, y_semantic
 
+    @K.in_own_format
     @torch.no_grad()
     def decode(self, fp=None, stream=None):
         """Reference signature (codec_module.py:356-369), one stream or a list of streams."""
@@ -297,6 +311,7 @@ class IntraNoAR:
         x_hat, y_semantic = self.synthesis(y_hat, z_semantic)
         return x_hat, y_semantic, orig_hw, pad_hw, pad
 
+    @K.in_own_format
     @torch.no_grad()
     def decode_entropy(self, fp=None, stream=None):
         """The entropy stage of `decode`: container parse, z unpack, prior networks and the four host
@@ -319,17 +334,20 @@ class IntraNoAR:
         return y_hat, z_semantic, orig_hw, (pad_h, pad_w), infos[0]["pad_tuple"]
 
     # ------------------------------------------------------------------ encode side
+    @K.in_own_format
     def load_hyper_encoder(self, sd):
         """The hyper analysis weights (`hyper_enc.*` of model_1.safetensors; a decode-only load skips them)."""
         self.hyper_enc = HyperEncoder(sd, self.device, self.N)
         return self
 
+    @K.in_own_format
     def load_encoder(self, sd):
         """The analysis transform (`enc.*` of model_1.safetensors)."""
         from .encoder import CodecEncoder
         self.enc = CodecEncoder(sd, self.device)
         return self
 
+    @K.in_own_format
     @torch.no_grad()
     def encode(self, x, cond, pic_width, pic_height, fp=None):
         """Reference `IntraNoAR.encode` (codec_module.py:326-353) for a batch of equally sized pictures:
@@ -351,6 +369,7 @@ class IntraNoAR:
                         "bpp_file": (len(blob) * 8 / n) if fp else 0.0})
         return blobs, out
 
+    @K.in_own_format
     @torch.no_grad()
     def compress(self, y, sem, heights=None, widths=None):
         """codec_module.py:372-415 after the analysis transform `enc` (SD-VAE encoder + UNet2DModel: not
@@ -367,12 +386,12 @@ class IntraNoAR:
             y = yf.t[:B * H * W * N].view(B, H, W, N)
         else:
             B, H, W, N = y.shape
-            yb = View(torch.empty((B * H * W + K.SLACK_ROWS) * N, dtype=torch.bfloat16, device=self.device), B, H, W, N)
-            yb.t[:B * H * W * N] = y.reshape(-1).to(torch.bfloat16)
+            yb = View(torch.empty((B * H * W + K.SLACK_ROWS) * N, dtype=K.a16(), device=self.device), B, H, W, N)
+            yb.t[:B * H * W * N] = y.reshape(-1).to(K.a16())
             sb = View(torch.empty((sem.shape[0] * sem.shape[1] * sem.shape[2] + K.SLACK_ROWS) * sem.shape[3],
-                                  dtype=torch.bfloat16, device=self.device), sem.shape[0], sem.shape[1], sem.shape[2],
+                                  dtype=K.a16(), device=self.device), sem.shape[0], sem.shape[1], sem.shape[2],
                       sem.shape[3])
-            sb.t[:sem.numel()] = sem.reshape(-1).to(torch.bfloat16)
+            sb.t[:sem.numel()] = sem.reshape(-1).to(K.a16())
         z = self.hyper_enc(yb, sb, self.ws)
         indices = torch.empty(B * z.H * z.W, dtype=torch.int32, device=self.device)
         K.fsq_quantize(z.slice(0, 7), indices)
@@ -381,6 +400,7 @@ class IntraNoAR:
         return blobs, indices, y_hat
 
     # ------------------------------------------------------------------ encode side of the prior
+    @K.in_own_format
     @torch.no_grad()
     def encode_latents(self, indices, y=None, noise_seed=0, heights=None, widths=None):
         """compress_four_part_prior + entropy encode (codec_module.py:372-415 minus the analysis

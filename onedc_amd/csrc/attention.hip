@@ -39,10 +39,10 @@ struct FA {
 };
 
 template <int DQ, int DV, bool ONES_ROW, bool PREFETCH>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restrict__ Q,
-                                                         const bf16_t *__restrict__ K,
-                                                         const bf16_t *__restrict__ VT,
-                                                         bf16_t *__restrict__ O, int H, int Nq, int Nk,
+__global__ __launch_bounds__(256) void flash_attn_kernel(const a16_t *__restrict__ Q,
+                                                         const a16_t *__restrict__ K,
+                                                         const a16_t *__restrict__ VT,
+                                                         a16_t *__restrict__ O, int H, int Nq, int Nk,
                                                          int Nk_pad, float scale_log2e, int d_real) {
     using C = FA<DQ, DV, ONES_ROW>;
     constexpr int NBUF = PREFETCH ? 2 : 1;
@@ -54,16 +54,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
     const int q0 = blockIdx.x * 128 + wave * 32;
 
     // Q fragments (B operand): lane (g, r) holds Q[q0 + 16*t + r][32*ks + 8*g .. +7]
-    bf16x8 qf[2][C::QS];
+    a16x8 qf[2][C::QS];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int qi = q0 + t * 16 + r;
 #pragma unroll
         for (int ks = 0; ks < C::QS; ++ks) {
             if (qi < Nq)
-                qf[t][ks] = *(const bf16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
+                qf[t][ks] = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
             else
-                qf[t][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                qf[t][ks] = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
 
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
         for (int t = 0; t < 2; ++t) o[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
 
-    const bf16_t *Kb = K + (int64_t)b * Nk * (H * DQ) + h * DQ;
-    const bf16_t *Vb = VT + ((int64_t)b * H + h) * DV * Nk_pad;
-    const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    const a16_t *Kb = K + (int64_t)b * Nk * (H * DQ) + h * DQ;
+    const a16_t *Vb = VT + ((int64_t)b * H + h) * DV * Nk_pad;
+    const uint4 ones = make_uint4(ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2);
 
     uint4 kreg[C::NKL], vreg[C::NVL];
     auto load_tile = [&](int k0) {
@@ -128,14 +128,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
         for (int ks = 0; ks < C::QS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const bf16x8 kf = *(const bf16x8 *)(ldsK + (kt * 16 + r) * C::KROW + (ks * 4 + g) * 16);
+                const a16x8 kf = *(const a16x8 *)(ldsK + (kt * 16 + r) * C::KROW + (ks * 4 + g) * 16);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt][t], 0, 0, 0);
+                    s[kt][t] = ONEDC_MFMA16(kf, qf[t][ks], s[kt][t]);
             }
         }
         // ---- online softmax, lane-local per query column
-        bf16x8 pf[2][2];   // [t][step]: P^T B-operand fragments
+        a16x8 pf[2][2];   // [t][step]: P^T B-operand fragments
         float alpha[2];
         bool changed = false;
 #pragma unroll
@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
             // step st covers key tiles 2*st and 2*st+1: element j<4 -> tile 2*st, j>=4 -> tile 2*st+1
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                union { bf16x8 v; uint32_t u[4]; } pk;
-                pk.u[0] = pack_bf2(s[2 * st][t][0], s[2 * st][t][1]);
-                pk.u[1] = pack_bf2(s[2 * st][t][2], s[2 * st][t][3]);
-                pk.u[2] = pack_bf2(s[2 * st + 1][t][0], s[2 * st + 1][t][1]);
-                pk.u[3] = pack_bf2(s[2 * st + 1][t][2], s[2 * st + 1][t][3]);
+                union { a16x8 v; uint32_t u[4]; } pk;
+                pk.u[0] = pack_a2(s[2 * st][t][0], s[2 * st][t][1]);
+                pk.u[1] = pack_a2(s[2 * st][t][2], s[2 * st][t][3]);
+                pk.u[2] = pack_a2(s[2 * st + 1][t][0], s[2 * st + 1][t][1]);
+                pk.u[3] = pack_a2(s[2 * st + 1][t][2], s[2 * st + 1][t][3]);
                 pf[t][st] = pk.v;
             }
         }
@@ -193,12 +193,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const char *vp = ldsV + (d * 16 + r) * C::VROW + (st * 32 + g * 4) * 2;
-                union { bf16x8 v; uint2 h2[2]; } vf;
+                union { a16x8 v; uint2 h2[2]; } vf;
                 vf.h2[0] = *(const uint2 *)vp;
                 vf.h2[1] = *(const uint2 *)(vp + 32);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[t][st], o[d][t], 0, 0, 0);
+                    o[d][t] = ONEDC_MFMA16(vf.v, pf[t][st], o[d][t]);
             }
         }
     };
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
         const float inv = 1.f / l;
         const int qi = q0 + t * 16 + r;
         if (qi >= Nq) continue;
-        bf16_t *op = O + ((int64_t)b * Nq + qi) * (H * DV) + h * DV + g * 4;
+        a16_t *op = O + ((int64_t)b * Nq + qi) * (H * DV) + h * DV + g * 4;
 #pragma unroll
         for (int d = 0; d < C::DT; ++d) {
             float v[4];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
                 v[e] = o[d][t][e] * inv;
                 if (ONES_ROW && d * 16 + g * 4 + e >= d_real) v[e] = 0.f;   // keep the pad channels zero
             }
-            *(uint2 *)(op + d * 16) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            *(uint2 *)(op + d * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         }
     }
 }
@@ -282,18 +282,18 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t *__restric
 //   * 4 waves / 42 KB per workgroup -> two workgroups per CU drift apart, so one SIMD overlaps the exp
 //     phase of one wave with the MFMA phase of another
 __device__ const uint32_t g_ones_page[64] = {
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
-    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
+    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2};
 
 // bf16 {1, 0, 0, 0, 0, 0, 0, 0}: stands in for chunk 5 (the all-padding dims 40..47) of every K row, so
 // that dim 40 of the S product is a free "+ 1 * q[40]" term: q[40] carries -m_run
-__device__ const uint32_t g_kone_page[4] = {0x00003f80u, 0u, 0u, 0u};
+__device__ const uint32_t g_kone_page[4] = {ONEDC_A16_ONE, 0u, 0u, 0u};
 
 constexpr int FA64_K = 64 * 128;                 // K tile bytes
 constexpr int FA64_V = 48 * 128;                 // V^T tile bytes
@@ -310,10 +310,10 @@ __device__ __forceinline__ void fa_glds16(const char *src, char *lds_dst) {
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__restrict__ Q,
-                                                              const bf16_t *__restrict__ K,
-                                                              const bf16_t *__restrict__ VT,
-                                                              bf16_t *__restrict__ O, int H, int Nq, int Nk,
+__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__restrict__ Q,
+                                                              const a16_t *__restrict__ K,
+                                                              const a16_t *__restrict__ VT,
+                                                              a16_t *__restrict__ O, int H, int Nq, int Nk,
                                                               int Nk_pad, float scale_log2e, int d_real) {
     constexpr int DQ = 64, DV = 48, QT = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,18 +330,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
 
     // Q fragments (B operand): lane (g, r) holds Q[q0 + 16 t + r][32 ks + 8 g .. + 7], pre-multiplied by
     // scale * log2(e): the S product then lands in the exp2 domain and needs no per-element multiply
-    bf16x8 qf[QT][2];
+    a16x8 qf[QT][2];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qi = q0 + t * 16 + r;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            union { bf16x8 v; uint32_t u[4]; } f;
-            f.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi < Nq) f.v = *(const bf16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
+            union { a16x8 v; uint32_t u[4]; } f;
+            f.v = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                f.u[e] = pack_bf2(bf2f((bf16_t)(f.u[e] & 0xffff)) * scale_log2e, bf2f((bf16_t)(f.u[e] >> 16)) * scale_log2e);
+                f.u[e] = pack_a2(a2f((a16_t)(f.u[e] & 0xffff)) * scale_log2e, a2f((a16_t)(f.u[e] >> 16)) * scale_log2e);
             qf[t][ks] = f.v;
         }
     }
@@ -414,7 +414,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
     // moved only when a later tile holds a score more than 2^FA64_THR above it; the move is applied AFTER
     // that tile's PV product (O and the riding row sum are scaled together), so no register between the
     // S product and the PV product is ever touched by the rare path.
+#ifdef ONEDC_ACT_F16
+    constexpr float FA64_THR = 8.f;                  // P <= 2^8 per element, its row sums far below 65504
+#else
     constexpr float FA64_THR = 12.f;
+#endif
     auto s_chain = [&](const char *ldsK, f32x4 (&s)[4][QT]) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -424,10 +428,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const bf16x8 kf = *(const bf16x8 *)(ldsK + (kt >> 1) * 4096 + kfo[kt & 1][ks]);
+                const a16x8 kf = *(const a16x8 *)(ldsK + (kt >> 1) * 4096 + kfo[kt & 1][ks]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt][t], 0, 0, 0);
+                    s[kt][t] = ONEDC_MFMA16(kf, qf[t][ks], s[kt][t]);
             }
     };
     auto mask_tail = [&](f32x4 (&s)[4][QT], int k0) {      // element (kt, e) is key k0 + 32 (kt >> 1) + 8 g + 4 (kt & 1) + e
@@ -451,16 +455,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
         }
     };
     // move the reference point of query tile t by the row maximum `mx` (relative to the current one)
-    auto move_ref = [&](int t, float mx, bool scale_o) {
+    auto move_ref = [&](int t, float mx, bool scale_o) -> float {
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = bf2f(f2bf(m_run[t] + mx));              // bf16 grid: it must fit Q'[40] exactly
+        const float m_new = a2f(f2a(m_run[t] + mx));              // bf16 grid: it must fit Q'[40] exactly
         const float inc = m_new - m_run[t];                          // exact (both on the bf16 grid)
         m_run[t] = m_new;
         if (g == 1) {                                                // dim 40 = element 0 of the (ks = 1, g = 1) fragment
-            union { bf16x8 v; uint32_t u[4]; } f;
+            union { a16x8 v; uint32_t u[4]; } f;
             f.v = qf[t][1];
-            f.u[0] = (f.u[0] & 0xffff0000u) | f2bf(-m_new);
+            f.u[0] = (f.u[0] & 0xffff0000u) | f2a(-m_new);
             qf[t][1] = f.v;
         }
         if (scale_o) {
@@ -470,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[d][t][e] *= alpha;
         }
+        return inc;
     };
     auto first_reference = [&](const char *stage, bool mask) {      // dry run of the S product on tile 0
         f32x4 s[4][QT];
@@ -488,7 +493,25 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
         if (MASK) mask_tail(s, k0);
         float tmax[QT];
         lane_max(s, tmax);
-        bf16x8 pf[QT][2];
+#ifdef ONEDC_ACT_F16
+        // IEEE-half P: exp2(s - m_run) must stay below 65504, so a tile that exceeds the reference by more than the
+        // threshold moves it BEFORE the exponentials (O and the riding row sum are rescaled, the scores of this tile are
+        // shifted by the same exact amount); bf16 has f32's exponent range and takes the cheaper order below.
+        {
+            const float wmax0 = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
+            if (__any(wmax0 > FA64_THR)) {          // wave-uniform, rare
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const float inc = move_ref(t, fmaxf(tmax[t], 0.f), true);
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[kt][t][e] -= inc;
+                }
+            }
+        }
+#endif
+        a16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
 #pragma unroll
@@ -497,11 +520,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
                 for (int e = 0; e < 4; ++e) s[kt][t][e] = __builtin_amdgcn_exp2f(s[kt][t][e]);
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                union { bf16x8 v; uint32_t u[4]; } pk;
-                pk.u[0] = pack_bf2(s[2 * st][t][0], s[2 * st][t][1]);
-                pk.u[1] = pack_bf2(s[2 * st][t][2], s[2 * st][t][3]);
-                pk.u[2] = pack_bf2(s[2 * st + 1][t][0], s[2 * st + 1][t][1]);
-                pk.u[3] = pack_bf2(s[2 * st + 1][t][2], s[2 * st + 1][t][3]);
+                union { a16x8 v; uint32_t u[4]; } pk;
+                pk.u[0] = pack_a2(s[2 * st][t][0], s[2 * st][t][1]);
+                pk.u[1] = pack_a2(s[2 * st][t][2], s[2 * st][t][3]);
+                pk.u[2] = pack_a2(s[2 * st + 1][t][0], s[2 * st + 1][t][1]);
+                pk.u[3] = pack_a2(s[2 * st + 1][t][2], s[2 * st + 1][t][3]);
                 pf[t][st] = pk.v;
             }
         }
@@ -510,16 +533,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
         for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const bf16x8 vf = *(const bf16x8 *)(ldsV + d * 2048 + vfo[st]);
+                const a16x8 vf = *(const a16x8 *)(ldsV + d * 2048 + vfo[st]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][st], o[d][t], 0, 0, 0);
+                    o[d][t] = ONEDC_MFMA16(vf, pf[t][st], o[d][t]);
             }
+#ifndef ONEDC_ACT_F16
         const float wmax = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
         if (__any(wmax > FA64_THR)) {               // wave-uniform, rare
 #pragma unroll
-            for (int t = 0; t < QT; ++t) move_ref(t, fmaxf(tmax[t], 0.f), true);
+            for (int t = 0; t < QT; ++t) (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
         }
+#endif
     };
 
     const int ntiles = (Nk + 63) >> 6;
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
         const float inv = 1.f / l;
         const int qi = q0 + t * 16 + r;
         if (qi >= Nq) continue;
-        bf16_t *op = O + ((int64_t)b * Nq + qi) * (H * DV) + h * DV + g * 4;
+        a16_t *op = O + ((int64_t)b * Nq + qi) * (H * DV) + h * DV + g * 4;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float v[4];
@@ -567,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const bf16_t *__re
                 v[e] = o[d][t][e] * inv;
                 if (d * 16 + g * 4 + e >= d_real) v[e] = 0.f;
             }
-            *(uint2 *)(op + d * 16) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            *(uint2 *)(op + d * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         }
     }
 }
@@ -582,13 +607,13 @@ extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, vo
     hipStream_t st = as_stream(stream);
     const float c = scale * 1.4426950408889634f;
 #define FA_LAUNCH(dq, dv, ones, pre, dreal)                                                                   \
-    hipLaunchKernelGGL((flash_attn_kernel<dq, dv, ones, pre>), grid, block, 0, st, (const bf16_t *)q,          \
-                       (const bf16_t *)k, (const bf16_t *)vt, (bf16_t *)o, H, Nq, Nk, Nk_pad, c, dreal)
+    hipLaunchKernelGGL((flash_attn_kernel<dq, dv, ones, pre>), grid, block, 0, st, (const a16_t *)q,          \
+                       (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c, dreal)
     if (DQ == 64 && DV == 48 && Nk >= 64) {
         static OnedcLdsAttrOnce once;
         once.ensure({{(const void *)flash_attn64_kernel, FA64_NST * FA64_STAGE}});
         hipLaunchKernelGGL(flash_attn64_kernel, dim3(((Nq + 255) / 256) * H * B), block, FA64_NST * FA64_STAGE, st,
-                           (const bf16_t *)q, (const bf16_t *)k, (const bf16_t *)vt, (bf16_t *)o, H, Nq, Nk, Nk_pad, c,
+                           (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
                            40);
     } else if (DQ == 64 && DV == 48) FA_LAUNCH(64, 48, true, true, 40);
     else if (DQ == 96 && DV == 80) FA_LAUNCH(96, 80, false, true, 80);

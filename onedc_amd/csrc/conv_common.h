@@ -218,7 +218,7 @@ __device__ __forceinline__ void conv_epi_load_res(const onedc_conv_params &p, co
         if (F32) {
             r.v = *(const uint4 *)((const float *)rb + e.opix * p.r_cs + p.r_co + e.n_out);
         } else {
-            const uint2 t = *(const uint2 *)((const bf16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out);
+            const uint2 t = *(const uint2 *)((const a16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out);
             r.v.x = t.x;
             r.v.y = t.y;
         }
@@ -234,7 +234,7 @@ __device__ __forceinline__ void conv_epi_load_res(const onedc_conv_params &p, co
             r.v = make_uint4(t[0], t[1], t[2], t[3]);
         }
     } else {
-        const bf16_t *rp = (const bf16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out;
+        const a16_t *rp = (const a16_t *)rb + e.opix * p.r_cs + p.r_co + e.n_out;
         if (e.full) {
             const uint2 t = *(const uint2 *)rp;
             r.v.x = t.x;
@@ -294,10 +294,10 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
         v[2] += __uint_as_float(r.v.z);
         v[3] += __uint_as_float(r.v.w);
     } else {
-        v[0] += bf2f((bf16_t)(r.v.x & 0xffff));
-        v[1] += bf2f((bf16_t)(r.v.x >> 16));
-        v[2] += bf2f((bf16_t)(r.v.y & 0xffff));
-        v[3] += bf2f((bf16_t)(r.v.y >> 16));
+        v[0] += a2f((a16_t)(r.v.x & 0xffff));
+        v[1] += a2f((a16_t)(r.v.x >> 16));
+        v[2] += a2f((a16_t)(r.v.y & 0xffff));
+        v[3] += a2f((a16_t)(r.v.y >> 16));
     }
     if (p.stats) {       // explicit order and explicit fma: identical rounding in every kernel that includes this
         // quads:  ssum = (((ssum + v0) + v1) + v2) + v3, ssq likewise with fma
@@ -321,7 +321,7 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
 #endif
     if (M::fast) {
         if (F32) *(float4 *)((float *)yb + yo) = make_float4(v[0], v[1], v[2], v[3]);
-        else *(uint2 *)((bf16_t *)yb + yo) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        else *(uint2 *)((a16_t *)yb + yo) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         return;
     }
     if (p.out_f32) {
@@ -332,11 +332,11 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
             for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = v[k];
         }
     } else {
-        bf16_t *yp = (bf16_t *)yb + yo;
+        a16_t *yp = (a16_t *)yb + yo;
         if (e.full && ((p.y_cs | p.y_co) & 3) == 0) {
-            *(uint2 *)yp = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            *(uint2 *)yp = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         } else {
-            for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = f2bf(v[k]);
+            for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = f2a(v[k]);
         }
     }
 }
@@ -365,10 +365,10 @@ __device__ __forceinline__ uint2 conv_epi_fast_value(const onedc_conv_params &p,
         if (ACT == ONEDC_EPI_LEAKY) v[k] = leaky(v[k], p.slope);
         if (ACT == ONEDC_EPI_SILU) v[k] = silu_f(v[k]);
     }
-    v[0] += bf2f((bf16_t)(res.x & 0xffff));
-    v[1] += bf2f((bf16_t)(res.x >> 16));
-    v[2] += bf2f((bf16_t)(res.y & 0xffff));
-    v[3] += bf2f((bf16_t)(res.y >> 16));
+    v[0] += a2f((a16_t)(res.x & 0xffff));
+    v[1] += a2f((a16_t)(res.x >> 16));
+    v[2] += a2f((a16_t)(res.y & 0xffff));
+    v[3] += a2f((a16_t)(res.y >> 16));
     if (p.stats) {
         const bool pairs = p.stats_gran == 2;
         const float s_lo = (ssum + v[0]) + v[1];
@@ -381,11 +381,11 @@ __device__ __forceinline__ uint2 conv_epi_fast_value(const onedc_conv_params &p,
         ssum_hi = pairs ? s_up : ssum_hi;
         ssq_hi = pairs ? q_up : ssq_hi;
     }
-    return make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    return make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
 }
 template <int ACT>
 __device__ __forceinline__ void conv_epi_fast(const onedc_conv_params &p, const f32x4 &accv, const float4 &bias,
-                                              const uint2 &res, bf16_t *yp, float &ssum, float &ssq, float &ssum_hi,
+                                              const uint2 &res, a16_t *yp, float &ssum, float &ssq, float &ssum_hi,
                                               float &ssq_hi) {
     const uint2 o = conv_epi_fast_value<ACT>(p, accv, bias, res, ssum, ssq, ssum_hi, ssq_hi);
 #ifdef EXP_NOSTORE

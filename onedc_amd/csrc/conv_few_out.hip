@@ -17,14 +17,17 @@ namespace {
 constexpr int FO_ROW = 80;                   // bytes per window pixel in LDS: 64 (32 channels) + 16 padding
 constexpr int FO_WIN = 324 * FO_ROW;         // 25920 B
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+#ifdef ONEDC_ACT_F16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(a16x2_t, a), __builtin_bit_cast(a16x2_t, b), c, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(a16x2_t, a), __builtin_bit_cast(a16x2_t, b), c, false);
+#endif
 }
 
 template <int COUT>
-__global__ __launch_bounds__(256) void conv_few_out_kernel(const bf16_t *__restrict__ x, const uint32_t *__restrict__ w,
+__global__ __launch_bounds__(256) void conv_few_out_kernel(const a16_t *__restrict__ x, const uint32_t *__restrict__ w,
                                                            const float *__restrict__ bias, const float2 *__restrict__ gn_ab,
                                                            void *__restrict__ y, int H, int W, int Cin, int x_cs, int x_co,
                                                            int y_cs, int y_co, int y_f32, int gn_silu, int Ktot) {
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void conv_few_out_kernel(const bf16_t *__restr
     const int img = blockIdx.y;
     const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
     const int nc = Cin >> 5;                        // 32-channel chunks
-    const bf16_t *xi = x + (int64_t)img * H * W * x_cs + x_co;
+    const a16_t *xi = x + (int64_t)img * H * W * x_cs + x_co;
 
     // window staging: unit u = tid + 256 i covers 16 bytes (8 channels) q = u & 3 = tid & 3 of window row u >> 2
     const int q = tid & 3;
@@ -72,13 +75,13 @@ __global__ __launch_bounds__(256) void conv_few_out_kernel(const bf16_t *__restr
             if (gn_ab) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float lo = __builtin_fmaf(bf2f((bf16_t)(o[e] & 0xffff)), a[2 * e], b[2 * e]);
-                    float hi = __builtin_fmaf(bf2f((bf16_t)(o[e] >> 16)), a[2 * e + 1], b[2 * e + 1]);
+                    float lo = __builtin_fmaf(a2f((a16_t)(o[e] & 0xffff)), a[2 * e], b[2 * e]);
+                    float hi = __builtin_fmaf(a2f((a16_t)(o[e] >> 16)), a[2 * e + 1], b[2 * e + 1]);
                     if (gn_silu) {
                         lo = silu_f(lo);
                         hi = silu_f(hi);
                     }
-                    o[e] = goff[i] >= 0 ? pack_bf2(lo, hi) : 0u;   // the conv pads the NORMALISED tensor with zeros
+                    o[e] = goff[i] >= 0 ? pack_a2(lo, hi) : 0u;   // the conv pads the NORMALISED tensor with zeros
                 }
             }
             *(uint4 *)(win[buf] + row * FO_ROW + q * 16) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -129,9 +132,9 @@ __global__ __launch_bounds__(256) void conv_few_out_kernel(const bf16_t *__restr
 #pragma unroll
         for (int o = 0; o < COUT; ++o) yp[o] = acc[o];
     } else {
-        bf16_t *yp = (bf16_t *)y + pix * y_cs + y_co;
+        a16_t *yp = (a16_t *)y + pix * y_cs + y_co;
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) yp[o] = f2bf(acc[o]);
+        for (int o = 0; o < COUT; ++o) yp[o] = f2a(acc[o]);
     }
 }
 
@@ -148,7 +151,7 @@ extern "C" int onedc_conv3x3_few_out(const void *x, const void *w, const float *
     const dim3 grid((H >> 4) * (W >> 4), B);
     const int Ktot = 9 * Cin;
 #define FEW_LAUNCH(N)                                                                                               \
-    hipLaunchKernelGGL(conv_few_out_kernel<N>, grid, dim3(256), 0, as_stream(stream), (const bf16_t *)x,              \
+    hipLaunchKernelGGL(conv_few_out_kernel<N>, grid, dim3(256), 0, as_stream(stream), (const a16_t *)x,              \
                        (const uint32_t *)w, bias, (const float2 *)gn_ab, y, H, W, Cin, x_cs, x_co, y_cs, y_co, y_f32, \
                        gn_silu, Ktot)
     switch (Cout) {

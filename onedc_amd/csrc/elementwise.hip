@@ -21,12 +21,12 @@ __device__ __forceinline__ int active_group(int step, int y, int x) {
 template <bool F32>
 __device__ __forceinline__ float ldp(const void *p, int64_t i) {
     if (F32) return ((const float *)p)[i];
-    return bf2f(((const bf16_t *)p)[i]);
+    return a2f(((const a16_t *)p)[i]);
 }
 template <bool F32>
 __device__ __forceinline__ void stp(void *p, int64_t i, float v) {
     if (F32) ((float *)p)[i] = v;
-    else ((bf16_t *)p)[i] = f2bf(v);
+    else ((a16_t *)p)[i] = f2a(v);
 }
 
 constexpr float LOG_SCALE_MIN = -2.2072749131897207f;           // ln 0.11
@@ -185,7 +185,7 @@ __global__ void nchw_to_nhwc_kernel(const float *x, void *y, int B, int C, int H
 
 // 8x8 / stride 8 patch embedding input (Encoder.pix_emb, codec_module.py:60): NHWC f32 picture (3 channels of a
 // buffer with stride x_cs) -> bf16 [B][H/8][W/8][192], k = (ky, kx, c): the conv is then a 1x1 GEMM
-__global__ void patchify8_kernel(const float *x, int x_cs, bf16_t *y, int B, int H, int W) {
+__global__ void patchify8_kernel(const float *x, int x_cs, a16_t *y, int B, int H, int W) {
     const int h8 = H >> 3, w8 = W >> 3;
     const int64_t total = (int64_t)B * h8 * w8 * 192;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -197,7 +197,7 @@ __global__ void patchify8_kernel(const float *x, int x_cs, bf16_t *y, int B, int
         const int py = (int)(r % h8);
         const int b = (int)(r / h8);
         const int c = k % 3, kx = (k / 3) & 7, ky = k / 24;
-        y[i] = f2bf(x[(((int64_t)b * H + py * 8 + ky) * W + px * 8 + kx) * x_cs + c]);
+        y[i] = f2a(x[(((int64_t)b * H + py * 8 + ky) * W + px * 8 + kx) * x_cs + c]);
     }
 }
 
@@ -216,7 +216,7 @@ __global__ void latent_sample_kernel(const float *moments, const float *noise, f
 }
 
 // region [y0,y0+RH) x [x0,x0+RW) of (B,H,W,C) <-> (B*nwin, wh*ww, C) windows, 8 channels per lane
-__global__ void window_partition_kernel(const bf16_t *x, bf16_t *y, int B, int H, int W, int C, int y0, int x0,
+__global__ void window_partition_kernel(const a16_t *x, a16_t *y, int B, int H, int W, int C, int y0, int x0,
                                         int RH, int RW, int wh, int ww, int reverse) {
     const int CC = C >> 3;
     const int nwx = RW / ww, nwy = RH / wh;
@@ -250,7 +250,7 @@ __global__ void timestep_embedding_kernel(const float *t, float *emb, int n, int
     emb[row * dim + half + k] = sinf(a);
 }
 
-__global__ void add_kernel(const bf16_t *a, const bf16_t *b, bf16_t *y, int64_t n8) {
+__global__ void add_kernel(const a16_t *a, const a16_t *b, a16_t *y, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
          i += (int64_t)gridDim.x * blockDim.x) {
         const uint4 va = ((const uint4 *)a)[i], vb = ((const uint4 *)b)[i];
@@ -259,15 +259,15 @@ __global__ void add_kernel(const bf16_t *a, const bf16_t *b, bf16_t *y, int64_t 
         uint32_t *po = (uint32_t *)&o;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            po[e] = pack_bf2(bf2f((bf16_t)(pa[e] & 0xffff)) + bf2f((bf16_t)(pb[e] & 0xffff)),
-                             bf2f((bf16_t)(pa[e] >> 16)) + bf2f((bf16_t)(pb[e] >> 16)));
+            po[e] = pack_a2(a2f((a16_t)(pa[e] & 0xffff)) + a2f((a16_t)(pb[e] & 0xffff)),
+                             a2f((a16_t)(pa[e] >> 16)) + a2f((a16_t)(pb[e] >> 16)));
         ((uint4 *)y)[i] = o;
     }
 }
 
 // depthwise 3x3 pad 1: 8 channels per lane, weights f32 [9][C]
-__global__ void dwconv3x3_kernel(const bf16_t *__restrict__ x, const float *__restrict__ w,
-                                 const float *__restrict__ bias, bf16_t *__restrict__ y, int B, int H, int W,
+__global__ void dwconv3x3_kernel(const a16_t *__restrict__ x, const float *__restrict__ w,
+                                 const float *__restrict__ bias, a16_t *__restrict__ y, int B, int H, int W,
                                  int C, int x_cs, int x_co, int y_cs, int y_co) {
     const int CC = C >> 3;
     const int64_t total = (int64_t)B * H * W * CC;
@@ -294,14 +294,14 @@ __global__ void dwconv3x3_kernel(const bf16_t *__restrict__ x, const float *__re
                 const float *wp = w + (ky * 3 + kx) * C + cc * 8;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[2 * e] += bf2f((bf16_t)(pv[e] & 0xffff)) * wp[2 * e];
-                    acc[2 * e + 1] += bf2f((bf16_t)(pv[e] >> 16)) * wp[2 * e + 1];
+                    acc[2 * e] += a2f((a16_t)(pv[e] & 0xffff)) * wp[2 * e];
+                    acc[2 * e + 1] += a2f((a16_t)(pv[e] >> 16)) * wp[2 * e + 1];
                 }
             }
         }
         *(uint4 *)(y + pix * y_cs + y_co + cc * 8) =
-            make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]),
-                       pack_bf2(acc[6], acc[7]));
+            make_uint4(pack_a2(acc[0], acc[1]), pack_a2(acc[2], acc[3]), pack_a2(acc[4], acc[5]),
+                       pack_a2(acc[6], acc[7]));
     }
 }
 
@@ -367,7 +367,7 @@ __global__ void direct_conv_kernel(const onedc_direct_conv_params p) {
         if (p.epi == ONEDC_EPI_LEAKY) acc = leaky(acc, p.slope);
         const int64_t yo = pix * p.y_cs + p.y_co + n;
         if (p.out_f32) ((float *)p.y)[yo] = acc;
-        else ((bf16_t *)p.y)[yo] = f2bf(acc);
+        else ((a16_t *)p.y)[yo] = f2a(acc);
     }
 }
 
@@ -384,7 +384,7 @@ inline int grid_for(int64_t n, int per = 256) { return (int)min((int64_t)16384, 
 
 extern "C" {
 
-const char *onedc_hip_version(void) { return "onedc-hip 0.1 (gfx950)"; }
+const char *onedc_hip_version(void) { return "onedc-hip 0.2 (gfx950, " ONEDC_ACT_NAME " activations)"; }
 
 int onedc_fsq_codes(const int32_t *idx, float *codes, int64_t n, void *stream) {
     if (!idx || !codes) return -1;
@@ -476,7 +476,7 @@ int onedc_nchw_to_nhwc(const float *x, void *y, int y_f32, int B, int C, int H, 
 int onedc_patchify8(const float *x, int x_cs, void *y, int B, int H, int W, void *stream) {
     if (!x || !y || (H & 7) || (W & 7) || x_cs < 3) return -1;
     const int64_t n = (int64_t)B * (H / 8) * (W / 8) * 192;
-    LAUNCH(patchify8_kernel, n, x, x_cs, (bf16_t *)y, B, H, W);
+    LAUNCH(patchify8_kernel, n, x, x_cs, (a16_t *)y, B, H, W);
     return 0;
 }
 
@@ -491,7 +491,7 @@ int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, i
     if (!x || !y || wh < 1 || ww < 1 || RH % wh || RW % ww || (C & 7)) return -1;
     if (y0 < 0 || x0 < 0 || y0 + RH > H || x0 + RW > W) return -2;
     const int64_t n = (int64_t)B * RH * RW * (C / 8);
-    LAUNCH(window_partition_kernel, n, (const bf16_t *)x, (bf16_t *)y, B, H, W, C, y0, x0, RH, RW, wh, ww, reverse);
+    LAUNCH(window_partition_kernel, n, (const a16_t *)x, (a16_t *)y, B, H, W, C, y0, x0, RH, RW, wh, ww, reverse);
     return 0;
 }
 
@@ -503,7 +503,7 @@ int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *s
 
 int onedc_add(const void *a, const void *b, void *y, int64_t n, void *stream) {
     if (!a || !b || !y || (n & 7)) return -1;
-    LAUNCH(add_kernel, n / 8, (const bf16_t *)a, (const bf16_t *)b, (bf16_t *)y, n / 8);
+    LAUNCH(add_kernel, n / 8, (const a16_t *)a, (const a16_t *)b, (a16_t *)y, n / 8);
     return 0;
 }
 
@@ -519,7 +519,7 @@ int onedc_dwconv3x3(const void *x, const float *w, const float *bias, void *y, i
                     int x_cs, int x_co, int y_cs, int y_co, void *stream) {
     if (!x || !w || !y || (C & 7) || (x_cs & 7) || (x_co & 7) || (y_cs & 7) || (y_co & 7)) return -1;
     const int64_t n = (int64_t)B * H * W * (C / 8);
-    LAUNCH(dwconv3x3_kernel, n, (const bf16_t *)x, w, bias, (bf16_t *)y, B, H, W, C, x_cs, x_co, y_cs, y_co);
+    LAUNCH(dwconv3x3_kernel, n, (const a16_t *)x, w, bias, (a16_t *)y, B, H, W, C, x_cs, x_co, y_cs, y_co);
     return 0;
 }
 

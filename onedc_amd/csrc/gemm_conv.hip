@@ -149,18 +149,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
                         for (int j = 0; j < T::FJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             } else {
-                bf16x8 a[T::FI], b[T::FJ];
+                a16x8 a[T::FI], b[T::FJ];
 #pragma unroll
                 for (int i = 0; i < T::FI; ++i)
-                    a[i] = *(const bf16x8 *)(cur + a_base + i * 2048 + foff[ks]);
+                    a[i] = *(const a16x8 *)(cur + a_base + i * 2048 + foff[ks]);
 #pragma unroll
                 for (int j = 0; j < T::FJ; ++j)
-                    b[j] = *(const bf16x8 *)(cur + b_base + j * 2048 + foff[ks]);
+                    b[j] = *(const a16x8 *)(cur + b_base + j * 2048 + foff[ks]);
 #pragma unroll
                 for (int i = 0; i < T::FI; ++i)
 #pragma unroll
                     for (int j = 0; j < T::FJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = ONEDC_MFMA16(a[i], b[j], acc[i][j]);
             }
         }
     }

@@ -133,25 +133,25 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     const int a_off = wr * 64 * 128;               // this wave's 64 rows inside A^h
     const int b_off = wc * 32 * 128;               // this wave's 32 rows inside B^h
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    a16x8 fa[4][2], fb0[2][2], fb1[2][2];
 
 #define LOAD_A(stage, h)                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-        fa[i][0] = *(const bf16x8 *)((stage) + ((h) ? OFF_A1 : OFF_A0) + a_off + i * 2048 + fo0); \
-        fa[i][1] = *(const bf16x8 *)((stage) + ((h) ? OFF_A1 : OFF_A0) + a_off + i * 2048 + fo1); \
+        fa[i][0] = *(const a16x8 *)((stage) + ((h) ? OFF_A1 : OFF_A0) + a_off + i * 2048 + fo0); \
+        fa[i][1] = *(const a16x8 *)((stage) + ((h) ? OFF_A1 : OFF_A0) + a_off + i * 2048 + fo1); \
     }
 #define LOAD_B(dstf, stage, h)                                                                     \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
-        dstf[j][0] = *(const bf16x8 *)((stage) + ((h) ? OFF_B1 : OFF_B0) + b_off + j * 2048 + fo0); \
-        dstf[j][1] = *(const bf16x8 *)((stage) + ((h) ? OFF_B1 : OFF_B0) + b_off + j * 2048 + fo1); \
+        dstf[j][0] = *(const a16x8 *)((stage) + ((h) ? OFF_B1 : OFF_B0) + b_off + j * 2048 + fo0); \
+        dstf[j][1] = *(const a16x8 *)((stage) + ((h) ? OFF_B1 : OFF_B0) + b_off + j * 2048 + fo1); \
     }
 #define MFMA_QUAD(a, b, fbx)                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
-                acc[a][i][b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fbx[j][ks],  \
-                                                                          acc[a][i][b][j], 0, 0, 0); \
+                acc[a][i][b][j] = ONEDC_MFMA16(fa[i][ks], fbx[j][ks],  \
+                                                                          acc[a][i][b][j]); \
     __builtin_amdgcn_s_setprio(0);
 
     // ---- prologue: K-tile 0 whole, K-tile 1 minus A^1 (which phase 0 of tile 0 stages) ---------------
@@ -413,24 +413,24 @@ __global__ __launch_bounds__(512, 2) void conv_gemm128x256_kernel(const onedc_co
     const int fo1 = frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
     const int a_off = wr * 64 * 128;
     const int b_off = wc * 32 * 128;
-    bf16x8 fa[4][2], fb[2][2];
+    a16x8 fa[4][2], fb[2][2];
 
 #define LOAD3_A(stage)                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
-        fa[i][0] = *(const bf16x8 *)((stage) + O3_A + a_off + i * 2048 + fo0);    \
-        fa[i][1] = *(const bf16x8 *)((stage) + O3_A + a_off + i * 2048 + fo1);    \
+        fa[i][0] = *(const a16x8 *)((stage) + O3_A + a_off + i * 2048 + fo0);    \
+        fa[i][1] = *(const a16x8 *)((stage) + O3_A + a_off + i * 2048 + fo1);    \
     }
 #define LOAD3_B(stage, h)                                                                      \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
-        fb[j][0] = *(const bf16x8 *)((stage) + ((h) ? O3_B1 : O3_B0) + b_off + j * 2048 + fo0); \
-        fb[j][1] = *(const bf16x8 *)((stage) + ((h) ? O3_B1 : O3_B0) + b_off + j * 2048 + fo1); \
+        fb[j][0] = *(const a16x8 *)((stage) + ((h) ? O3_B1 : O3_B0) + b_off + j * 2048 + fo0); \
+        fb[j][1] = *(const a16x8 *)((stage) + ((h) ? O3_B1 : O3_B0) + b_off + j * 2048 + fo1); \
     }
 #define MFMA3_HALF(b)                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
-                acc[i][b][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][b][j], 0, 0, 0); \
+                acc[i][b][j] = ONEDC_MFMA16(fa[i][ks], fb[j][ks], acc[i][b][j]); \
     __builtin_amdgcn_s_setprio(0);
 
     // ---- prologue: K-tiles 0 and 1 ------------------------------------------------------------------

@@ -111,7 +111,7 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
             const int w = (4 * wc + r + PY) * WW + frow + PX + tx;
             wrd[r][tx] = UPS_NA * UPS_A + w * 128 + ((fq ^ (w & 7)) << 4);
         }
-    bf16x8 fa[4][2], fb[2][2];
+    a16x8 fa[4][2], fb[2][2];
 
     // ---- prologue: window of chunk 0, weights of K-tiles 0 and 1 -------------------------------------------------
 #pragma unroll
@@ -138,14 +138,14 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ro = wrd[j + ty][tx];
-                fb[j][0] = *(const bf16x8 *)(smem + ro);
-                fb[j][1] = *(const bf16x8 *)(smem + (ro ^ 64));
+                fb[j][0] = *(const a16x8 *)(smem + ro);
+                fb[j][1] = *(const a16x8 *)(smem + (ro ^ 64));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i][0] = *(const bf16x8 *)(a_slot0 + i * 2048);
-                fa[i][1] = *(const bf16x8 *)(a_slot1 + i * 2048);
+                fa[i][0] = *(const a16x8 *)(a_slot0 + i * 2048);
+                fa[i][1] = *(const a16x8 *)(a_slot1 + i * 2048);
             }
             __builtin_amdgcn_sched_barrier(0);
             const bool a_next = k < 2 || more;       // weights of K-tile t + 2
@@ -161,7 +161,7 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][0][j], 0, 0, 0);
+                        acc[i][0][j] = ONEDC_MFMA16(fa[i][ks], fb[j][ks], acc[i][0][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -169,8 +169,8 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ro = wrd[2 + j + ty][tx];
-                fb[j][0] = *(const bf16x8 *)(smem + ro);
-                fb[j][1] = *(const bf16x8 *)(smem + (ro ^ 64));
+                fb[j][0] = *(const a16x8 *)(smem + ro);
+                fb[j][1] = *(const a16x8 *)(smem + (ro ^ 64));
             }
             __builtin_amdgcn_sched_barrier(0);
             // window blocks 2 k, 2 k + 1 of the next chunk ride on taps 0..2
@@ -200,7 +200,7 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][1][j], 0, 0, 0);
+                        acc[i][1][j] = ONEDC_MFMA16(fa[i][ks], fb[j][ks], acc[i][1][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -255,7 +255,7 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
             const u32x4_t o = *(const __attribute__((address_space(3))) u32x4_t *)(my + px * 128 + ((c ^ (px & 7)) << 4));
             const int oy = 2 * (y0 + 4 * wc + (px >> 4)) + PY, ox = 2 * (x0 + (px & 15)) + PX;
             const int64_t pix = ((int64_t)img * p.OH + oy) * p.OW + ox;
-            *(u32x4_t *)((bf16_t *)p.y + pix * p.y_cs + p.y_co + nw + c * 8) = o;
+            *(u32x4_t *)((a16_t *)p.y + pix * p.y_cs + p.y_co + nw + c * 8) = o;
         }
     }
     if (p.stats) {       // one statistics row per (image, phase, patch, wave column): 64 output pixels

@@ -133,15 +133,15 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int c = 4 * half + 2 * e;
-            float lo = __builtin_fmaf(bf2f((bf16_t)(w2[e] & 0xffff)), na[c], nb[c]);
-            float hi = __builtin_fmaf(bf2f((bf16_t)(w2[e] >> 16)), na[c + 1], nb[c + 1]);
+            float lo = __builtin_fmaf(a2f((a16_t)(w2[e] & 0xffff)), na[c], nb[c]);
+            float hi = __builtin_fmaf(a2f((a16_t)(w2[e] >> 16)), na[c + 1], nb[c + 1]);
 #ifndef EXP_NORM_NOSILU
             if (p.gn_silu) {
                 lo = silu_f(lo);
                 hi = silu_f(hi);
             }
 #endif
-            o2[e] = off != x_bytes ? pack_bf2(lo, hi) : 0u;
+            o2[e] = off != x_bytes ? pack_a2(lo, hi) : 0u;
         }
         o0 = o2[0];
         o1 = o2[1];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             const int w = UP ? ((4 * wc + r + 1) >> 1) * WW + ((frow + kx + 1) >> 1) : (4 * wc + r) * WW + frow + kx;
             wrd[r][kx] = WIN_NA * WIN_A + w * 128 + ((fq ^ (w & 7)) << 4);
         }
-    bf16x8 fa[4][2], fb[2][2];
+    a16x8 fa[4][2], fb[2][2];
 
     // ---- prologue: window of chunk 0, weights of K-tiles 0 and 1 -------------------------------------------------
     if (NORM) {
@@ -239,14 +239,14 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ro = wrd[j + ky][kx];
-                fb[j][0] = *(const bf16x8 *)(smem + ro);
-                fb[j][1] = *(const bf16x8 *)(smem + (ro ^ 64));
+                fb[j][0] = *(const a16x8 *)(smem + ro);
+                fb[j][1] = *(const a16x8 *)(smem + (ro ^ 64));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i][0] = *(const bf16x8 *)(a_slot0 + i * 2048);
-                fa[i][1] = *(const bf16x8 *)(a_slot1 + i * 2048);
+                fa[i][0] = *(const a16x8 *)(a_slot0 + i * 2048);
+                fa[i][1] = *(const a16x8 *)(a_slot1 + i * 2048);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (NORM && tap >= 3 && tap - 3 < MAXWB) {   // second half of block tap - 3, and its LDS write
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][0][j], 0, 0, 0);
+                        acc[i][0][j] = ONEDC_MFMA16(fa[i][ks], fb[j][ks], acc[i][0][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ro = wrd[2 + j + ky][kx];
-                fb[j][0] = *(const bf16x8 *)(smem + ro);
-                fb[j][1] = *(const bf16x8 *)(smem + (ro ^ 64));
+                fb[j][0] = *(const a16x8 *)(smem + ro);
+                fb[j][1] = *(const a16x8 *)(smem + (ro ^ 64));
             }
             __builtin_amdgcn_sched_barrier(0);
             // DMA issued after the weights of K-tile t + 1: this tap's and the previous tap's window block, and
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[i][1][j], 0, 0, 0);
+                        acc[i][1][j] = ONEDC_MFMA16(fa[i][ks], fb[j][ks], acc[i][1][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         uint2 res[4][4];
 #pragma unroll
         for (int bj = 0; bj < 4; ++bj) {
-            const bf16_t *rp = (const bf16_t *)rb + (pix0 + bj * p.OW) * p.r_cs + p.r_co + nw + fq * 4;
+            const a16_t *rp = (const a16_t *)rb + (pix0 + bj * p.OW) * p.r_cs + p.r_co + nw + fq * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) res[bj][i] = (rb && ok[i]) ? *(const uint2 *)(rp + i * 16) : make_uint2(0u, 0u);
         }
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             constexpr int ACT = decltype(act)::value;
 #pragma unroll
             for (int bj = 0; bj < 4; ++bj) {
-                bf16_t *yp = (bf16_t *)yb + (pix0 + bj * p.OW) * p.y_cs + p.y_co + nw + fq * 4;
+                a16_t *yp = (a16_t *)yb + (pix0 + bj * p.OW) * p.y_cs + p.y_co + nw + fq * 4;
                 const int px = bj * 16 + frow;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                 const int px = it * 8 + (lane >> 3);           // pixel (row 4 wc + (px >> 4), column px & 15) of the patch
                 const u32x4_t o = *(const __attribute__((address_space(3))) u32x4_t *)(my + px * 128 + ((c ^ (px & 7)) << 4));
                 const int64_t pix = ((int64_t)img * p.OH + y0 + 4 * wc + (px >> 4)) * p.OW + x0 + (px & 15);
-                *(u32x4_t *)((bf16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
+                *(u32x4_t *)((a16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
             }
         }
     } else {

@@ -11,18 +11,18 @@ constexpr int GN_GROUPS = 32;
 constexpr int GN_PPC = 1024;  // pixels per partial-sum chunk
 
 __device__ __forceinline__ void unpack8(const uint4 &v, float *f) {
-    f[0] = bf2f((bf16_t)(v.x & 0xffff)); f[1] = bf2f((bf16_t)(v.x >> 16));
-    f[2] = bf2f((bf16_t)(v.y & 0xffff)); f[3] = bf2f((bf16_t)(v.y >> 16));
-    f[4] = bf2f((bf16_t)(v.z & 0xffff)); f[5] = bf2f((bf16_t)(v.z >> 16));
-    f[6] = bf2f((bf16_t)(v.w & 0xffff)); f[7] = bf2f((bf16_t)(v.w >> 16));
+    f[0] = a2f((a16_t)(v.x & 0xffff)); f[1] = a2f((a16_t)(v.x >> 16));
+    f[2] = a2f((a16_t)(v.y & 0xffff)); f[3] = a2f((a16_t)(v.y >> 16));
+    f[4] = a2f((a16_t)(v.z & 0xffff)); f[5] = a2f((a16_t)(v.z >> 16));
+    f[6] = a2f((a16_t)(v.w & 0xffff)); f[7] = a2f((a16_t)(v.w >> 16));
 }
 __device__ __forceinline__ uint4 pack8(const float *f) {
-    return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+    return make_uint4(pack_a2(f[0], f[1]), pack_a2(f[2], f[3]), pack_a2(f[4], f[5]), pack_a2(f[6], f[7]));
 }
 
 // stage 1: block (chunk, b) sums x and x^2 per group over GN_PPC pixels.
 // threads = CC * PL with CC = C/8 channel chunks and PL pixel lanes.
-__global__ void gn_partial_kernel(const bf16_t *__restrict__ x, float *__restrict__ part, int HW, int C,
+__global__ void gn_partial_kernel(const a16_t *__restrict__ x, float *__restrict__ part, int HW, int C,
                                   int cs, int co, int CC, int PL, int nchunk) {
     extern __shared__ float lds[];  // [PL][C][2]
     const int t = threadIdx.x;
@@ -33,7 +33,7 @@ __global__ void gn_partial_kernel(const bf16_t *__restrict__ x, float *__restric
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-    const bf16_t *base = x + ((int64_t)b * HW) * cs + co + cc * 8;
+    const a16_t *base = x + ((int64_t)b * HW) * cs + co + cc * 8;
     for (int p = p0 + pl; p < p1; p += PL) {
         const uint4 v = *(const uint4 *)(base + (int64_t)p * cs);
         float f[8];
@@ -139,8 +139,8 @@ __global__ void gn_from_stats_kernel(const float2 *__restrict__ stats, const flo
 // thread's 8 (a, bb) pairs are loaded once and stay in registers while it walks its pixels, so the
 // loop is one 16-byte load, 8 fma (+ 8 exp / rcp for SiLU) and one 16-byte store, no index division.
 constexpr int SSA_PPC = 256;  // pixels per block
-__global__ void scale_shift_act_kernel(const bf16_t *__restrict__ x, const float2 *__restrict__ ab,
-                                       bf16_t *__restrict__ y, int HW, int C, int CC, int PL, int x_cs, int x_co,
+__global__ void scale_shift_act_kernel(const a16_t *__restrict__ x, const float2 *__restrict__ ab,
+                                       a16_t *__restrict__ y, int HW, int C, int CC, int PL, int x_cs, int x_co,
                                        int y_cs, int y_co, int silu) {
     const int t = threadIdx.x;
     const int cc = t % CC, pl = t / CC;
@@ -157,8 +157,8 @@ __global__ void scale_shift_act_kernel(const bf16_t *__restrict__ x, const float
         a[2 * e + 1] = v.z;
         bb[2 * e + 1] = v.w;
     }
-    const bf16_t *xp = x + ((int64_t)b * HW) * x_cs + x_co + cc * 8;
-    bf16_t *yp = y + ((int64_t)b * HW) * y_cs + y_co + cc * 8;
+    const a16_t *xp = x + ((int64_t)b * HW) * x_cs + x_co + cc * 8;
+    a16_t *yp = y + ((int64_t)b * HW) * y_cs + y_co + cc * 8;
     // four pixels per iteration, all loads issued before the first use: the loop is bound by memory latency
     auto run = [&](auto silu_c) {
         constexpr bool SILU = decltype(silu_c)::value;
@@ -196,8 +196,8 @@ __global__ void scale_shift_act_kernel(const bf16_t *__restrict__ x, const float
 
 // LayerNorm: one wave per row, row cached in registers (C <= 8*64*NCH)
 template <int NCH>
-__global__ void layernorm_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma,
-                                 const float *__restrict__ beta, bf16_t *__restrict__ y, int64_t rows, int C,
+__global__ void layernorm_kernel(const a16_t *__restrict__ x, const float *__restrict__ gamma,
+                                 const float *__restrict__ beta, a16_t *__restrict__ y, int64_t rows, int C,
                                  float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -247,7 +247,7 @@ __global__ void layernorm_kernel(const bf16_t *__restrict__ x, const float *__re
 
 // softmax over f32 rows (n <= 64*NV), bf16 out with zero padding up to n_pad
 template <int NV>
-__global__ void softmax_rows_kernel(const float *__restrict__ s, bf16_t *__restrict__ p, int64_t rows, int n,
+__global__ void softmax_rows_kernel(const float *__restrict__ s, a16_t *__restrict__ p, int64_t rows, int n,
                                     int n_pad) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -275,14 +275,14 @@ __global__ void softmax_rows_kernel(const float *__restrict__ s, bf16_t *__restr
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
-        if (c < n_pad) p[row * n_pad + c] = f2bf(v[i] * inv);
+        if (c < n_pad) p[row * n_pad + c] = f2a(v[i] * inv);
     }
 }
 
 // any row length: one wave per row, three sweeps over the row (max, sum of exponentials, write); the second and third
 // sweep hit L2.  Same operations per element as the register-resident kernel above (max-subtracted __expf, one
 // reciprocal), the wave reduction order differs only in how many elements a lane folds before the shuffles.
-__global__ void softmax_rows_any_kernel(const float *__restrict__ s, bf16_t *__restrict__ p, int64_t rows, int n,
+__global__ void softmax_rows_any_kernel(const float *__restrict__ s, a16_t *__restrict__ p, int64_t rows, int n,
                                         int n_pad) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -297,8 +297,8 @@ __global__ void softmax_rows_any_kernel(const float *__restrict__ s, bf16_t *__r
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float inv = 1.f / sum;
-    bf16_t *pr = p + row * n_pad;
-    for (int c = lane; c < n_pad; c += 64) pr[c] = c < n ? f2bf(__expf(sr[c] - mx) * inv) : (bf16_t)0;
+    a16_t *pr = p + row * n_pad;
+    for (int c = lane; c < n_pad; c += 64) pr[c] = c < n ? f2a(__expf(sr[c] - mx) * inv) : (a16_t)0;
 }
 
 }  // namespace
@@ -318,7 +318,7 @@ int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *
     const int nchunk = onedc_gn_chunks(HW);
     const size_t lds = (size_t)PL * C * 2 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(threads), lds, as_stream(stream),
-                       (const bf16_t *)x, partial, HW, C, x_cs, x_co, CC, PL, nchunk);
+                       (const a16_t *)x, partial, HW, C, x_cs, x_co, CC, PL, nchunk);
     ONEDC_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, as_stream(stream), partial, gamma, beta,
                        (float2 *)ab, HW, C, nchunk, eps);
@@ -345,7 +345,7 @@ int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW
     const int threads = CC * PL;
     if (threads > 1024) return -3;
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3((HW + SSA_PPC - 1) / SSA_PPC, B), dim3(threads), 0,
-                       as_stream(stream), (const bf16_t *)x, (const float2 *)ab, (bf16_t *)y, HW, C, CC, PL, x_cs,
+                       as_stream(stream), (const a16_t *)x, (const float2 *)ab, (a16_t *)y, HW, C, CC, PL, x_cs,
                        x_co, y_cs, y_co, silu);
     ONEDC_LAUNCH_CHECK();
     return 0;
@@ -357,13 +357,13 @@ int onedc_layernorm(const void *x, const float *gamma, const float *beta, void *
     const int blocks = (int)((rows + 3) / 4);
     if (C <= 512)
         hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream),
-                           (const bf16_t *)x, gamma, beta, (bf16_t *)y, rows, C, eps);
+                           (const a16_t *)x, gamma, beta, (a16_t *)y, rows, C, eps);
     else if (C <= 1024)
         hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(stream),
-                           (const bf16_t *)x, gamma, beta, (bf16_t *)y, rows, C, eps);
+                           (const a16_t *)x, gamma, beta, (a16_t *)y, rows, C, eps);
     else
         hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, as_stream(stream),
-                           (const bf16_t *)x, gamma, beta, (bf16_t *)y, rows, C, eps);
+                           (const a16_t *)x, gamma, beta, (a16_t *)y, rows, C, eps);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }
@@ -372,16 +372,16 @@ int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, 
     if (!s || !p || n < 1 || n_pad < n || rows < 0 || (rows + 3) / 4 > 0x7fffffff) return -1;
     const int blocks = (int)((rows + 3) / 4);
     if (n_pad > 2560)              // larger pictures (1024x1024 and up on the encode side): streaming kernel, any n
-        hipLaunchKernelGGL(softmax_rows_any_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p, rows, n,
+        hipLaunchKernelGGL(softmax_rows_any_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), s, (a16_t *)p, rows, n,
                            n_pad);
     else if (n_pad <= 256)
-        hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
+        hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (a16_t *)p,
                            rows, n, n_pad);
     else if (n_pad <= 1024)        // the analysis transform's single-head attention at 1/16 resolution (512x512 pictures)
-        hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
+        hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (a16_t *)p,
                            rows, n, n_pad);
     else                           // ... and 2304 tokens at 768x768
-        hipLaunchKernelGGL(softmax_rows_kernel<40>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (bf16_t *)p,
+        hipLaunchKernelGGL(softmax_rows_kernel<40>, dim3(blocks), dim3(256), 0, as_stream(stream), s, (a16_t *)p,
                            rows, n, n_pad);
     ONEDC_LAUNCH_CHECK();
     return 0;

@@ -37,6 +37,7 @@ class UNet:
     def __init__(self, sd, device, lora_rank=64, lora_alpha=8.0):
         """sd: checkpoint-named state dict of model.safetensors (LoRA tensors still separate)."""
         self.device = device
+        self.act = K.act()                 # the format the weights below are packed in
         if any(".lora_A." in k for k in sd):
             sd = pack.fold_lora(sd, lora_rank, lora_alpha)
         self.ws = Workspace(device)
@@ -84,6 +85,7 @@ class UNet:
             r.set_temb(act)
         self._timestep = t
 
+    @K.in_own_format
     @torch.no_grad()
     def __call__(self, sample, timestep, ctx):
         """sample: View (B,H,W,320) bf16; ctx: View (B,h,w,768) tokens. -> (eps f32 View, reduced f32 View)"""

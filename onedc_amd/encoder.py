@@ -51,6 +51,7 @@ class VAEEncoder:
                 if f"{a}.{old}.{leaf}" in sd:
                     sd[f"{a}.{new}.{leaf}"] = sd.pop(f"{a}.{old}.{leaf}").reshape(512, -1).squeeze(-1)
         self.device, self.attn_patch, self.scaling_factor = device, attn_patch, scaling_factor
+        self.act = K.act()
         self.ws = Workspace(device)
         # conv_in (3x3, 3 -> 128) on the exact-f32 matrix-core path: input channels zero-padded 3 -> 32
         wci = torch.zeros(128, 32, 3, 3)
@@ -74,6 +75,7 @@ class VAEEncoder:
         self.attn_patch = attn_patch
 
     @torch.no_grad()
+    @K.in_own_format
     def encode(self, image, noise=None):
         """image: f32 NHWC View (B,H,W,32) holding the picture in channels 0..2 (3..31 zero) ->
         f32 View (B,H/8,W/8,4): latent_dist.sample() * scaling_factor.  noise: f32 device tensor
@@ -147,7 +149,7 @@ class GroupNormAttention:
         n_pad = (N + 63) // 64 * 64
         hn = self.norm(x, ws, False)
         q, k = self.q(hn), self.k(hn)
-        vt = torch.zeros(B * self.H * self.DV * n_pad, dtype=torch.bfloat16, device=dev)
+        vt = torch.zeros(B * self.H * self.DV * n_pad, dtype=K.a16(), device=dev)
         K.conv_gemm(self.wv, hn.t, None, View(vt, 1, 1, self.H * self.DV, N, n_pad), Cin=self.C, Cout=N, batch=B,
                     x_bs=0, w_bs=N * hn.cs, y_bs=self.H * self.DV * n_pad, flop_scale=self.d / self.DV)
         o = new_view(B, x.H, x.W, self.H * self.DV, dev)
@@ -161,6 +163,7 @@ class AnalysisUNet:
 
     def __init__(self, sd, device, p="enc.unet"):
         self.device, self.ws = device, Workspace(device)
+        self.act = K.act()
         ch = arch.ENC_UNET_CH
         self.conv_in = [OwnResnetBlock(sd, f"{p}.conv_in.{i}", device) for i in range(3)]
         self.conv_in_down = Conv(sd, f"{p}.conv_in.3", device)
@@ -195,6 +198,7 @@ class AnalysisUNet:
             r.set_temb(act)
 
     @torch.no_grad()
+    @K.in_own_format
     def __call__(self, x):
         ws, dev, B = self.ws, self.device, x.B
         h = x
@@ -269,6 +273,7 @@ class CodecEncoder:
 
     def __init__(self, sd, device, p="enc"):
         self.device, self.ws = device, Workspace(device)
+        self.act = K.act()
         self.pix_emb = Conv(sd, f"{p}.pix_emb", device)       # (192, 3, 8, 8) -> [192][ky][kx][c]: a 1x1 GEMM on patches
         self.pix_emb.k = 1
         self.pix_emb.cin = 192
@@ -285,13 +290,14 @@ class CodecEncoder:
         self.t4 = DepthConvBlock4(sd, f"{t}.4", device)
 
     @torch.no_grad()
+    @K.in_own_format
     def __call__(self, image, cond):
         """image: f32 NHWC View (B,H,W,>=3); cond: f32 View (B,H/8,W/8,4) (the VAE latent)."""
         dev, ws = self.device, self.ws
         B, h8, w8 = image.B, image.H // 8, image.W // 8
         patches = new_view(B, h8, w8, 192, dev)
         K.patchify8(image, patches)
-        cat = View(torch.zeros((B * h8 * w8 + K.SLACK_ROWS) * 256, dtype=torch.bfloat16, device=dev), B, h8, w8, 256)
+        cat = View(torch.zeros((B * h8 * w8 + K.SLACK_ROWS) * 256, dtype=K.a16(), device=dev), B, h8, w8, 256)
         self.pix_emb(patches, cat.slice(0, 192))
         K.copy_channels(cond, cat.slice(192, 4))
         x_emb = self.pix_fusion(cat, stats=True)

@@ -25,6 +25,11 @@ import yaml
 def save_image(img, path):
     """torchvision.utils.save_image for one [3,H,W] tensor in [0,1] (x255 + 0.5, clamp, uint8)."""
     from PIL import Image
+    if not bool(torch.isfinite(img).all()):
+        # the only way a decode produces them: an activation left the IEEE-half range (act_dtype "f16", +-65504 after
+        # the VAE's 2^-6 stream scale) -- decode this picture with act_dtype: bf16 in the config instead
+        raise FloatingPointError(f"{path}: the decoded picture has non-finite values (half-precision range exceeded); "
+                                 "set act_dtype: bf16 in the config")
     arr = img.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
     Image.fromarray(arr).save(path)
 

@@ -4,11 +4,58 @@ PyTorch is plumbing here: device memory (`tensor.data_ptr()`), the current HIP s
 nothing else.  Every wrapper launches on torch's current stream and raises on a non-zero status.
 There is no CPU or eager fallback: without the built library `_native.hip()` raises.
 """
+import contextlib
 import ctypes as C
+import os
+import threading
 
 import torch
 
 from . import _native
+
+# ---- 16-bit activation / weight format ------------------------------------------------------------------------------
+# The kernel library exists twice (csrc/common.h): "bf16" and "f16" (IEEE half: 3 more mantissa bits in every stored
+# activation, packed weight and MFMA operand at the same speed; finite range +-65504).  The format is a property of the
+# CALLING CONTEXT (thread-local): layers pack their weights and allocate their outputs in the format that is current when
+# they are built / called, and `lib()` hands out the matching library.
+DEFAULT_ACT = os.environ.get("ONEDC_ACT", "f16")
+_tls = threading.local()
+
+
+def act():
+    return getattr(_tls, "act", None) or DEFAULT_ACT
+
+
+def a16():
+    """torch dtype of 16-bit activations and packed weights in the current format."""
+    return torch.float16 if act() == "f16" else torch.bfloat16
+
+
+def set_act(name):
+    if name not in ("bf16", "f16"):
+        raise ValueError(f"activation format must be 'bf16' or 'f16', not {name!r}")
+    _tls.act = name
+
+
+def in_own_format(method):
+    """Decorator: run a method under the activation format its object was built in (`self.act`)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with act_format(self.act):
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
+@contextlib.contextmanager
+def act_format(name):
+    prev = getattr(_tls, "act", None)
+    set_act(name)
+    try:
+        yield
+    finally:
+        _tls.act = prev
 
 EPI_LINEAR, EPI_LEAKY, EPI_SILU, EPI_GLU_LEAKY, EPI_GEGLU = range(5)
 
@@ -77,19 +124,22 @@ SIGNATURES = {
 }
 HIP_SYMBOLS = list(SIGNATURES)
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        l = _native.hip()
+def lib(fmt=None):
+    fmt = fmt or act()
+    l = _libs.get(fmt)
+    if l is None:
+        l = _native.hip(fmt)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = l
-    return _lib
+        if fmt.encode() not in l.onedc_hip_version():
+            raise _native.NativeLibraryError(f"{fmt} kernel library reports {l.onedc_hip_version()!r}")
+        _libs[fmt] = l
+    return l
 
 
 class KernelError(RuntimeError):
@@ -187,14 +237,17 @@ class View:
 SLACK_ROWS = 128   # a GEMM may read (never use) up to one tile of rows past its "weight" operand
 
 
-def new_view(B, H, W, C, device, dtype=torch.bfloat16, cs=None, stats=False):
+def new_view(B, H, W, C, device, dtype=None, cs=None, stats=False):
+    """dtype None: 16-bit activations in the current format (a16())."""
     cs = C if cs is None else cs
+    dtype = dtype or a16()
     v = View(torch.empty((B * H * W + SLACK_ROWS) * cs, dtype=dtype, device=device), B, H, W, C, cs, 0)
     return v.want_stats(stats if stats in (2, 4) else None) if stats else v
 
 
-def from_nchw(x, dtype=torch.bfloat16, cs=None, pad_to=None):
+def from_nchw(x, dtype=None, cs=None, pad_to=None):
     """torch NCHW tensor -> NHWC View (optionally zero-padded to `pad_to` channels)."""
+    dtype = dtype or a16()
     B, Cc, H, W = x.shape
     Cp = pad_to or Cc
     cs = cs or Cp

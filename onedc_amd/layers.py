@@ -37,7 +37,7 @@ class Workspace:
         return self._get(name, n, torch.float32)
 
     def bf16(self, name, n):
-        return self._get(name, n, torch.bfloat16)
+        return self._get(name, n, K.a16())
 
 
 USE_UPSAMPLE_PHASES = True    # tests switch it off to compare with the plain fused-upsample path
@@ -59,7 +59,7 @@ class Conv:
             perm = pack.glu_perm(self.cout // 2)
         elif shuffle:
             perm = pack.shuffle_perm(self.cout)
-        self.w = pack.pack_matrix(m, device, perm, torch.float32 if f32 else torch.bfloat16)
+        self.w = pack.pack_matrix(m, device, perm, torch.float32 if f32 else K.a16())
         self.b = pack.f32(b, device, perm)
         self.glu, self.shuffle = glu, shuffle
         # conv behind a nearest x2 upsample: also keep the four 2x2 phase convolutions (2.25x fewer MACs); used
@@ -87,7 +87,7 @@ class Conv:
             if self.shuffle:
                 c //= 4
                 oh, ow = 2 * oh, 2 * ow
-            y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else torch.bfloat16)
+            y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else K.a16())
         if stats:
             y.want_stats()
         if (up and self.w_ups is not None and USE_UPSAMPLE_PHASES and res is None and x.H % 16 == 0 and
@@ -134,7 +134,7 @@ class DepthConvBlock4:
         identity = self.adaptor(x) if self.adaptor is not None else x
         t = self.conv1(x, epi=EPI_LEAKY, slope=0.01)
         t2 = K.dwconv3x3(t, self.dw_w, self.dw_b,
-                         new_view(t.B, t.H, t.W, t.C, t.t.device, torch.float32 if self.f32 else torch.bfloat16))
+                         new_view(t.B, t.H, t.W, t.C, t.t.device, torch.float32 if self.f32 else K.a16()))
         h = self.conv2(t2, res=identity)
         u = self.ffn_in(h, epi=EPI_GLU_LEAKY)
         return self.ffn_out(u, y, res=h, out_f32=out_f32)
@@ -180,6 +180,11 @@ class SingleHeadAttention:
         self.bv = pack.f32(sd[f"{vn}.bias"], device)
         self.o = Conv(sd, on, device)
 
+    def scale_output(self, s):
+        """The block's output joins a residual stream that is stored times `s` (vae.py): out = s * (o(a) + b)."""
+        self.out_scale = s
+        self.o.b = (self.o.b * s).contiguous()
+
     def __call__(self, hn, res, n, y=None):
         """hn: normalised tokens View with B groups of n = H*W tokens; res: residual View."""
         dev, C, G = hn.t.device, self.C, hn.B
@@ -189,19 +194,19 @@ class SingleHeadAttention:
         k = self.k(hn)
         kbuf = k.t
         # V^T per group: [C][n_pad], zero padded keys
-        vt = torch.zeros(G * C * n_pad, dtype=torch.bfloat16, device=dev)
+        vt = torch.zeros(G * C * n_pad, dtype=K.a16(), device=dev)
         hn_flat = hn
         K.conv_gemm(self.wv, hn_flat.t, None, View(vt, 1, 1, C, n, n_pad), Cin=C, Cout=n, batch=G,
                     x_bs=0, w_bs=n * C, y_bs=C * n_pad)
         s = torch.empty(rows * n, dtype=torch.float32, device=dev)
         K.conv_gemm(View(q.t, 1, 1, n, C), kbuf, None, View(s, 1, 1, n, n), Cin=C, Cout=n, batch=G,
                     x_bs=n * C, w_bs=n * C, y_bs=n * n, alpha=C ** -0.5)
-        p = torch.empty(rows * n_pad, dtype=torch.bfloat16, device=dev)
+        p = torch.empty(rows * n_pad, dtype=K.a16(), device=dev)
         K.softmax_rows(s, p, rows, n, n_pad)
-        a = torch.empty(rows * C, dtype=torch.bfloat16, device=dev)
+        a = torch.empty(rows * C, dtype=K.a16(), device=dev)
         K.conv_gemm(View(p, 1, 1, n, n_pad), vt, self.bv, View(a, 1, 1, n, C), Cin=n_pad, Cout=C, batch=G,
                     x_bs=n * n_pad, w_bs=C * n_pad, y_bs=n * C)
-        return self.o(View(a, hn.B, hn.H, hn.W, C), y, res=res)
+        return self.o(View(a, hn.B, hn.H, hn.W, C), y, res=res, alpha=getattr(self, "out_scale", 1.0))
 
 
 class VQAttnBlock:
@@ -217,14 +222,22 @@ class ResnetBlock2D:
     """diffusers ResnetBlock2D; `temb` (B-independent, timestep is a constant of the codec) is
     folded into conv1's bias by `set_temb`."""
 
-    def __init__(self, sd, p, device, eps):
+    def __init__(self, sd, p, device, eps, stream_scale=1.0):
+        """stream_scale s (a power of two): the residual stream this block reads and writes is stored times s.
+        GroupNorm is scale invariant up to eps (norm1 gets eps * s^2), the branch output and the biases of the linear
+        maps of the stream are multiplied by s in the epilogue (alpha) / at load."""
         self.p, self.device = p, device
+        self.stream_scale = s = float(stream_scale)
         cin = sd[f"{p}.norm1.weight"].shape[0]
-        self.n1 = GroupNorm(sd, f"{p}.norm1", device, eps)
+        self.n1 = GroupNorm(sd, f"{p}.norm1", device, eps * s * s)
         self.c1 = Conv(sd, f"{p}.conv1", device)
         self.n2 = GroupNorm(sd, f"{p}.norm2", device, eps)
         self.c2 = Conv(sd, f"{p}.conv2", device)
         self.short = Conv(sd, f"{p}.conv_shortcut", device) if f"{p}.conv_shortcut.weight" in sd else None
+        if s != 1.0:
+            self.c2.b = (self.c2.b * s).contiguous()
+            if self.short is not None:
+                self.short.b = (self.short.b * s).contiguous()
         self.cin = cin
         self._c1_bias = sd[f"{p}.conv1.bias"].float()
         if f"{p}.time_emb_proj.weight" in sd:
@@ -240,7 +253,7 @@ class ResnetBlock2D:
     def __call__(self, x, ws, y=None):
         h = self.c1(x, stats=True, gn=(self.n1, ws, True))
         res = self.short(x) if self.short is not None else x
-        return self.c2(h, y, res=res, stats=True, gn=(self.n2, ws, True))
+        return self.c2(h, y, res=res, stats=True, gn=(self.n2, ws, True), alpha=self.stream_scale)
 
 
 class MultiHeadAttention:
@@ -267,7 +280,7 @@ class MultiHeadAttention:
         Nk_pad = (Nk + 63) // 64 * 64
         q = self.q(x)
         k = self.k(ctx)
-        vt = torch.zeros(B * self.H * self.DV * Nk_pad, dtype=torch.bfloat16, device=dev)
+        vt = torch.zeros(B * self.H * self.DV * Nk_pad, dtype=K.a16(), device=dev)
         K.conv_gemm(self.wv, ctx.t, None, View(vt, 1, 1, self.H * self.DV, Nk, Nk_pad), Cin=self.ctx_dim,
                     Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=self.H * self.DV * Nk_pad,
                     flop_scale=self.d / self.DV)

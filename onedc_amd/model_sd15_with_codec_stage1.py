@@ -54,6 +54,9 @@ class SD15_1step_codec_stage1:
         self.device = torch.device(device)
         self.args = args
         self.accelerator = accelerator
+        # 16-bit storage / MFMA operand format of the device path: "f16" (default: the 0.01 dB budget needs its 11-bit
+        # mantissa) or "bf16" (the reference's autocast format; unlimited range)
+        self.act = _get(args, "act_dtype", None) or K.DEFAULT_ACT
         self.use_fp16 = _get(args, "use_fp16", True)
         self.vae_attn_patch = _get(args, "vae_attn_patch", 16)
         self.lora_config = _get(args, "lora_config", {"lora_rank": 64, "lora_alpha": 8.0})
@@ -66,6 +69,10 @@ class SD15_1step_codec_stage1:
 
     # -- weights -------------------------------------------------------------------------------
     def load_state_dicts(self, feedforward_sd, codec_sd, vae_sd):
+        with K.act_format(self.act):
+            return self._load_state_dicts(feedforward_sd, codec_sd, vae_sd)
+
+    def _load_state_dicts(self, feedforward_sd, codec_sd, vae_sd):
         lc = self.lora_config or {}
         rank = _get(lc, "lora_rank", 64)
         alpha = _get(lc, "lora_alpha", 8.0)
@@ -94,6 +101,10 @@ class SD15_1step_codec_stage1:
                                      synth.vae_state_dict(seed))
 
     def load_encoder_state_dicts(self, codec_enc_sd, hyper_enc_sd, vae_enc_sd):
+        with K.act_format(self.act):
+            return self._load_encoder_state_dicts(codec_enc_sd, hyper_enc_sd, vae_enc_sd)
+
+    def _load_encoder_state_dicts(self, codec_enc_sd, hyper_enc_sd, vae_enc_sd):
         """Encode side: `enc.*` and `hyper_enc.*` of model_1.safetensors, encoder half of the SD-2.1 VAE."""
         from .encoder import VAEEncoder
         with torch.cuda.device(self.device):
@@ -106,8 +117,12 @@ class SD15_1step_codec_stage1:
         return self.load_encoder_state_dicts(synth.codec_encoder_state_dict(seed), synth.hyper_enc_state_dict(seed),
                                              synth.vae_encoder_state_dict(seed))
 
-    @torch.no_grad()
     def encode(self, image, fp=None, noise=None):
+        with K.act_format(self.act):
+            return self._encode(image, fp=fp, noise=noise)
+
+    @torch.no_grad()
+    def _encode(self, image, fp=None, noise=None):
         """Reference `encode` (model_sd15_with_codec_stage1.py:275-292): image f32 [B,3,H,W] in [-1,1] on this
         device (B = 1 in the reference) -> (stream bytes, bpp dict) (lists when B > 1).  Replicate padding up to a
         multiple of 64, SD-VAE encoder, analysis transform, hyper analysis, entropy coding.
@@ -126,8 +141,12 @@ class SD15_1step_codec_stage1:
             blobs, bpp = self.codec_model.encode(img, latent, W, H, fp=fp)
         return (blobs[0], bpp[0]) if B == 1 else (blobs, bpp)
 
-    @torch.no_grad()
     def forward_z_only(self, image, noise=None):
+        with K.act_format(self.act):
+            return self._forward_z_only(image, noise=noise)
+
+    @torch.no_grad()
+    def _forward_z_only(self, image, noise=None):
         """The ex-low-rate model's harness (models/sd15_onedc_codec_z_only/inference.py:100-131 around
         model_sd15_with_codec_stage1.py:198-218): reflect padding to a multiple of 64, analysis -> FSQ indices, the
         picture is reconstructed from the indices alone (four-part prior run with means only, no y stream).
@@ -163,8 +182,12 @@ class SD15_1step_codec_stage1:
         return self
 
     # -- decode ---------------------------------------------------------------------------------
-    @torch.no_grad()
     def decode_latents(self, h_detail_hat, y_semantic):
+        with K.act_format(self.act):
+            return self._decode_latents(h_detail_hat, y_semantic)
+
+    @torch.no_grad()
+    def _decode_latents(self, h_detail_hat, y_semantic):
         """model...stage1.py:303-324 after the codec: UNet step, x0, VAE decode. Returns dict of Views."""
         ctx = y_semantic                                            # 'b c h w -> b (h w) c' is the NHWC layout itself
         eps, reduced = self.feedforward_model(h_detail_hat, self.conditioning_timestep, ctx)
@@ -174,8 +197,12 @@ class SD15_1step_codec_stage1:
         image = self.vae_large.decode(x0)
         return {"eps": eps, "reduced": reduced, "x0": x0, "image": image}
 
-    @torch.no_grad()
     def decode(self, fp=None, stream=None, unit_range=False):
+        with K.act_format(self.act):
+            return self._decode(fp=fp, stream=stream, unit_range=unit_range)
+
+    @torch.no_grad()
+    def _decode(self, fp=None, stream=None, unit_range=False):
         """-> f32 tensor [B,3,H,W] (B = 1 for a single path/bytes, as in the reference)."""
         assert fp or stream
         with torch.cuda.device(self.device):
@@ -199,8 +226,12 @@ class SD15_1step_codec_stage1:
     def pipeline(self, depth=2, s_streams=2):
         return DecodePipeline(self, depth, s_streams)
 
-    @torch.no_grad()
     def decode_z_only(self, indices):
+        with K.act_format(self.act):
+            return self._decode_z_only(indices)
+
+    @torch.no_grad()
+    def _decode_z_only(self, indices):
         """sd15_onedc_codec_z_only forward path from FSQ indices alone
         (models/sd15_onedc_codec_z_only/model_sd15_with_codec_stage1.py:198-218)."""
         with torch.cuda.device(self.device):
@@ -245,6 +276,7 @@ class DecodePipeline:
 
     def _entropy_loop(self):
         torch.cuda.set_device(self.dev)
+        K.set_act(self.model.act)
         while True:
             item = self._in.get()
             if item is None:
@@ -275,6 +307,7 @@ class DecodePipeline:
 
     def _synthesis_loop(self, stream):
         torch.cuda.set_device(self.dev)
+        K.set_act(self.model.act)
         while True:
             item = self._mid.get()
             if item is None:

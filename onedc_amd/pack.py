@@ -38,8 +38,12 @@ def _pad_rows(m):
     return m
 
 
-def pack_matrix(w2d, device, row_perm=None, dtype=torch.bfloat16):
-    """[rows][K] f32 -> padded bf16 (or f32 for the exact-f32 prior path) on `device`."""
+def pack_matrix(w2d, device, row_perm=None, dtype=None):
+    """[rows][K] f32 -> padded 16-bit matrix in the current activation format (or f32 for the exact-f32 prior path) on
+    `device`."""
+    if dtype is None:
+        from . import kernels
+        dtype = kernels.a16()
     if row_perm is not None:
         w2d = w2d[row_perm]
     return _pad_rows(w2d.contiguous()).to(dtype).to(device).contiguous()

@@ -14,15 +14,28 @@ from .kernels import View, new_view
 from .layers import Conv, GroupNorm, ResnetBlock2D, SingleHeadAttention, Workspace
 
 
+F16_STREAM_SCALE = 2.0 ** -6
+
+
 class VAEDecoder:
-    def __init__(self, sd, device, attn_patch=16, scaling_factor=0.18215):
+    def __init__(self, sd, device, attn_patch=16, scaling_factor=0.18215, stream_scale=None):
+        """stream_scale: the decoder's residual stream (everything between conv_in and conv_norm_out) is stored times
+        this power of two.  With IEEE-half activations the default 2^-6 moves the stream's headroom from 65504 to 4.2e6
+        (SD-VAE decoder activations reach the thousands; with random-init weights and their huge x0, 2e4) at no cost:
+        every consumer of the stream is a GroupNorm (scale invariant, eps scaled by s^2) or a linear map back into the
+        stream, a power of two changes no rounding, and values below 2^-14 / s = 0.004 are far under the noise of a
+        group's statistics.  bf16 has f32's range: 1."""
         sd = dict(sd)
+        if stream_scale is None:
+            stream_scale = F16_STREAM_SCALE if K.act() == "f16" else 1.0
+        self.stream_scale = s = float(stream_scale)
         a = "decoder.mid_block.attentions.0"
         for old, new in arch.VAE_LEGACY_ATTN.items():      # pre-0.15 diffusers attention names
             for leaf in ("weight", "bias"):
                 if f"{a}.{old}.{leaf}" in sd:
                     sd[f"{a}.{new}.{leaf}"] = sd.pop(f"{a}.{old}.{leaf}").reshape(512, -1).squeeze(-1)
         self.device = device
+        self.act = K.act()                 # the format the weights below are packed in
         self.attn_patch = attn_patch
         self.scaling_factor = scaling_factor
         self.ws = Workspace(device)
@@ -32,16 +45,19 @@ class VAEDecoder:
         # conv_in (3x3, 4 -> 512) on the exact-f32 matrix-core path: input channels zero-padded 4 -> 32
         wci = torch.zeros(512, 32, 3, 3)
         wci[:, :4] = sd["decoder.conv_in.weight"].float()
-        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["decoder.conv_in.bias"], f32=True, flop_scale=4 / 32)
-        self.mid_res = [ResnetBlock2D(sd, f"decoder.mid_block.resnets.{j}", device, 1e-6) for j in range(2)]
-        self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6)
+        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["decoder.conv_in.bias"] * s, f32=True, flop_scale=4 / 32)
+        self.mid_res = [ResnetBlock2D(sd, f"decoder.mid_block.resnets.{j}", device, 1e-6, s) for j in range(2)]
+        self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6 * s * s)
         self.attn = SingleHeadAttention(sd, (f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{a}.to_out.0"), device, 512)
+        self.attn.scale_output(s)
         self.up = []
         for i, (cin, cout) in enumerate(arch.VAE_UP):
-            blk = {"res": [ResnetBlock2D(sd, f"decoder.up_blocks.{i}.resnets.{j}", device, 1e-6) for j in range(3)]}
+            blk = {"res": [ResnetBlock2D(sd, f"decoder.up_blocks.{i}.resnets.{j}", device, 1e-6, s) for j in range(3)]}
             blk["up"] = Conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", device, upsample=True) if i < 3 else None
+            if blk["up"] is not None:
+                blk["up"].b = (blk["up"].b * s).contiguous()       # a linear map of the stream: only its bias scales
             self.up.append(blk)
-        self.norm_out = GroupNorm(sd, "decoder.conv_norm_out", device, 1e-6)
+        self.norm_out = GroupNorm(sd, "decoder.conv_norm_out", device, 1e-6 * s * s)
         self.conv_out = Conv(sd, "decoder.conv_out", device)
 
     def set_attn_patch(self, attn_patch):
@@ -52,6 +68,7 @@ class VAEDecoder:
         from .encoder import windowed_attention
         return windowed_attention(x, self.attn_norm, self.attn, self.attn_patch, self.ws, self.device)
 
+    @K.in_own_format
     @torch.no_grad()
     def decode(self, latents):
         """latents: f32 View (B,h,w,4) -> f32 View (B,8h,8w,3) picture in [-1,1] (unclamped)."""
@@ -59,7 +76,7 @@ class VAEDecoder:
         zbuf = torch.zeros((latents.B * latents.H * latents.W + K.SLACK_ROWS) * 32, dtype=torch.float32, device=dev)
         z = View(zbuf, latents.B, latents.H, latents.W, 32)
         K.direct_conv(latents, self.pq_w, self.pq_b, z.slice(0, 4), K=1, in_scale=1.0 / self.scaling_factor)
-        h = self.conv_in(z, new_view(latents.B, latents.H, latents.W, 512, dev), stats=True)
+        h = self.conv_in(z, new_view(latents.B, latents.H, latents.W, 512, dev), stats=True, alpha=self.stream_scale)
         h = self.mid_res[0](h, ws)
         h = self._windowed_attention(h)
         h = self.mid_res[1](h, ws)

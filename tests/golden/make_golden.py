@@ -9,7 +9,8 @@ load_state_dict (which pins our key/shape tables to the reference's modules), ru
 stores inputs + expected outputs as small .npz files.  The fixtures are data; no reference source
 text is stored.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py g8         # only the files whose name starts with g8
 """
 import glob
 import hashlib
@@ -79,7 +80,12 @@ def sample_points(t, n=2048, seed=0):
             "sum": np.float64(flat.sum()), "abs_sum": np.float64(flat.abs().sum())}
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]
+
+
 def save(name, **arrays):
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
     flat = {}
     for k, v in arrays.items():
         if isinstance(v, dict):
@@ -276,6 +282,39 @@ def main():
          mask0=masks[0][0, ::32, :4, :4], mask1=masks[1][0, ::32, :4, :4],
          mask2=masks[2][0, ::32, :4, :4], mask3=masks[3][0, ::32, :4, :4],
          y_semantic=sample_points(y_semantic, 4096), x_hat=sample_points(x_hat, 8192))
+
+    # ---------------------------------------------------------------- G8 reference-made streams at larger sizes
+    # What a drop-in decoder must cope with: y streams written by the reference's own compress path
+    # (compression_model.py:360-367 + entropy_models.py:364-367 + rans.cpp) for 256x256 and 768x768 pictures.  Stored:
+    # the z indices and the y stream (= the decoder's whole input), and for checking the four symbol planes, the
+    # four table-index planes and y_hat (sample points + sha256 of the f32 bytes).
+    print("G8 reference-made streams (256x256, 768x768)")
+    rng8 = np.random.default_rng(8)
+    for tag, zn in (("256", 4), ("768", 12)):
+        with torch.no_grad():
+            indices8 = torch.from_numpy(rng8.integers(0, 16384, (1, zn, zn)))
+            z_hat8 = torch.stack([((indices8 // 4 ** d) % 4 - 2).float() / 2 for d in range(7)], dim=1)
+            params8, _ = hyper_dec(z_hat8)
+            fused8 = fusion(params8)
+            means8 = fused8.chunk(2, 1)[1]
+            y8 = means8 + 3.0 * torch.randn(means8.shape, generator=torch.Generator().manual_seed(80 + zn))
+            out8 = cm.compress_four_part_prior(y8, fused8, adaptors[0], adaptors[1], adaptors[2], spatial,
+                                               y_spatial_prior_reduction=reduction)
+            yq8, s8, y_hat8 = out8[0:4], out8[4:8], out8[8]
+            ec.reset()
+            planes8 = []
+            for yq, sc in zip(yq8, s8):
+                planes8.append(cm.gaussian_encoder.build_indexes(sc))
+                cm.gaussian_encoder.encode(yq, sc)
+            ec.flush()
+            stream8 = ec.get_encoded_stream()
+            ec.set_stream(stream8)
+            back8 = cm.decompress_four_part_prior(fused8, adaptors[0], adaptors[1], adaptors[2], spatial, reduction)
+            assert torch.equal(back8, y_hat8)
+        save(f"g8_ref_stream_{tag}.npz", indices=indices8.int(), stream=np.frombuffer(stream8, np.uint8),
+             symbols=torch.stack(list(yq8)).to(torch.int16), index_planes=torch.stack(planes8).to(torch.int16),
+             y_hat=sample_points(y_hat8, 16384),
+             y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat8.numpy().tobytes()).digest(), dtype=np.uint8))
 
     # ---------------------------------------------------------------- G7 hyper encoder (encode side)
     print("G7 hyper encoder")

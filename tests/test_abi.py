@@ -32,12 +32,17 @@ def test_hip_library_exports_header_symbols():
     """hipcc cross-compiles for gfx950 without a GPU; dlopen works because the HIP runtime
     initialises lazily."""
     build.build_hip()
-    lib = ctypes.CDLL(_native.HIP_SO)
     names = declared("onedc_hip.h")
     assert len(names) >= 20
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in onedc_hip.h but not exported"
+    # the same sources are built twice: bf16 activations and IEEE-half activations (csrc/common.h)
+    for path, fmt in ((_native.HIP_SO, b"bf16"), (_native.HIP_F16_SO, b"f16")):
+        lib = ctypes.CDLL(path)
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in onedc_hip.h but not exported by {path}"
+        lib.onedc_hip_version.restype = ctypes.c_char_p
+        assert fmt + b" activations" in lib.onedc_hip_version()
     assert set(names) == set(kernels.HIP_SYMBOLS)
+    assert kernels.lib("bf16") is not kernels.lib("f16")
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -21,7 +21,8 @@ DEV = "cuda:0"
 
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
-    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+    # representable in bf16 AND in the current 16-bit activation format (f16 has subnormals where bf16 still has 8 bits)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float().to(K.a16()).float()
 
 
 def close(got, ref, rms=4e-3, mx=2.5e-2, what=""):
@@ -118,8 +119,8 @@ def test_conv_gemm_batched_nt():
     """Batched activation x activation product (QK^T of the single-head attention)."""
     G, n, Cc = 5, 144, 128
     q, k = rnd(G, n, Cc, seed=22), rnd(G, n, Cc, seed=23)
-    qd = torch.zeros(G * n + 128, Cc, dtype=torch.bfloat16, device=DEV)
-    kd = torch.zeros(G * n + 128, Cc, dtype=torch.bfloat16, device=DEV)
+    qd = torch.zeros(G * n + 128, Cc, dtype=K.a16(), device=DEV)
+    kd = torch.zeros(G * n + 128, Cc, dtype=K.a16(), device=DEV)
     qd[:G * n] = q.view(-1, Cc).to(DEV)
     kd[:G * n] = k.view(-1, Cc).to(DEV)
     s = torch.empty(G * n * n, dtype=torch.float32, device=DEV)
@@ -142,7 +143,7 @@ def test_conv_gemm_batch_invariant():
 def test_conv_gemm_rejects_bad_arguments():
     y = new_view(1, 4, 4, 128, DEV)
     with pytest.raises(K.KernelError):
-        K.conv_gemm(new_view(1, 4, 4, 100, DEV), torch.zeros(128, 100, dtype=torch.bfloat16, device=DEV), None, y)
+        K.conv_gemm(new_view(1, 4, 4, 100, DEV), torch.zeros(128, 100, dtype=K.a16(), device=DEV), None, y)
 
 
 class _WS:
@@ -176,15 +177,15 @@ def test_group_norm_large_map_many_chunks():
 @pytest.mark.parametrize("C", [320, 640, 1280])
 def test_layernorm(C):
     x, g, b = rnd(300, C, seed=32) * 3, rnd(C, seed=33), rnd(C, seed=34)
-    y = torch.empty(300, C, dtype=torch.bfloat16, device=DEV)
-    K.layernorm(x.to(torch.bfloat16).to(DEV), g.to(DEV), b.to(DEV), y, 300, C)
+    y = torch.empty(300, C, dtype=K.a16(), device=DEV)
+    K.layernorm(x.to(K.a16()).to(DEV), g.to(DEV), b.to(DEV), y, 300, C)
     close(y.float(), F.layer_norm(x, (C,), g, b, 1e-5), what="layernorm")
 
 
 @pytest.mark.parametrize("n,n_pad", [(144, 192), (256, 256), (16, 64)])
 def test_softmax_rows(n, n_pad):
     s = torch.randn(77, n, generator=torch.Generator().manual_seed(35)) * 4
-    p = torch.empty(77, n_pad, dtype=torch.bfloat16, device=DEV)
+    p = torch.empty(77, n_pad, dtype=K.a16(), device=DEV)
     K.softmax_rows(s.to(DEV), p, 77, n, n_pad)
     close(p[:, :n].float(), torch.softmax(s, -1), what="softmax")
     assert float(p[:, n:].float().abs().max() if n_pad > n else 0.0) == 0.0
@@ -218,12 +219,12 @@ def test_flash_attention(d, Nq, Nk):
     def padded(t, dp):                      # (B,H,N,d) -> (B,N,H*dp) bf16 with zero padding
         out = torch.zeros(B, t.shape[2], Hh, dp)
         out[..., :d] = t.permute(0, 2, 1, 3)
-        return out.reshape(B, t.shape[2], Hh * dp).to(torch.bfloat16).to(DEV).contiguous()
+        return out.reshape(B, t.shape[2], Hh * dp).to(K.a16()).to(DEV).contiguous()
 
     vt = torch.zeros(B, Hh, DV, Nk_pad)
     vt[:, :, :d, :Nk] = v.transpose(2, 3)
-    o = torch.empty(B, Nq, Hh * DV, dtype=torch.bfloat16, device=DEV)
-    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk_pad).to(torch.bfloat16).to(DEV).contiguous(),
+    o = torch.empty(B, Nq, Hh * DV, dtype=K.a16(), device=DEV)
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk_pad).to(K.a16()).to(DEV).contiguous(),
                  o, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5)
     ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v               # (B,H,Nq,d)
     got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
@@ -549,12 +550,12 @@ def test_flash_attention_reference_point_moves():
     def padded(t, dp):
         out = torch.zeros(B, t.shape[2], Hh, dp)
         out[..., :d] = t.permute(0, 2, 1, 3)
-        return out.reshape(B, t.shape[2], Hh * dp).to(torch.bfloat16).to(DEV).contiguous()
+        return out.reshape(B, t.shape[2], Hh * dp).to(K.a16()).to(DEV).contiguous()
 
     vt = torch.zeros(B, Hh, DV, Nk)
     vt[:, :, :d] = v.transpose(2, 3)
-    o = torch.empty(B, Nq, Hh * DV, dtype=torch.bfloat16, device=DEV)
-    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk).to(torch.bfloat16).to(DEV).contiguous(),
+    o = torch.empty(B, Nq, Hh * DV, dtype=K.a16(), device=DEV)
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk).to(K.a16()).to(DEV).contiguous(),
                  o, B, Hh, Nq, Nk, Nk, DQ, DV, d ** -0.5)
     ref = torch.softmax(q.double() @ k.double().transpose(-1, -2) * d ** -0.5, -1) @ v.double()
     got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
@@ -734,7 +735,7 @@ def test_conv3x3_few_out(B, H, W, Cin, Cout, gn, f32):
     x, w, b = rnd(B, Cin, H, W, seed=271), rnd(Cout, Cin, 3, 3, seed=272, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=273)
     g, be = 1 + 0.2 * rnd(Cin, seed=274), 0.5 * rnd(Cin, seed=275)
     xbuf = from_nchw(torch.cat([rnd(B, 32, H, W, seed=276), x], 1).to(DEV))
-    y = new_view(B, H, W, Cout, DEV, torch.float32 if f32 else torch.bfloat16)
+    y = new_view(B, H, W, Cout, DEV, torch.float32 if f32 else K.a16())
     K.conv3x3_few_out(xbuf.slice(32, Cin), packed(w), b.to(DEV), y, gn=(g.to(DEV), be.to(DEV), 1e-6, True, _WS()) if gn else None)
     xin = F.silu(F.group_norm(x, 32, g, be, 1e-6)) if gn else x
     close(y.torch_nchw(), F.conv2d(xin, w, b, padding=1), rms=6e-3, mx=4e-2, what="few-out conv")
@@ -766,7 +767,7 @@ def test_conv_stats_identical_across_kernel_families():
 @pytest.mark.parametrize("n,n_pad", [(1024, 1024), (2304, 2304), (600, 640)])
 def test_softmax_rows_long(n, n_pad):
     s = torch.randn(9, n, generator=torch.Generator().manual_seed(151)) * 4
-    p = torch.empty(9, n_pad, dtype=torch.bfloat16, device=DEV)
+    p = torch.empty(9, n_pad, dtype=K.a16(), device=DEV)
     K.softmax_rows(s.to(DEV), p, 9, n, n_pad)
     close(p[:, :n].float(), torch.softmax(s, -1), what="softmax long rows")
     assert float(p[:, n:].float().abs().max() if n_pad > n else 0.0) == 0.0

@@ -240,3 +240,53 @@ def test_encoder_specs_parameter_counts():
     assert arch.param_count(arch.vae_encoder_spec()) == 34_163_592 + 72
     plan = arch.enc_unet_up_plan()
     assert plan[(0, 0)] == (1536, 768) and plan[(1, 2)] == (1280, 768) and plan[(2, 0)] == (1280, 512) and plan[(2, 2)] == (1024, 512)
+
+
+# ---- G8: y streams written by the reference's own compress path at 256x256 and 768x768 ------------------------------
+@pytest.mark.parametrize("tag", ["256", "768"])
+def test_reference_made_stream_decodes_with_the_product_coder(tag, gaussian_tables):
+    """The host boundary alone: fed the reference's table-index planes, the product's rANS decoder returns the
+    reference's symbol planes from the reference's stream (73 728 x 4 symbols at 768x768) and ends exactly on the
+    encoder's initial state (onedc_rans_dec_finished)."""
+    from onedc_amd.entropy import rans
+    g = golden(f"g8_ref_stream_{tag}.npz")
+    d = rans.RansDecoder(1)
+    d.add_cdf(*gaussian_tables)
+    d.set_stream(g["stream"].tobytes())
+    for k in range(4):
+        got = d.decode_stream(g["index_planes"][k].reshape(-1), 0)
+        assert np.array_equal(got, g["symbols"][k].reshape(-1)), k
+        assert d.finished() == (k == 3)
+    # and the product encoder writes the reference's bytes from the reference's decisions
+    e = rans.RansEncoder(False, 1)
+    e.add_cdf(*gaussian_tables)
+    for k in range(4):
+        e.encode_with_indexes(g["symbols"][k].reshape(-1), g["index_planes"][k].reshape(-1), 0)
+    e.flush()
+    assert e.get_encoded_stream().tobytes() == g["stream"].tobytes()
+
+
+def test_reference_made_stream_through_the_oracle_prior(codec_sd, gaussian_tables):
+    """The whole entropy stage of the oracle on the 256x256 reference-made stream: z indices -> hyper decoder -> prior
+    fusion -> four hops (oracle C port as the coder).  torch-CPU fp32 on both sides, so the table indexes agree except
+    for the odd boundary flip between two builds / thread counts; where there is none, the symbols and y_hat are the
+    reference's."""
+    g = golden("g8_ref_stream_256.npz")
+    t = rans_port.Tables(*gaussian_tables)
+    dec = rans_port.Decoder(g["stream"].tobytes(), t)
+    planes = []
+
+    def hop(k, idx_plane):
+        planes.append(idx_plane.to(torch.int16).numpy())
+        return torch.from_numpy(dec.decode(planes[-1]).astype(np.float32)).reshape(idx_plane.shape)
+
+    with torch.no_grad():
+        fused, _ = R.z_indices_to_params(codec_sd, torch.from_numpy(g["indices"]).long())
+        y_hat = R.decompress_four_part_prior(codec_sd, fused, hop)
+    flips = sum(int((p != g["index_planes"][k]).sum()) for k, p in enumerate(planes))
+    print(f"[oracle] index flips vs the reference on its 256x256 stream: {flips} of {4 * planes[0].size}")
+    if flips == 0:
+        flat = y_hat.reshape(-1)
+        np.testing.assert_allclose(flat[torch.from_numpy(g["y_hat.idx"])].numpy(), g["y_hat.val"], rtol=1e-4, atol=1e-4)
+    else:
+        assert flips <= 8         # a flip desynchronises the rest: only the count of FIRST-hop flips is meaningful

@@ -5,7 +5,7 @@ from onedc_amd import kernels as K, pack
 DEV="cuda:0"
 g = torch.Generator(device=DEV).manual_seed(0)
 for name,B,H,W,Cin,Cout in [("512->512@192",16,192,192,512,512),("256->256@384",16,384,384,256,256)]:
-    x = K.View(torch.randn((B*H*W+128)*Cin, generator=g, device=DEV).to(torch.bfloat16), B,H,W,Cin)
+    x = K.View(torch.randn((B*H*W+128)*Cin, generator=g, device=DEV).to(K.a16()), B,H,W,Cin)
     w = pack.pack_matrix(torch.randn(Cout, 9*Cin, generator=g, device=DEV)*(9*Cin)**-0.5, DEV)
     y = K.new_view(B,H,W,Cout,DEV)
     for _ in range(3): K.conv_gemm(x,w,None,y,KH=3,tile=256)

@@ -10,7 +10,7 @@ g = torch.Generator(device=DEV).manual_seed(0)
 B, H, W, Cout = 8, 768, 768, 128
 pts = []
 for Cin in (64, 128, 256, 512):
-    x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(torch.bfloat16), B, H, W, Cin)
+    x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, W, Cin)
     w = pack.pack_matrix(torch.randn(Cout, 9 * Cin, generator=g, device=DEV) * (9 * Cin) ** -0.5, DEV)
     y = K.new_view(B, H, W, Cout, DEV)
     for _ in range(3):

@@ -19,7 +19,7 @@ SH = [("ff-in geglu 320->2560 @96", 96, 320, 2560, 1, K.EPI_GEGLU, False), ("ff-
       ("1x1 1280->1280 @24", 24, 1280, 1280, 1, 0, False), ("3x3 1280->1280 @24 +res", 24, 1280, 1280, 3, 0, True)]
 for name, H, Cin, Cout, k, epi, res in SH:
     B = 16
-    x = K.View(torch.randn((B * H * H + 128) * Cin, generator=g, device=DEV).to(torch.bfloat16), B, H, H, Cin)
+    x = K.View(torch.randn((B * H * H + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, H, Cin)
     glu = epi in (K.EPI_GEGLU, K.EPI_GLU_LEAKY)
     wm = torch.randn(Cout, k * k * Cin, generator=g, device=DEV) * (k * k * Cin) ** -0.5
     w = pack.pack_matrix(wm, DEV, pack.glu_perm(Cout // 2).to(DEV) if glu else None)

@@ -39,7 +39,7 @@ def main():
     for name, B, H, W, Cin, Cout, k, up in SHAPES:
         if only and only not in name:
             continue
-        x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(torch.bfloat16), B, H, W, Cin)
+        x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, W, Cin)
         w = pack.pack_matrix(torch.randn(Cout, k * k * Cin, generator=g, device=DEV) * (k * k * Cin) ** -0.5, DEV)
         OH, OW = (2 * H, 2 * W) if up else (H, W)
         y = K.new_view(B, OH, OW, Cout, DEV)

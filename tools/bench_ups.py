@@ -13,7 +13,7 @@ DEV = "cuda:0"
 g = torch.Generator(device=DEV).manual_seed(0)
 for name, B, H, W, C in [("vae 512 96->192", 16, 96, 96, 512), ("vae 512 192->384", 16, 192, 192, 512),
                          ("vae 256 384->768", 16, 384, 384, 256), ("unet 640 48->96", 16, 48, 48, 640)]:
-    x = K.View(torch.randn((B * H * W + 128) * C, generator=g, device=DEV).to(torch.bfloat16), B, H, W, C)
+    x = K.View(torch.randn((B * H * W + 128) * C, generator=g, device=DEV).to(K.a16()), B, H, W, C)
     w = torch.randn(C, C, 3, 3, generator=g, device=DEV) * (9 * C) ** -0.5
     w1 = pack.pack_matrix(pack.conv_matrix(w), DEV)
     w2 = pack.pack_matrix(pack.upsample_phase_matrix(w), DEV)

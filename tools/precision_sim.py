@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""CPU simulation of storage / operand precisions on the oracle (no GPU): which roundings of the HIP path spend the
+0.01 dB budget?  Patches oracle.torch_ref so that every conv / linear rounds its input (`op`), its weights (`w`) and
+its output (`store`), and every residual block rounds the stream it hands on (`stream`), then compares the decoded
+picture with the pure-fp32 oracle.  Formats: f32, bf16, f16.
+
+    python tools/precision_sim.py --size 256 --stage vae
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+import torch.nn.functional as F
+
+from onedc_amd import synth
+from oracle import torch_ref as R
+
+FMT = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def q(x, fmt):
+    return x if FMT[fmt] is None else x.to(FMT[fmt]).float()
+
+
+class Sim:
+    def __init__(self, op, w, store, stream):
+        self.op, self.w, self.store, self.stream = op, w, store, stream
+        self.on = True
+
+    def install(self):
+        self.orig = {n: getattr(R, n) for n in ("conv", "linear", "unet_resnet_block", "vq_resnet_block",
+                                                "depth_conv_block4", "residual_block_upsample", "vq_attn_block")}
+        sim = self
+
+        def conv(sd, p, x, stride=1, padding=0, groups=1):
+            if not sim.on:
+                return sim.orig["conv"](sd, p, x, stride, padding, groups)
+            wt = sd[f"{p}.weight"] if groups > 1 else q(sd[f"{p}.weight"], sim.w)
+            y = F.conv2d(q(x, sim.op), wt, sd.get(f"{p}.bias"), stride=stride, padding=padding, groups=groups)
+            return q(y, sim.store)
+
+        def linear(sd, p, x):
+            if not sim.on:
+                return sim.orig["linear"](sd, p, x)
+            return q(F.linear(q(x, sim.op), q(sd[f"{p}.weight"], sim.w), sd.get(f"{p}.bias")), sim.store)
+
+        def wrap(name):
+            f = self.orig[name]
+
+            def g(*a, **k):
+                y = f(*a, **k)
+                return q(y, sim.stream) if sim.on else y
+            return g
+
+        R.conv, R.linear = conv, linear
+        for n in ("unet_resnet_block", "vq_resnet_block", "depth_conv_block4", "residual_block_upsample", "vq_attn_block"):
+            setattr(R, n, wrap(n))
+
+    def remove(self):
+        for n, f in self.orig.items():
+            setattr(R, n, f)
+
+
+def psnr_pair(img, ref):
+    out = [R.psnr(img, ref)]
+    for level in (25.0, 27.0):
+        sigma = 10 ** (-level / 20)
+        orig = ref + sigma * torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+        out.append(abs(R.psnr(img, orig) - R.psnr(ref, orig)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--stage", default="vae", choices=["vae", "synthesis", "unet", "all"])
+    ap.add_argument("--threads", type=int, default=8)
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    S = a.size
+    codec_sd, unet_sd, vae_sd = synth.codec_state_dict(0), R.fold_lora(synth.unet_state_dict(0)), synth.vae_state_dict(0)
+    g = torch.Generator().manual_seed(0)
+    y_hat = torch.randn(1, 128, S // 16, S // 16, generator=g).round()
+    z_sem = torch.randn(1, 128, S // 64, S // 64, generator=g)
+    with torch.no_grad():
+        ref = R.decode_from_latents(codec_sd, unet_sd, vae_sd, y_hat, z_sem)
+    ref_img = R.to_unit_range(ref["image"])
+    t = torch.full((1,), 999, dtype=torch.long)
+    acp = R.ddim_alphas_cumprod().double()
+
+    def run(stage):
+        with torch.no_grad():
+            if stage == "vae":
+                return R.vae_decode(vae_sd, ref["x0"], 16)
+            if stage == "synthesis":
+                ys = R.semantic_adaptor(codec_sd, z_sem)
+                hd = R.codec_decoder(codec_sd, y_hat, ys)
+                sim.on = False
+                ctx = ys.permute(0, 2, 3, 1).reshape(1, -1, ys.shape[1])
+                eps, red = R.unet_forward(unet_sd, hd, t, ctx)
+                x0 = R.get_x0_from_noise(red.double(), eps.double(), acp, t).float()
+                img = R.vae_decode(vae_sd, x0, 16)
+                sim.on = True
+                return img
+            if stage == "unet":
+                ctx = ref["y_semantic"].permute(0, 2, 3, 1).reshape(1, -1, 768)
+                eps, red = R.unet_forward(unet_sd, ref["h_detail"], t, ctx)
+                sim.on = False
+                x0 = R.get_x0_from_noise(red.double(), eps.double(), acp, t).float()
+                img = R.vae_decode(vae_sd, x0, 16)
+                sim.on = True
+                return img
+            return R.decode_from_latents(codec_sd, unet_sd, vae_sd, y_hat, z_sem)["image"]
+
+    ap_cfg = os.environ.get("SIM_CONFIGS")
+    configs = [("bf16", "bf16", "bf16", "bf16"), ("bf16", "bf16", "bf16", "f32"), ("bf16", "bf16", "f32", "f32"),
+               ("f16", "bf16", "bf16", "bf16"), ("f16", "f16", "bf16", "bf16"), ("f16", "f16", "f16", "f16"),
+               ("f16", "f16", "f16", "f32"), ("f16", "f16", "f32", "f32"), ("bf16", "f32", "bf16", "bf16"),
+               ("f32", "bf16", "f32", "f32"), ("f32", "f32", "bf16", "bf16"), ("f32", "f32", "f32", "bf16")]
+    if ap_cfg:
+        configs = [tuple(c.split("/")) for c in ap_cfg.split(",")]
+    print(f"stage {a.stage} at {S}x{S}: conv operand / weights / conv-output store / residual stream")
+    for op, w, store, stream in configs:
+        sim = Sim(op, w, store, stream)
+        sim.install()
+        try:
+            img = R.to_unit_range(run(a.stage))
+        finally:
+            sim.remove()
+        p, d25, d27 = psnr_pair(img, ref_img)
+        print(f"  op {op:5s} w {w:5s} store {store:5s} stream {stream:5s}   PSNR {p:6.2f} dB   dPSNR@25 {d25:.4f} @27 {d27:.4f}",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ B, H, W, Cin, Cout, k, up = map(int, sys.argv[1:8])
 TILE = int(sys.argv[8]) if len(sys.argv) > 8 else 129
 DEV = "cuda:0"
 g = torch.Generator(device=DEV).manual_seed(0)
-x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(torch.bfloat16), B, H, W, Cin)
+x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, W, Cin)
 w = pack.pack_matrix(torch.randn(Cout, k * k * Cin, generator=g, device=DEV) * (k * k * Cin) ** -0.5, DEV)
 OH, OW = (2 * H, 2 * W) if up else (H, W)
 y = K.new_view(B, OH, OW, Cout, DEV)

@@ -15,7 +15,7 @@ from onedc_amd import pack
 B, H, W, Cin, Cout = map(int, sys.argv[1:6])
 DEV = "cuda:0"
 g = torch.Generator(device=DEV).manual_seed(0)
-x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(torch.bfloat16), B, H, W, Cin)
+x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, W, Cin)
 w = pack.pack_matrix(torch.randn(Cout, 9 * Cin, generator=g, device=DEV) * (9 * Cin) ** -0.5, DEV)
 y = K.new_view(B, H, W, Cout, DEV)
 blocks = (Cout + 127) // 128 * (H // 16) * (W // 16) * B

@@ -16,9 +16,9 @@ DEV = "cuda:0"
 unet = UNet(synth.unet_state_dict(0), DEV)
 g = torch.Generator(device=DEV).manual_seed(0)
 x = new_view(16, 96, 96, 320, DEV)
-x.t.copy_(torch.randn(x.t.numel(), generator=g, device=DEV).to(torch.bfloat16))
+x.t.copy_(torch.randn(x.t.numel(), generator=g, device=DEV).to(K.a16()))
 ctx = new_view(16, 12, 12, 768, DEV)
-ctx.t.copy_(torch.randn(ctx.t.numel(), generator=g, device=DEV).to(torch.bfloat16))
+ctx.t.copy_(torch.randn(ctx.t.numel(), generator=g, device=DEV).to(K.a16()))
 unet(x, 999, ctx)
 torch.cuda.synchronize()
 rec = []
