@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of BASELINE.json: 768x768 images/sec decoded.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                       # BASELINE configs[1] / [2] (default mode)
+    python bench.py --mode z_only                                       # configs[3]: ex-low-rate model, 768x768, B=16
+    python bench.py --mode encode_decode                                # configs[4]: 512x512 encode + decode, B=8 / GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one full decode of a batch of 16 synthetic 768x768 bitstreams per GPU
-(BASELINE configs[1]: "768x768 batch=16 decode, lambda=4.6, bf16, 1xMI355X"): container parse,
-FSQ index unpack, hyperprior synthesis, the four host rANS hops of the four-part prior, semantic
-adaptor + codec synthesis, one SD1.5-UNet step, x0, SD-VAE decoder, crop.  Weights are
-deterministic random-init tensors of the real architecture (no checkpoints offline), bitstreams
-are produced beforehand by the product's own encode side of the prior.  N > 1: image-batch data
-parallel, one process per GPU, weak scaling, one RCCL broadcast of the weights, no data-path
+decode (default)  One step = one full decode of a batch of 16 synthetic 768x768 bitstreams per GPU: container parse,
+                  FSQ index unpack, hyperprior synthesis, the four host rANS hops of the four-part prior, semantic
+                  adaptor + codec synthesis, one SD1.5-UNet step, x0, SD-VAE decoder, crop.
+z_only            One step = one decode of 16 indices-only containers (268 B each at 768x768) per GPU: the same path
+                  with y_hat = the prior's means (no y stream, no rANS hop).
+encode_decode     One step = model.encode of 8 synthetic 512x512 pictures per GPU (SD-VAE encoder, analysis transform,
+                  hyper analysis, four-part prior, host rANS encode, container) followed by model.decode of the 8
+                  streams.  Pictures and the injected latent noise are resident in HBM when the timed region starts.
+                  Also reports bpp against the fp32 oracle and the prior's table-index mismatch rate.
+
+Weights are deterministic random-init tensors of the real architecture (no checkpoints offline).  N > 1: image-batch
+data parallel, one process per GPU, weak scaling, every rank builds the same synthetic weights itself (a real checkpoint
+is read by rank 0 and broadcast once over RCCL: --broadcast-weights forces that path here too), no data-path
 collective.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      for the dominant kernel (the implicit-GEMM instantiation with the most device time): achieved =
-                algorithmic FLOPs of its launches / their summed duration, measured live with HIP
-                events on the launch stream during the timed region; peak = dense bf16 MFMA.
-  cpu_baseline  the fp32 oracle (oracle/torch_ref.py, "port") timed on the host cores of this box
-                on a bounded sample, scaled to the metric's unit by algorithmic FLOPs.
+  roofline      for the dominant kernel (the implicit-GEMM kernel family with the most device time, as reported by the
+                C dispatcher itself): achieved = algorithmic FLOPs of its launches / their summed duration, measured
+                live with HIP events on the launch stream during the timed region; peak = dense 16-bit MFMA.
+  cpu_baseline  the fp32 oracle (oracle/torch_ref.py, "port") timed on the host cores of this box on a bounded
+                sample, scaled to the metric's unit by algorithmic FLOPs.
 """
 import argparse
 import json
@@ -33,8 +41,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (guide: MI355X_MICROARCH.md)
-GFLOP_PER_IMAGE = {768: 8046.7, 512: 3419.5, 256: 831.4}   # SURVEY.md 8(d), algorithmic, 2*MAC
+PEAK_MFMA16_TFLOPS = 2500.0        # MI355X dense bf16 / f16 MFMA (guide: MI355X_MICROARCH.md)
+GFLOP_PER_IMAGE = {768: 8046.7, 512: 3419.5, 256: 831.4}   # SURVEY.md 8(d), decode, algorithmic, 2*MAC
+MODE_DEFAULTS = {"decode": (768, 16), "z_only": (768, 16), "encode_decode": (512, 8)}
 
 
 def parse():
@@ -42,38 +51,133 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=768)
+    ap.add_argument("--mode", choices=sorted(MODE_DEFAULTS), default="decode")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: 16; encode_decode: 8)")
+    ap.add_argument("--size", type=int, default=None, help="picture size (default: 768; encode_decode: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sequential", action="store_true", help="no pipelining across batches")
     ap.add_argument("--s-streams", type=int, default=2, help="concurrent synthesis/UNet/VAE stages in the pipeline")
-    ap.add_argument("--cpu-sample", type=int, default=768, help="picture size of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="picture size of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline (16 was the fastest of 16/32/64 on the 2x64-core host)")
-    return ap.parse_args()
+    ap.add_argument("--broadcast-weights", action="store_true",
+                    help="rank 0 builds the weights, one flat RCCL broadcast hands them to the other ranks (the path a "
+                         "real checkpoint takes); default: every rank builds the synthetic weights itself")
+    a = ap.parse_args()
+    size, batch = MODE_DEFAULTS[a.mode]
+    a.size = a.size or size
+    a.batch = a.batch or batch
+    a.cpu_sample = a.cpu_sample or a.size
+    return a
 
 
-def cpu_baseline(sample, threads, codec_sd, unet_sd, vae_sd):
-    """Oracle decode (everything after the entropy decode) of one sample x sample picture on the
-    host; scaled to 768^2-equivalent images/s by algorithmic FLOPs when sample != 768."""
+def _oracle_weights(sds):
+    from oracle import torch_ref as R
+    unet_sd, codec_sd, vae_sd = ({k: v.cpu() for k, v in sd.items()} for sd in sds[:3])
+    return codec_sd, R.fold_lora(unet_sd), vae_sd
+
+
+def cpu_baseline_decode(sample, threads, sds, z_only=False):
+    """Oracle decode (everything after the entropy decode) of one sample x sample picture on the host; scaled to
+    768^2-equivalent images/s by algorithmic FLOPs when sample != 768."""
     from oracle import torch_ref as R
     cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
-    unet_folded = R.fold_lora({k: v.cpu() for k, v in unet_sd.items()})
-    codec_cpu = {k: v.cpu() for k, v in codec_sd.items()}
-    vae_cpu = {k: v.cpu() for k, v in vae_sd.items()}
+    codec_cpu, unet_folded, vae_cpu = _oracle_weights(sds)
     g = torch.Generator().manual_seed(0)
-    y_hat = torch.randn(1, 128, sample // 16, sample // 16, generator=g)
     z_sem = torch.randn(1, 128, sample // 64, sample // 64, generator=g)
     with torch.no_grad():
         t0 = time.perf_counter()
+        if z_only:
+            idx = torch.randint(0, 16384, (1, sample // 64, sample // 64), generator=g)
+            fused, z_sem = R.z_indices_to_params(codec_cpu, idx)
+            y_hat = R.recon_with_z_four_part_prior(codec_cpu, fused)
+        else:
+            y_hat = torch.randn(1, 128, sample // 16, sample // 16, generator=g)
         R.decode_from_latents(codec_cpu, unet_folded, vae_cpu, y_hat, z_sem)
         dt = time.perf_counter() - t0
-    scale = GFLOP_PER_IMAGE[sample] / GFLOP_PER_IMAGE[768]
+    scale = GFLOP_PER_IMAGE[sample] / GFLOP_PER_IMAGE.get(768)
+    what = ("z indices -> hyper decoder + means-only four-part prior + decode_from_latents" if z_only
+            else "decode_from_latents")
     return {"value": round(scale / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_ref.py fp32 decode_from_latents of one {sample}x{sample} picture in "
+            "sample": f"oracle/torch_ref.py fp32 {what} of one {sample}x{sample} picture in "
                       f"{dt:.2f} s on {cores} of {os.cpu_count()} host threads, scaled to 768x768 by algorithmic "
-                      f"GFLOP ({GFLOP_PER_IMAGE[sample]}/{GFLOP_PER_IMAGE[768]}); host rANS not included"}
+                      f"GFLOP ({GFLOP_PER_IMAGE[sample]}/{GFLOP_PER_IMAGE[768]})"
+                      + ("" if z_only else "; host rANS not included")}
+
+
+def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, product_blob):
+    """Oracle encode + decode of ONE picture of the batch on the host (the same picture and latent noise the product
+    coded), its stream size against the product's, and the prior's table-index decisions against the product's on the
+    product's own symbols ("bpp delta and scale-index mismatch rate vs ref_cpu")."""
+    from onedc_amd.entropy.utils import decode_i
+    from oracle import rans_port
+    from oracle import torch_ref as R
+    cores = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    codec_cpu, unet_folded, vae_cpu = _oracle_weights(sds)
+    enc_cpu, henc_cpu, vae_enc_cpu = ({k: v.cpu() for k, v in sd.items()} for sd in enc_sds)
+    tables = rans_port.Tables(*model.codec_model._tables)
+    img = image.cpu()
+    S = img.shape[-1]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        latent = R.vae_encode(vae_enc_cpu, img, 16, noise.cpu().permute(0, 3, 1, 2).contiguous())
+        y, sem = R.codec_encoder(enc_cpu, img, latent)
+        z = R.hyper_encoder(henc_cpu, y, sem)
+        _, idx = R.fsq_quantize(z)
+        fused, z_sem = R.z_indices_to_params(codec_cpu, idx.long())
+        y_q_w, s_w, y_hat = R.compress_four_part_prior(codec_cpu, y, fused)
+        sym = torch.stack(y_q_w).to(torch.int16).numpy().reshape(-1)
+        planes = torch.stack([R.build_indexes(s) for s in s_w]).to(torch.int16).numpy().reshape(-1)
+        stream = rans_port.encode(sym, planes, tables)
+        t_enc = time.perf_counter() - t0
+        R.decode_from_latents(codec_cpu, unet_folded, vae_cpu, y_hat, z_sem)
+        dt = time.perf_counter() - t0
+    n_idx = idx.numel()
+    oracle_bytes = 16 + len(stream) + (n_idx * 14 + 7) // 8
+    d = decode_i(product_blob, 14, 64)
+    # teacher-forced table-index agreement: the oracle's prior on the PRODUCT's z indices, fed the product's symbols
+    trace = []
+    idx_p = torch.from_numpy(np.asarray(
+        __import__("onedc_amd.entropy.utils", fromlist=["unpack_indices"]).unpack_indices(d["bit_stream_z"], n_idx, 14)
+    ).reshape(idx.shape).astype(np.int64))
+    model.codec_model.decompress([d["bit_stream_y"]], idx_p.to(model.device, torch.int32), trace=trace)
+    mism = total = 0
+    with torch.no_grad():
+        fused_p, _ = R.z_indices_to_params(codec_cpu, idx_p)
+
+        def hop(k, plane):
+            nonlocal mism, total
+            mism += int((plane.to(torch.int16).numpy() != trace[k][0]).sum())
+            total += plane.numel()
+            return torch.from_numpy(trace[k][1].astype(np.float32)).reshape(plane.shape)
+        R.decompress_four_part_prior(codec_cpu, fused_p, hop)
+    parity = {"picture": f"{S}x{S}", "stream_bytes_product": len(product_blob), "stream_bytes_oracle": oracle_bytes,
+              "bpp_product": round(len(product_blob) * 8 / (S * S), 5), "bpp_oracle": round(oracle_bytes * 8 / (S * S), 5),
+              "bpp_delta_rel": round(len(product_blob) / oracle_bytes - 1, 5),
+              "z_indices_equal": bool(torch.equal(idx_p, idx.long())),
+              "scale_index_mismatch_rate": round(mism / max(total, 1), 6), "scale_index_decisions": total,
+              "how": "free-running stream sizes from the same picture and latent noise; table indexes: the oracle's "
+                     "prior on the product's z indices, teacher-forced with the product's symbols, hop by hop"}
+    return ({"value": round(1.0 / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
+             "sample": f"oracle/torch_ref.py fp32 encode ({t_enc:.2f} s, rANS by oracle/rans_port.c) + decode of one "
+                       f"{S}x{S} picture in {dt:.2f} s on {cores} of {os.cpu_count()} host threads"}, parity)
+
+
+def pin_host_threads(local_rank, world):
+    """Keep this rank's host threads (rANS pool, pipeline workers, torch) on its own share of the host cores, next to
+    its GPU: rank r of w gets the r-th contiguous slice of the cores this process may use.  On the 8-GPU node (2 sockets,
+    4 GPUs each) contiguous slices keep a rank's threads on the socket of its GPU."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // world
+    if per < 2:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
 
 
 def main():
@@ -84,48 +188,79 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    pinned = pin_host_threads(local_rank, world)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.broadcast_weights:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     from onedc_amd import arch, synth
     from onedc_amd.dataparallel import broadcast_state_dicts, max_over_ranks
     from onedc_amd import kernels as K
     from onedc_amd.model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
 
-    specs = [arch.unet_spec(True), arch.codec_decode_spec(), arch.vae_decoder_spec()]
-    if rank == 0:
-        sds = [synth.unet_state_dict(0), synth.codec_state_dict(0), synth.vae_state_dict(0)]
-    else:
-        sds = [None, None, None]
-    if world > 1:
+    mode = args.mode
+    t_setup = time.perf_counter()
+    if args.broadcast_weights:
+        specs = [arch.unet_spec(True), arch.codec_decode_spec(), arch.vae_decoder_spec()]
+        sds = [synth.unet_state_dict(0), synth.codec_state_dict(0), synth.vae_state_dict(0)] if rank == 0 else [None] * 3
         sds_dev = broadcast_state_dicts(sds, specs, device, rank, world)
-    else:
-        sds_dev = sds
+    else:                                  # synthetic weights are a pure function of (key, seed): every rank builds its own
+        sds = sds_dev = [synth.unet_state_dict(0), synth.codec_state_dict(0), synth.vae_state_dict(0)]
     model = SD15_1step_codec_stage1({"vae_attn_patch": 16}, device=device).load_state_dicts(*sds_dev)
+    enc_sds = None
+    if mode == "encode_decode":
+        enc_sds = [synth.codec_encoder_state_dict(0), synth.hyper_enc_state_dict(0), synth.vae_encoder_state_dict(0)]
+        model.load_encoder_state_dicts(*enc_sds)
     model.codec_model.update(force=True)
+    t_setup = time.perf_counter() - t_setup
 
-    # ---- synthetic bitstreams of the right shape (made by the product's own encoder side) ----------
     B, S = args.batch, args.size
     zh = S // 64
     rng = np.random.default_rng(1000 + rank)
-    idx = torch.from_numpy(rng.integers(0, 16384, (B, zh, zh)).astype(np.int32)).to(device)
-    blobs, _ = model.codec_model.encode_latents(idx, None, noise_seed=2 + rank)
+    images = noise = None
+    if mode == "decode":
+        # synthetic bitstreams of the right shape, made by the product's own encoder side of the prior
+        idx = torch.from_numpy(rng.integers(0, 16384, (B, zh, zh)).astype(np.int32)).to(device)
+        blobs, _ = model.codec_model.encode_latents(idx, None, noise_seed=2 + rank)
+    elif mode == "z_only":
+        from onedc_amd.entropy.utils import encode_i, pack_indices
+        idx = rng.integers(0, 16384, (B, zh * zh)).astype(np.int32)
+        blobs = [encode_i(S, S, b"", pack_indices(idx[b], 14), b"", 0) for b in range(B)]
+    else:
+        # uniform-noise-plus-gradient RGB in [-1, 1]
+        g = torch.Generator(device=device).manual_seed(3 + rank)
+        ramp = torch.linspace(-0.5, 0.5, S, device=device)
+        images = (0.5 * (torch.rand(B, 3, S, S, generator=g, device=device) * 2 - 1) + ramp[None, None, :, None] * 0.5 +
+                  ramp[None, None, None, :] * 0.5).clamp(-1, 1).contiguous()
+        noise = torch.randn(B, S // 8, S // 8, 4, generator=g, device=device)
+        blobs, _ = model.encode(images, noise=noise)
     stream_bytes = sum(len(b) for b in blobs)
-    del sds_dev
+    if args.broadcast_weights:
+        del sds_dev
     torch.cuda.empty_cache()
 
-    # One step = one whole decode of one batch.  Default: the two-stage pipeline (the rANS hops of
-    # batch n+1 overlap the UNet / VAE of batch n; all K batches start and finish inside the timed
-    # region).  --sequential times K back-to-back model.decode() calls instead.
-    pipe = None if args.sequential else model.pipeline(s_streams=args.s_streams)
+    # One step = one whole pass over one batch.  decode / z_only default: the pipeline (the entropy stage of batch n+1
+    # overlaps the UNet / VAE of batch n; all K batches start and finish inside the timed region).
+    pipe = None
+    if not args.sequential and mode != "encode_decode":
+        pipe = model.pipeline(s_streams=args.s_streams, z_only=(mode == "z_only"))
+
+    def one_sequential():
+        if mode == "decode":
+            return model.decode(stream=blobs)
+        if mode == "z_only":
+            return model.decode_z_only_stream(stream=blobs)
+        bl, _ = model.encode(images, noise=noise)
+        return model.decode(stream=bl)
 
     def run(k):
         if pipe is None:
-            return [model.decode(stream=blobs) for _ in range(k)][-1]
+            return [one_sequential() for _ in range(k)][-1]
         return pipe.map([blobs] * k)[-1]
 
     if args.warmup:
@@ -147,12 +282,12 @@ def main():
     elapsed = max_over_ranks(elapsed, device, world)
 
     # The timed region runs several batches at once (the pipeline's streams): a kernel's event-bracketed duration
-    # there includes the time it shares the GPU with kernels of other batches.  One more, untimed, sequential decode
+    # there includes the time it shares the GPU with kernels of other batches.  One more, untimed, sequential pass
     # gives the same per-launch figures with the GPU to itself ("isolated" in the roofline object).
     iso = None
     if rank == 0 and pipe is not None:
         K.PROFILE = []
-        model.decode(stream=blobs)
+        one_sequential()
         torch.cuda.synchronize()
         iso, K.PROFILE = K.PROFILE, None
 
@@ -166,66 +301,89 @@ def main():
             d[3] += nbytes
         dom = max(by_tile, key=lambda k: by_tile[k][1])
         flops, secs, launches, dom_bytes = by_tile[dom]
+        kernel_symbol = {"256x256": "conv_gemm256_kernel", "128x256": "conv_gemm128x256_kernel", "win3x3": "conv_win_kernel",
+                         "ups2x2": "conv_ups_kernel"}.get(dom, f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
+                                                           + (" f32" if dom.startswith("f32") else ""))
         # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in
         # separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) and committed under
         # profiles/; PMC passes serialise every dispatch, so they cannot run inside the timed region.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tpath):
-            t = json.load(open(tpath)).get({"256x256": "conv_gemm256_kernel", "128x256": "conv_gemm128x256_kernel",
-                                            "win3x3": "conv_win_kernel", "ups2x2": "conv_ups_kernel"}.get(dom, dom))
-            if t:
-                traffic = t["hbm_bytes_per_launch"]
+        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if mode == "decode" and os.path.exists(tpath):
+                t = json.load(open(tpath)).get(kernel_symbol)
+                if t:
+                    traffic = t["hbm_bytes_per_launch"]
+                    break
         all_flops = sum(v[0] for v in by_tile.values())
         all_secs = sum(v[1] for v in by_tile.values())
         achieved = flops / secs / 1e12
-        images = B * world * args.steps
-        value = images / elapsed
+        images_done = B * world * args.steps
+        value = images_done / elapsed
+        metric = {"decode": f"{S}x{S} images/sec decode (whole node)",
+                  "z_only": f"{S}x{S} images/sec decode, ex-low-rate z-only model (whole node)",
+                  "encode_decode": f"{S}x{S} images/sec encode + decode (whole node)"}[mode]
+        workload = {
+            "decode": f"{S}x{S} batch={B}/GPU decode, lambda=4.6-shaped model (random-init weights of the real architecture)",
+            "z_only": f"{S}x{S} batch={B}/GPU decode of indices-only streams, ex-low-rate 0.0034-bpp z-only model "
+                      f"(sd15_onedc_codec_z_only; random-init weights of the real architecture)",
+            "encode_decode": f"{S}x{S} batch={B}/GPU full encode path (SD-VAE encoder, analysis transform, hyperprior, "
+                             f"four-part prior, host rANS encode) + decode, lambda=4.6-shaped model (random-init weights)",
+        }[mode] + f", {model.act} MFMA / fp32 accumulate, {world}xMI355X"
         line = {
-            "metric": "768x768 images/sec decode (whole node)", "value": round(value, 3), "unit": "images/s",
+            "metric": metric, "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{S}x{S} batch={B}/GPU decode, lambda=4.6-shaped model (random-init weights "
-                                   f"of the real architecture), bf16 MFMA / fp32 accumulate, {world}xMI355X",
+            "vs_baseline": None, "dtype": model.act, "data": "synthetic",
+            "config": {"workload": workload, "mode": mode,
                        "images_per_gpu_per_step": B, "picture": f"{S}x{S}", "parallelism": f"dp{world}",
                        "stream_bytes_per_image": stream_bytes // B, "host_rans_threads": model.codec_model.host_threads,
-                       "timed": "container parse + host rANS + H2D/D2H + all device kernels + crop",
+                       "host_cores_of_rank0": len(pinned) if pinned else len(os.sched_getaffinity(0)),
+                       "weights": "rank 0 builds, one flat RCCL broadcast" if args.broadcast_weights else
+                                  "every rank builds the deterministic synthetic weights itself",
+                       "setup_s": round(t_setup, 1),
+                       "arithmetic": f"{model.act} storage and MFMA operands (synthesis, UNet, VAE), exact f32 MFMA (prior "
+                                     f"networks, VAE conv_in), f64 (eps -> x0), f32 accumulation everywhere",
+                       "timed": {"decode": "container parse + host rANS + H2D/D2H + all device kernels + crop",
+                                 "z_only": "container parse + index unpack + H2D + all device kernels + crop",
+                                 "encode_decode": "encode (all device kernels + D2H + host rANS + container) then decode "
+                                                  "(as in decode mode) of the streams just written"}[mode],
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
-                       "schedule": "sequential decode() calls" if args.sequential else
+                       "schedule": "sequential calls" if pipe is None else
                                    f"pipeline over batches: entropy stage of batch n+1 on its own stream || synthesis+UNet+VAE "
                                    f"of {args.s_streams} batches on {args.s_streams} streams"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA16_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(dom_bytes / launches),
-                         "kernel": ("conv_gemm256_kernel" if dom == "256x256" else
-                                    "conv_gemm128x256_kernel" if dom == "128x256" else
-                                    "conv_win_kernel" if dom == "win3x3" else
-                                    f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
-                                    + (" f32" if dom.startswith("f32") else "")),
+                         "kernel": kernel_symbol,
                          "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.steps * 1e3, 2),
                                            "launches_per_step": v[2] // args.steps} for k, v in sorted(by_tile.items())},
                          "launches_per_step": launches // args.steps,
                          "avg_launch_us": round(secs / launches * 1e6, 2),
                          "algorithmic_gflop_per_step": round(flops / args.steps / 1e9, 1),
                          "all_conv_gemm_tflops": round(all_flops / all_secs / 1e12, 2),
-                         "conv_gemm_share_of_step": round(all_secs / elapsed, 3),
-                         "whole_path_tflops": round(value / world * GFLOP_PER_IMAGE.get(S, 0) / 1e3, 2)},
+                         "conv_gemm_share_of_step": round(all_secs / elapsed, 3)},
         }
+        if mode != "encode_decode":
+            line["roofline"]["whole_path_tflops"] = round(value / world * GFLOP_PER_IMAGE.get(S, 0) / 1e3, 2)
         if iso:
             it = [(f, e0.elapsed_time(e1) * 1e-3) for tile, f, e0, e1, _ in iso if tile == dom]
             if it:
                 f_iso, s_iso = sum(f for f, _ in it), sum(t for _, t in it)
                 line["roofline"]["isolated"] = {
-                    "achieved": round(f_iso / s_iso / 1e12, 2), "frac": round(f_iso / s_iso / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "achieved": round(f_iso / s_iso / 1e12, 2), "frac": round(f_iso / s_iso / 1e12 / PEAK_MFMA16_TFLOPS, 4),
                     "avg_launch_us": round(s_iso / len(it) * 1e6, 2), "launches": len(it),
-                    "how": "same kernel, one untimed sequential decode after the timed region (no other batch on the GPU)"}
+                    "how": "same kernel, one untimed sequential pass after the timed region (no other batch on the GPU)"}
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_threads, sds[1], sds[0], sds[2])
+            if mode == "encode_decode":
+                line["cpu_baseline"], line["parity"] = cpu_baseline_encode_decode(
+                    model, images[:1], noise[:1], args.cpu_threads, sds, enc_sds, model.encode(images[:1], noise=noise[:1])[0])
+            else:
+                line["cpu_baseline"] = cpu_baseline_decode(args.cpu_sample, args.cpu_threads, sds, z_only=(mode == "z_only"))
         print(json.dumps(line), flush=True)
     if pipe is not None:
         pipe.close()
-    if world > 1:
+    if world > 1 or args.broadcast_weights:
         dist.barrier()
         dist.destroy_process_group()
 

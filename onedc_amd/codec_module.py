@@ -333,6 +333,30 @@ class IntraNoAR:
         orig_hw = [(d["height"], d["width"]) for d in infos]
         return y_hat, z_semantic, orig_hw, (pad_h, pad_w), infos[0]["pad_tuple"]
 
+    @K.in_own_format
+    @torch.no_grad()
+    def decode_entropy_z_only(self, fp=None, stream=None):
+        """The ex-low-rate model's entropy stage (sd15_onedc_codec_z_only: y is never transmitted): containers whose y
+        part is empty -- 16 B header + ceil(14 n / 8) B of FSQ indices, 252 B of payload at 768x768 -- -> the same tuple as
+        `decode_entropy`, with y_hat = the prior's means (forward_four_part_prior_recon_with_z,
+        compression_model.py:421-465).  No rANS hop, no host synchronisation."""
+        assert fp or stream
+        blobs = stream if stream else [read_from_file(f) for f in ([fp] if isinstance(fp, str) else fp)]
+        if isinstance(blobs, (bytes, bytearray)):
+            blobs = [blobs]
+        infos = [decode_i(b, self.index_unit_length, self.ds) for b in blobs]
+        hw = {(d["pad_height"], d["pad_width"]) for d in infos}
+        if len(hw) != 1:
+            raise ValueError("a batch must share one padded picture size")
+        if any(len(d["bit_stream_y"]) for d in infos):
+            raise ValueError("a z-only container carries no y stream: decode it with decode_entropy / decode")
+        pad_h, pad_w = hw.pop()
+        zh, zw = pad_h // self.ds, pad_w // self.ds
+        idx = np.stack([unpack_indices(d["bit_stream_z"], zh * zw, self.index_unit_length) for d in infos])
+        indices = torch.from_numpy(idx.reshape(len(blobs), zh, zw)).to(self.device)
+        y_hat, z_semantic = self.recon_with_z(indices)
+        return y_hat, z_semantic, [(d["height"], d["width"]) for d in infos], (pad_h, pad_w), infos[0]["pad_tuple"]
+
     # ------------------------------------------------------------------ encode side
     @K.in_own_format
     def load_hyper_encoder(self, sd):

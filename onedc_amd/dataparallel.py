@@ -17,7 +17,9 @@ def shard(n_items, rank, world):
 
 def broadcast_state_dicts(sds, specs, device, rank, world, dist=None):
     """Rank 0 owns the weights (`sds`: list of state dicts, ignored elsewhere); `specs` (list of
-    {key: shape}) is known to every rank.  ONE flat fp32 broadcast, then views into the flat buffer."""
+    {key: shape}) is known to every rank.  ONE flat fp32 broadcast, then views into the flat buffer.
+    The collective is issued whenever a process group exists, also for a group of one (a single-GPU run of
+    `bench.py --broadcast-weights` exercises RCCL initialisation and the broadcast on the device buffer)."""
     if dist is None:
         import torch.distributed as dist
     total = sum(int(np.prod(s)) for spec in specs for s in spec.values())
@@ -29,7 +31,7 @@ def broadcast_state_dicts(sds, specs, device, rank, world, dist=None):
                 n = int(np.prod(shape))
                 flat[off:off + n] = sd[k].reshape(-1).to(device=device, dtype=torch.float32)
                 off += n
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.broadcast(flat, src=0)
     out, off = [], 0
     for spec in specs:
@@ -44,10 +46,10 @@ def broadcast_state_dicts(sds, specs, device, rank, world, dist=None):
 
 def max_over_ranks(value, device, world, dist=None):
     """The job's step time is the slowest rank's."""
-    if world <= 1:
-        return float(value)
     if dist is None:
         import torch.distributed as dist
+    if world <= 1 and not (dist.is_available() and dist.is_initialized()):
+        return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -83,7 +83,9 @@ class SD15_1step_codec_stage1:
         return self
 
     def load(self, checkpoint_path, vae_path=None):
-        """inference.py:87-93 + the VAE file the reference fetches from the hub."""
+        """inference.py:87-93 + the VAE file the reference fetches from the hub.  The ex-low-rate model
+        (models/sd15_onedc_codec_z_only) uses the same two files with the same key layout: its IntraNoAR declares the
+        same sub-modules as the stage-1 one (only `forward` differs), so its checkpoints load here unchanged."""
         ff = load_safetensor(os.path.join(checkpoint_path, "model.safetensors"))
         codec = load_safetensor(os.path.join(checkpoint_path, "model_1.safetensors"))
         vae_path = vae_path or os.path.join(checkpoint_path, "vae", "diffusion_pytorch_model.safetensors")
@@ -173,7 +175,10 @@ class SD15_1step_codec_stage1:
         streams = [encode_i(H, W, b"", pack_indices(idx_host[b].reshape(-1), cm.index_unit_length), b"", 0)
                    for b in range(B)]
         bits = (Hp // 64) * (Wp // 64) * 14
-        return {"indices": indices, "stream": streams, "bpp_z": bits / (H * W)}, recon
+        # bpp_hard_y: the harness's second column (z_only/inference.py:126).  In eval mode the z-only codec sets y_q = 0 and
+        # sigma = 0 (z_only/codec_module.py:252-254), so every symbol has probability 1 and the estimate is exactly 0
+        # (compression_model.py:137-150: -log2(1 + 1e-5) lower-bounded at 0)
+        return {"indices": indices, "stream": streams, "bpp_z": bits / (H * W), "bpp_hard_y": 0.0}, recon
 
     def prepare(self):
         return self
@@ -223,8 +228,16 @@ class SD15_1step_codec_stage1:
         K.image_out(image, res, H, W, unit_range)
         return res
 
-    def pipeline(self, depth=2, s_streams=2):
-        return DecodePipeline(self, depth, s_streams)
+    def pipeline(self, depth=2, s_streams=2, z_only=False):
+        """z_only: the batches are indices-only containers of the ex-low-rate model (`decode_z_only_stream`)."""
+        return DecodePipeline(self, depth, s_streams, z_only)
+
+    def decode_z_only_stream(self, fp=None, stream=None, unit_range=False):
+        """Decoder of the ex-low-rate model from files / byte strings: the 16 B + ceil(14 n / 8) B containers written by
+        `forward_z_only` / `python -m onedc_amd.inference_z_only` (the reference has no such entry: its z-only harness
+        runs `forward()` and never writes a stream, models/sd15_onedc_codec_z_only/inference.py:125)."""
+        with K.act_format(self.act), torch.no_grad(), torch.cuda.device(self.device):
+            return self._decode_after_entropy(self.codec_model.decode_entropy_z_only(fp=fp, stream=stream), unit_range)
 
     def decode_z_only(self, indices):
         with K.act_format(self.act):
@@ -257,10 +270,11 @@ class DecodePipeline:
     Hand-overs are HIP events; results are bit-identical to `decode` (same kernels, same order per batch;
     scratch buffers are per stream, layers.Workspace).  No inter-GPU traffic: one pipeline per process / GPU."""
 
-    def __init__(self, model, depth=2, s_streams=2):
+    def __init__(self, model, depth=2, s_streams=2, z_only=False):
         import queue
         import threading
         self.model = model
+        self.z_only = z_only
         self.dev = model.device
         with torch.cuda.device(self.dev):
             self.stream_e = torch.cuda.Stream(device=self.dev, priority=-1)
@@ -286,7 +300,8 @@ class DecodePipeline:
             blobs, job, split = item
             try:
                 with torch.cuda.stream(self.stream_e), torch.no_grad():
-                    out = self.model.codec_model.decode_entropy(stream=blobs)
+                    cm = self.model.codec_model
+                    out = cm.decode_entropy_z_only(stream=blobs) if self.z_only else cm.decode_entropy(stream=blobs)
                     ev = torch.cuda.Event()
                     ev.record(self.stream_e)
                 if split:

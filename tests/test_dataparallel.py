@@ -85,3 +85,30 @@ def test_shard_is_a_partition():
             parts = [shard(n, r, world) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_rccl_broadcast_on_one_gpu(tmp_path):
+    """The launch line the driver uses for N > 1, with N = 1 (the only size a 1-GPU box allows):
+    `python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1 --broadcast-weights` -- process-group
+    initialisation on the nccl (= RCCL) backend, the flat weight broadcast on the DEVICE buffer, the barrier-bracketed
+    timed region and the MAX reduction all run on hardware.  Started as a fresh child process, and only while this
+    process has not touched the GPU (this file sorts in front of the tests/test_gpu_* files for that reason)."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already initialised the GPU: a child launch from here is not allowed on the pool")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--broadcast-weights", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["weights"].startswith("rank 0 builds") and line["config"]["images_per_gpu_per_step"] == 4
+    assert not torch.cuda.is_initialized()

@@ -505,3 +505,50 @@ def test_z_only_harness_forward(full_model):
     K.nchw_to_nhwc(img, iv.slice(0, 3), reflect=True)
     ref = torch.nn.functional.pad(img.cpu(), (0, 22, 0, 28), mode="reflect")
     assert torch.equal(iv.slice(0, 3).torch_nchw().cpu(), ref)
+
+
+def test_z_only_cli_harness_on_a_folder(tmp_path):
+    """`python -m onedc_amd.inference_z_only` (reference: models/sd15_onedc_codec_z_only/inference.py:93-161) on
+    synthetic checkpoint FILES and a picture folder: recon/, the two tables with the reference's columns, the
+    indices-only .bin (16 B + ceil(14 n / 8) B), and --decoder_only on those files reproduces the pictures."""
+    import pandas as pd
+    import yaml
+    from PIL import Image
+    from safetensors.torch import save_file
+    from onedc_amd import inference_z_only
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    save_file(synth.unet_state_dict(0), str(ckpt / "model.safetensors"))
+    codec_full = dict(synth.codec_state_dict(0))
+    codec_full.update(synth.codec_encoder_state_dict(0))
+    codec_full.update(synth.hyper_enc_state_dict(0))
+    save_file(codec_full, str(ckpt / "model_1.safetensors"))
+    vae_full = dict(synth.vae_state_dict(0))
+    vae_full.update(synth.vae_encoder_state_dict(0))
+    save_file(vae_full, str(ckpt / "vae.safetensors"))
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump({"vae_attn_patch": 16, "conditioning_timestep": 999}))
+    pics = tmp_path / "pics"
+    pics.mkdir()
+    rng = np.random.default_rng(71)
+    sizes = {"a": (100, 170), "b": (128, 192), "c": (128, 192)}
+    for name, (h, w) in sizes.items():
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(pics / f"{name}.png")
+    out = tmp_path / "out"
+    common = ["--config_path", str(tmp_path / "cfg.yaml"), "--checkpoint_path", str(ckpt), "--vae_path", str(ckpt / "vae.safetensors")]
+    avg = inference_z_only.main(common + ["--output_path", str(out), "--eval_image_path", str(pics)])
+    detail = pd.read_csv(out / "detail_bpp_caption.xlsx")
+    assert list(detail["image_name"]) == ["a", "b", "c"] and {"bpp_hard_y", "bpp_z"} <= set(detail.columns)
+    assert abs(detail["bpp_z"][0] - 6 * 14 / (100 * 170)) < 1e-12 and abs(detail["bpp_z"][1] - 6 * 14 / (128 * 192)) < 1e-12
+    assert float(detail["bpp_hard_y"].abs().max()) == 0.0 and abs(avg["bpp_z"] - detail["bpp_z"].mean()) < 1e-12
+    for name, (h, w) in sizes.items():
+        assert Image.open(out / "recon" / f"{name}.png").size == (w, h)
+        assert (out / "stream" / f"{name}.bin").stat().st_size == 16 + 11          # 6 indices x 14 bit -> 11 bytes
+    # decoder only: one file, then the folder (b and c share a size and go through one batch)
+    inference_z_only.main(common + ["--decoder_only", "--decoder_bin_path", str(out / "stream" / "a.bin"),
+                                    "--decoder_out_path", str(tmp_path / "a2.png")])
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "a2.png")), np.asarray(Image.open(out / "recon" / "a.png")))
+    inference_z_only.main(common + ["--decoder_only", "--decoder_bin_path", str(out / "stream"),
+                                    "--decoder_out_path", str(tmp_path / "dec")])
+    for name in sizes:
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "dec" / f"{name}.png")),
+                              np.asarray(Image.open(out / "recon" / f"{name}.png")))
