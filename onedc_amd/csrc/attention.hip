@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
     // that tile's PV product (O and the riding row sum are scaled together), so no register between the
     // S product and the PV product is ever touched by the rare path.
 #ifdef ONEDC_ACT_F16
-    constexpr float FA64_THR = 8.f;                  // P <= 2^8 per element, its row sums far below 65504
+    constexpr float FA64_THR = 8.f;                  // the reference follows the scores more closely than with bf16 ...
+    constexpr float FA64_CLAMP = 15.f;               // ... and no P element can leave the IEEE-half range
 #else
     constexpr float FA64_THR = 12.f;
 #endif
@@ -493,31 +494,46 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
         if (MASK) mask_tail(s, k0);
         float tmax[QT];
         lane_max(s, tmax);
-#ifdef ONEDC_ACT_F16
-        // IEEE-half P: exp2(s - m_run) must stay below 65504, so a tile that exceeds the reference by more than the
-        // threshold moves it BEFORE the exponentials (O and the riding row sum are rescaled, the scores of this tile are
-        // shifted by the same exact amount); bf16 has f32's exponent range and takes the cheaper order below.
-        {
-            const float wmax0 = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
-            if (__any(wmax0 > FA64_THR)) {          // wave-uniform, rare
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    const float inc = move_ref(t, fmaxf(tmax[t], 0.f), true);
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[kt][t][e] -= inc;
-                }
-            }
-        }
-#endif
         a16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s[kt][t][e] = __builtin_amdgcn_exp2f(s[kt][t][e]);
+                for (int e = 0; e < 4; ++e) {
+#ifdef ONEDC_ACT_F16
+                    s[kt][t][e] = __builtin_amdgcn_exp2f(fminf(s[kt][t][e], FA64_CLAMP));     // P <= 2^15 < 65504
+#else
+                    s[kt][t][e] = __builtin_amdgcn_exp2f(s[kt][t][e]);
+#endif
+                }
+        }
+#ifdef ONEDC_ACT_F16
+        // IEEE-half P cannot hold exp2 of an arbitrary excess over the reference (bf16 can: f32's exponent range).  The
+        // exponentials above are clamped at 2^15 and do not wait for the row maxima; only if a score really exceeded the
+        // clamp (a jump of more than 2^15 between the reference and a later tile: next to never) the reference moves
+        // NOW, before the PV product, and the tile's scores are recomputed against it.
+        {
+            const float wmax0 = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
+            if (__any(wmax0 > FA64_CLAMP)) {        // wave-uniform
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
+                    tmax[t] = 0.f;
+                }
+                s_chain(ldsK, s);
+                if (MASK) mask_tail(s, k0);
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[kt][t][e] = __builtin_amdgcn_exp2f(fminf(s[kt][t][e], FA64_CLAMP));
+            }
+        }
+#endif
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 union { a16x8 v; uint32_t u[4]; } pk;
@@ -538,13 +554,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
                 for (int t = 0; t < QT; ++t)
                     o[d][t] = ONEDC_MFMA16(vf, pf[t][st], o[d][t]);
             }
-#ifndef ONEDC_ACT_F16
         const float wmax = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
         if (__any(wmax > FA64_THR)) {               // wave-uniform, rare
 #pragma unroll
             for (int t = 0; t < QT; ++t) (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
         }
-#endif
     };
 
     const int ntiles = (Nk + 63) >> 6;

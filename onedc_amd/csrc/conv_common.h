@@ -21,6 +21,23 @@ __device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned
                                              (int)soff, 0, 0);
 }
 
+// Division of a non-negative 31-bit integer by a launch constant as one multiply-high and a shift (the divisor's magic
+// pair is computed on the host): tile decoding sits in front of a workgroup's first DMA, where a 25-instruction software
+// division per quotient is dead time on every CU.
+struct OnedcFastDiv {
+    uint32_t mul, shift;
+    __host__ __device__ explicit OnedcFastDiv(uint32_t d = 1) : mul(0), shift(0) {
+        if (d > 1) {
+            while ((1ull << shift) < d) ++shift;                          // ceil(log2 d)
+            mul = (uint32_t)(((uint64_t)1 << (31 + shift)) / d + 1);     // Granlund-Montgomery, 31-bit numerators
+        }
+    }
+    // exact for 0 <= x < 2^31
+    __device__ __forceinline__ int div(int x) const {
+        return mul ? (int)(((uint64_t)(uint32_t)x * mul) >> (31 + shift)) : x;
+    }
+};
+
 // XCD-aware bijective remap of the launch index: consecutive logical tiles land on one XCD (one L2).
 __device__ __forceinline__ int xcd_logical_tile(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
@@ -74,6 +91,21 @@ struct ConvPixSrc {
             off[i] = in ? pix * (unsigned)pix_bytes + lane_off : oob;
         }
     }
+    // 1x1 / stride 1 / pad 0 layers (two thirds of all launches: every Linear of the transformer blocks, every 1x1 of
+    // the DepthConvBlocks): input pixel == output pixel, nothing to decode -- the general init + tap above cost some 200
+    // instructions of integer division per lane in front of a workgroup's first DMA
+    __device__ __forceinline__ void init_linear(const char *xb0, int pix_bytes, const int (&m)[NP], int M) {
+        valid = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const bool in = m[i] < M;
+            valid |= in ? (1u << i) : 0u;
+            base[i] = 0;
+            iyx0[i] = 0;
+            src[i] = xb0 + (int64_t)(in ? m[i] : 0) * pix_bytes;
+        }
+        ok = valid;
+    }
     // xb0 = input base + (x_co * elem + chunk * 16) bytes; pix_bytes = x_cs * elem
     __device__ __forceinline__ void tap(const onedc_conv_params &p, const char *xb0, int pix_bytes, int ky, int kx) {
         ok = 0;
@@ -100,6 +132,10 @@ struct ConvPixSrc {
 // XCD) -- measured HBM reads of the 256-tile kernel were 4.6x the input bytes.  With patch16 the tile is a
 // 16 x 16 patch: its nine taps touch one 18 x 18 window (1.27x the patch), and tiles that follow each other
 // on an XCD are neighbouring patches.  Needs OH, OW multiples of 16.
+__device__ __forceinline__ bool conv_is_linear(const onedc_conv_params &p) {      // wave-uniform (kernel arguments only)
+    return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.up && p.IH == p.OH && p.IW == p.OW;
+}
+
 struct ConvPatch {
     int img, y0, x0;      // patch origin of this workgroup's pixel tile (patch16 only)
     bool on;
@@ -351,7 +387,10 @@ __host__ __device__ __forceinline__ bool conv_epi_fast_ok(const onedc_conv_param
     return !p.out_f32 && !p.pixel_shuffle && !glu && ((p.y_cs | p.y_co | p.Cout) & 3) == 0 &&
            (p.epi == ONEDC_EPI_LINEAR || p.epi == ONEDC_EPI_LEAKY || p.epi == ONEDC_EPI_SILU);
 }
-template <int ACT>   // ONEDC_EPI_LINEAR / _LEAKY / _SILU: the four bf16 values of one tile, packed
+// STATS: -1 = decided at run time from p.stats / p.stats_gran (branch-free selects: 6 extra instructions per quad),
+// 0 = none, 4 = one entry per channel quad, 2 = per channel pair (the compile-time forms do exactly the same operations
+// in the same order: bit-identical sums)
+template <int ACT, int STATS = -1>   // ONEDC_EPI_LINEAR / _LEAKY / _SILU: the four 16-bit values of one tile, packed
 __device__ __forceinline__ uint2 conv_epi_fast_value(const onedc_conv_params &p, const f32x4 &accv, const float4 &bias,
                                                      const uint2 &res, float &ssum, float &ssq, float &ssum_hi,
                                                      float &ssq_hi) {
@@ -369,7 +408,15 @@ __device__ __forceinline__ uint2 conv_epi_fast_value(const onedc_conv_params &p,
     v[1] += a2f((a16_t)(res.x >> 16));
     v[2] += a2f((a16_t)(res.y & 0xffff));
     v[3] += a2f((a16_t)(res.y >> 16));
-    if (p.stats) {
+    if (STATS == 4) {
+        ssum = (((ssum + v[0]) + v[1]) + v[2]) + v[3];
+        ssq = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq))));
+    } else if (STATS == 2) {
+        ssum = (ssum + v[0]) + v[1];
+        ssq = __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq));
+        ssum_hi = (ssum_hi + v[2]) + v[3];
+        ssq_hi = __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], ssq_hi));
+    } else if (STATS == -1 && p.stats) {
         const bool pairs = p.stats_gran == 2;
         const float s_lo = (ssum + v[0]) + v[1];
         const float q_lo = __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[0], v[0], ssq));

@@ -68,38 +68,53 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         const int row = (wave + 4 * i) * 8 + lrow;
         wsrc[i] = wb + ((int64_t)(n0 + row) * Ktot) * ES + chunk * 16;
     }
-    ConvPixSrc<T::NPI> px;
-    {
-        int mrow[T::NPI];
-#pragma unroll
-        for (int i = 0; i < T::NPI; ++i) mrow[i] = m0 + (wave + 4 * i) * 8 + lrow;
-        px.init(p, mrow, M);
-    }
-    const char *xb0 = xb + p.x_co * ES + chunk * 16;
-    const int pix_bytes = p.x_cs * ES;
     const int nc = p.Cin >> KSH;                   // 128-byte steps per tap
     const int steps = p.KH * p.KW * nc;
-
-    auto tap_sources = [&](int tap) {
-        const int ky = tap / p.KW;
-        px.tap(p, xb0, pix_bytes, ky, tap - ky * p.KW);
-    };
-
-    auto issue = [&](int step, int tap, int ci, char *buf) {
+    // weights of step 0 leave first: their addresses need nothing but the channel tile, the pixel sources below
+    // (a decode per row unless the layer is 1x1) are then worked out under that latency
+    auto issue_w = [&](int tap, int ci, char *buf) {
         const int64_t kbyte = (int64_t)tap * p.Cin * ES + ci * 128;
 #pragma unroll
         for (int i = 0; i < T::NWI; ++i) {
             const int blk = wave + 4 * i;          // wave-uniform
             if (T::WBLK % 4 == 0 || blk < T::WBLK) glds16(wsrc[i] + kbyte, buf + blk * 1024);
         }
+    };
+    issue_w(0, 0, smem);
+    __builtin_amdgcn_sched_barrier(0);
+
+    ConvPixSrc<T::NPI> px;
+    const char *xb0 = xb + p.x_co * ES + chunk * 16;
+    const int pix_bytes = p.x_cs * ES;
+    const bool linear = conv_is_linear(p);
+    {
+        int mrow[T::NPI];
+#pragma unroll
+        for (int i = 0; i < T::NPI; ++i) mrow[i] = m0 + (wave + 4 * i) * 8 + lrow;
+        if (linear) px.init_linear(xb0, pix_bytes, mrow, M);
+        else px.init(p, mrow, M);
+    }
+
+    auto tap_sources = [&](int tap) {
+        const int ky = tap / p.KW;
+        px.tap(p, xb0, pix_bytes, ky, tap - ky * p.KW);
+    };
+    auto issue_px = [&](int ci, char *buf) {
         const int cbyte = ci * 128;
 #pragma unroll
         for (int i = 0; i < T::NPI; ++i) {
             glds16(((px.ok >> i) & 1) ? px.src[i] + cbyte : zeros + chunk * 16,
                    buf + (T::WBLK + wave + 4 * i) * 1024);
         }
+    };
+    auto issue = [&](int step, int tap, int ci, char *buf) {
+        issue_w(tap, ci, buf);
+        issue_px(ci, buf);
         (void)step;
     };
+    if (!linear) tap_sources(0);
+    issue_px(0, smem);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- accumulators ---------------------------------------------------------------------------
     f32x4 acc[T::FI][T::FJ];
@@ -115,10 +130,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     const int a_base = (wn * T::WTN) * 128;
     const int b_base = (TN + wm * T::WTM) * 128;
 
+    // fragment addresses exist before the first wait (an empty asm the optimiser cannot look through keeps their
+    // arithmetic from sinking behind it, onto the critical path of every workgroup)
+    asm volatile("" : "+v"(foff[0]), "+v"(foff[1]));
     // ---- main loop: one barrier per K-step, next step's DMA in flight during the MFMAs -------------
     int tap = 0, ci = 0;
-    tap_sources(0);
-    issue(0, 0, 0, smem);
     for (int s = 0; s < steps; ++s) {
         char *cur = smem + (s & 1) * T::BUF;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

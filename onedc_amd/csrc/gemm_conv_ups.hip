@@ -229,14 +229,15 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     lds_char *const my = (lds_char *)smem + wave * 8192;
-    auto finish = [&](auto act) {
+    auto finish = [&](auto act, auto stats_mode) {
+        constexpr int ST = decltype(stats_mode)::value;
         constexpr int ACT = decltype(act)::value;
 #pragma unroll
         for (int bj = 0; bj < 4; ++bj) {
             const int px = bj * 16 + frow;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint2 o = conv_epi_fast_value<ACT>(p, acc[i][bj >> 1][bj & 1], bias[i], make_uint2(0u, 0u), ssum[i],
+                const uint2 o = conv_epi_fast_value<ACT, ST>(p, acc[i][bj >> 1][bj & 1], bias[i], make_uint2(0u, 0u), ssum[i],
                                                          ssq[i], ssum_hi[i], ssq_hi[i]);
                 const int s8 = i * 4 + fq;             // 8-byte slot of the pixel's 128-byte row
                 *(__attribute__((address_space(3))) u32x2_t *)(my + px * 128 + (((s8 >> 1) ^ (px & 7)) << 4) + (s8 & 1) * 8) =
@@ -244,9 +245,14 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
             }
         }
     };
-    if (p.epi == ONEDC_EPI_SILU) finish(std::integral_constant<int, ONEDC_EPI_SILU>());
-    else if (p.epi == ONEDC_EPI_LEAKY) finish(std::integral_constant<int, ONEDC_EPI_LEAKY>());
-    else finish(std::integral_constant<int, ONEDC_EPI_LINEAR>());
+    auto with_stats = [&](auto act) {              // compile-time statistics mode, as in gemm_conv_win.hip
+        if (!p.stats) finish(act, std::integral_constant<int, 0>());
+        else if (p.stats_gran == 2) finish(act, std::integral_constant<int, 2>());
+        else finish(act, std::integral_constant<int, 4>());
+    };
+    if (p.epi == ONEDC_EPI_SILU) with_stats(std::integral_constant<int, ONEDC_EPI_SILU>());
+    else if (p.epi == ONEDC_EPI_LEAKY) with_stats(std::integral_constant<int, ONEDC_EPI_LEAKY>());
+    else with_stats(std::integral_constant<int, ONEDC_EPI_LINEAR>());
     {
         const int c = lane & 7;
 #pragma unroll
@@ -268,17 +274,18 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
 }
 
 __global__ __launch_bounds__(512, 2) void conv_ups_kernel(const onedc_conv_params p, int tiles_n, int tiles_x, int tiles_y,
-                                                          int Ktot) {
+                                                          int Ktot, OnedcFastDiv dv_n, OnedcFastDiv dv_pi, OnedcFastDiv dv_x,
+                                                          OnedcFastDiv dv_c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // channel tile fastest, then x, y, image; a channel tile belongs to one phase (C % 128 == 0)
     const int tiles_pi = tiles_x * tiles_y;
     const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_pi * p.B);
-    const int n0 = (logical % tiles_n) * 128;
-    const int pt = logical / tiles_n;
-    const int img = pt / tiles_pi, pin = pt - img * tiles_pi;
-    const int ty = pin / tiles_x, tx = pin - ty * tiles_x;
+    const int pt = dv_n.div(logical);
+    const int n0 = (logical - pt * tiles_n) * 128;
+    const int img = dv_pi.div(pt), pin = pt - img * tiles_pi;
+    const int ty = dv_x.div(pin), tx = pin - ty * tiles_x;
     const int y0 = ty * 16, x0 = tx * 16;            // low-resolution origin of the patch
-    const int phase = n0 / p.Cout;
+    const int phase = dv_c.div(n0);
     switch (phase) {
         case 0: ups_body<0, 0>(p, smem, n0, pt, img, pin, y0, x0, tiles_n, tiles_pi, Ktot); break;
         case 1: ups_body<0, 1>(p, smem, n0, pt, img, pin, y0, x0, tiles_n, tiles_pi, Ktot); break;
@@ -305,7 +312,9 @@ int onedc_conv_ups_launch(const onedc_conv_params &p, hipStream_t st) {
     const int Ktot = 4 * p.Cin;
     const int64_t blocks = (int64_t)tiles_n * tiles_x * tiles_y * p.B;
     if (blocks > 0x7fffffff) return -1;
-    hipLaunchKernelGGL(conv_ups_kernel, dim3((unsigned)blocks), dim3(512), UPS_LDS, st, p, tiles_n, tiles_x, tiles_y, Ktot);
+    hipLaunchKernelGGL(conv_ups_kernel, dim3((unsigned)blocks), dim3(512), UPS_LDS, st, p, tiles_n, tiles_x, tiles_y, Ktot,
+                       OnedcFastDiv((uint32_t)tiles_n), OnedcFastDiv((uint32_t)(tiles_x * tiles_y)), OnedcFastDiv((uint32_t)tiles_x),
+                       OnedcFastDiv((uint32_t)p.Cout));
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

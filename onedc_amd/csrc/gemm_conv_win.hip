@@ -44,7 +44,8 @@ constexpr int WIN_LDS = WIN_NA * WIN_A + 2 * WIN_W;   // 133120 B
 
 template <bool UP, bool NORM>
 __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_params p, int tiles_n, int tiles_x,
-                                                          int tiles_y, int Ktot) {
+                                                          int tiles_y, int Ktot, OnedcFastDiv dv_n, OnedcFastDiv dv_pi,
+                                                          OnedcFastDiv dv_x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef EXP_WIN_TIMELINE
     unsigned long long tl[6];
@@ -67,10 +68,10 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     // ---- patch of this workgroup: channel tile fastest, then x, y, image --------------------------------
     const int tiles_pi = tiles_x * tiles_y;
     const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_pi * p.B);
-    const int n0 = (logical % tiles_n) * 128;
-    const int pt = logical / tiles_n;               // patch index over all images
-    const int img = pt / tiles_pi, pin = pt - img * tiles_pi;
-    const int ty = pin / tiles_x, tx = pin - ty * tiles_x;
+    const int pt = dv_n.div(logical);               // patch index over all images
+    const int n0 = (logical - pt * tiles_n) * 128;
+    const int img = dv_pi.div(pt), pin = pt - img * tiles_pi;
+    const int ty = dv_x.div(pin), tx = pin - ty * tiles_x;
     const int y0 = ty * 16, x0 = tx * 16;           // output origin of the patch
 
     // ---- DMA geometry: buffer descriptors, per-lane byte offsets fixed for the whole kernel ------------------
@@ -81,6 +82,18 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)((int64_t)w_rows * Ktot * 2));
     const unsigned wvoff = (unsigned)((int64_t)(n0 + wave * 8 + lrow) * Ktot * 2) + chunk * 16;
     const unsigned wrow64 = (unsigned)(64 * Ktot * 2);
+    // K-tile (chunk ci, tap): weights are [row][tap][cin] -> byte offset (tap * Cin + ci * 64) * 2 inside a row
+    auto stage_A = [&](int tap, int ci, int slot) {
+        char *dst = lds_a + slot * WIN_A + wave * 1024;
+        const unsigned so = (unsigned)(tap * p.Cin + ci * 64) * 2;
+        glds16_buf(w_rsrc, wvoff, so, dst);
+        glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 8192);
+    };
+    // The first two weight tiles need nothing but the channel tile: they leave before the window offsets (six row
+    // decodes per lane) are worked out, so that arithmetic runs under their latency instead of in front of it.
+    stage_A(0, 0, 0);
+    stage_A(1, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     // window: block k of this wave covers window rows (wave + 8 k) * 8 + lrow; rows outside the picture (and the
     // padding rows of the last block) carry an out-of-range offset: the descriptor's range check returns zeros
     const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
@@ -100,6 +113,27 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         }
     }
     const int nc = p.Cin >> 6;                       // 64-channel chunks
+    auto stage_W = [&](unsigned off, int k, int ci, int wbuf) {      // block k of this wave, window of chunk ci
+        glds16_buf(x_rsrc, off, (unsigned)ci * 128, lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024);
+    };
+    // prologue, part 1: the first window leaves as soon as its offsets exist (HBM latency is the long pole of the
+    // prologue); the fragment addresses and the accumulator set-up below run while it is in flight
+    const char *const xb_img = (const char *)p.x + img * img_bytes;
+    auto load_raw = [&](unsigned off, int ci) {      // 8 channels of one window row (zeros for halo / padding rows)
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (off != x_bytes) r = *(const uint4 *)(xb_img + off + ci * 128);
+        return r;
+    };
+    uint4 raw0[MAXWB];                               // NORM: the first window's blocks, raw, on their way to registers
+    if (!NORM) {
+#pragma unroll
+        for (int k = 0; k < MAXWB; ++k)
+            if (k < nwb) stage_W(woff[k], k, 0, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < MAXWB; ++k) raw0[k] = k < nwb ? load_raw(woff[k], 0) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // NORM: the input is the raw tensor in front of a GroupNorm (+SiLU); the window is staged through registers and
     // normalised on the way: v = silu(a[c] * x + b[c]) with (a, b) per (image, channel) from onedc_gn_from_stats, the
@@ -107,7 +141,6 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     // normalised tensor never exists in HBM (it was 10 % of the device time to write and re-read it).  (a, b) of the
     // image sit in LDS behind the window buffers; halo rows stay zero (the conv pads the NORMALISED tensor).
     float2 *const lds_ab = (float2 *)(smem + WIN_LDS);
-    const char *const xb_img = (const char *)p.x + img * img_bytes;
     float na[8], nb[8];                              // (a, b) of this lane's 8 channels of the chunk being staged
     auto load_ab = [&](int ci) {
         const float4 *q = (const float4 *)(lds_ab + ci * 64 + chunk * 8);
@@ -119,11 +152,6 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             na[2 * e + 1] = v.z;
             nb[2 * e + 1] = v.w;
         }
-    };
-    auto load_raw = [&](unsigned off, int ci) {      // 8 channels of one window row (zeros for halo / padding rows)
-        uint4 r = make_uint4(0u, 0u, 0u, 0u);
-        if (off != x_bytes) r = *(const uint4 *)(xb_img + off + ci * 128);
-        return r;
     };
     // two of the four 32-bit words (4 of the 8 channels) of a block: the main loop spreads a block over two phases so
     // that the work of a phase fits under the other wave row's MFMA segment
@@ -153,16 +181,6 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         *(uint4 *)(lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024 + lane * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     };
 
-    // K-tile (chunk ci, tap): weights are [row][tap][cin] -> byte offset (tap * Cin + ci * 64) * 2 inside a row
-    auto stage_A = [&](int tap, int ci, int slot) {
-        char *dst = lds_a + slot * WIN_A + wave * 1024;
-        const unsigned so = (unsigned)(tap * p.Cin + ci * 64) * 2;
-        glds16_buf(w_rsrc, wvoff, so, dst);
-        glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 8192);
-    };
-    auto stage_W = [&](unsigned off, int k, int ci, int wbuf) {      // block k of this wave, window of chunk ci
-        glds16_buf(x_rsrc, off, (unsigned)ci * 128, lds_w + wbuf * WIN_W + (wave + 8 * k) * 1024);
-    };
 
     // ---- accumulators: acc[i][b][j]: channels wr*64 + i*16.., output row 4 wc + 2 b + j, column frow ------
     f32x4 acc[4][2][2];
@@ -175,8 +193,8 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
 
     const int frow = lane & 15, fq = lane >> 4;
     // weight fragments: row 16 i + frow of the wave's 64 channels, 16-byte chunk fq (k 0..31) / 4 + fq (k 32..63)
-    const char *const fa0 = lds_a + wr * 64 * 128 + frow * 128 + ((fq ^ (lane & 7)) << 4);
-    const char *const fa1 = lds_a + wr * 64 * 128 + frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    int fao0 = wr * 64 * 128 + frow * 128 + ((fq ^ (lane & 7)) << 4);
+    int fao1 = wr * 64 * 128 + frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
     // pixel fragments: output (row 4 wc + bj, column frow) under tap (ky, kx) reads window row
     //   (4 wc + bj + ky) * 18 + frow + kx        (fused x2 upsample: ((4 wc + bj + ky + 1) >> 1) * 10 + ((frow + kx + 1) >> 1))
     // which depends on bj + ky only: 6 x 3 LDS addresses per lane, computed once.  k 32..63 is the address ^ 64.
@@ -189,27 +207,35 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
             wrd[r][kx] = WIN_NA * WIN_A + w * 128 + ((fq ^ (w & 7)) << 4);
         }
     a16x8 fa[4][2], fb[2][2];
+    // these addresses are needed from the first K-tile on: make them exist HERE (an empty asm the optimiser cannot look
+    // through), or the compiler sinks their arithmetic behind the prologue's wait, onto the critical path
+#define PIN_V(x) asm volatile("" : "+v"(x))
+    PIN_V(fao0);
+    PIN_V(fao1);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) PIN_V(wrd[r][kx]);
+    const char *const fa0 = lds_a + fao0, *const fa1 = lds_a + fao1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][b][j]));     // zeroed before the wait, not after
 
     // ---- prologue: window of chunk 0, weights of K-tiles 0 and 1 -------------------------------------------------
     if (NORM) {
         for (int c = tid; c < p.Cin; c += 512) lds_ab[c] = ((const float2 *)p.gn_ab)[(int64_t)img * p.Cin + c];
-        stage_A(0, 0, 0);
-        stage_A(1, 0, 1);
-        uint4 raw[MAXWB];
-#pragma unroll
-        for (int k = 0; k < MAXWB; ++k) raw[k] = k < nwb ? load_raw(woff[k], 0) : make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();                             // (a, b) of the image are in LDS
         load_ab(0);
 #pragma unroll
         for (int k = 0; k < MAXWB; ++k)
-            if (k < nwb) norm_store(raw[k], woff[k], k, 0);
-    } else {
-#pragma unroll
-        for (int k = 0; k < MAXWB; ++k)
-            if (k < nwb) stage_W(woff[k], k, 0, 0);
-        stage_A(0, 0, 0);
-        stage_A(1, 0, 1);
+            if (k < nwb) norm_store(raw0[k], woff[k], k, 0);
     }
+    // everything above (fragment addresses included) is address arithmetic that must not sink behind the wait: the
+    // first bytes take a microsecond to arrive, which is when that arithmetic is free
+    __builtin_amdgcn_sched_barrier(0);
     WAIT_VMCNT(0);
     WAIT_LGKMCNT(0);
     __builtin_amdgcn_s_barrier();
@@ -387,8 +413,9 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         lds_char *const my = (lds_char *)smem + wave * 8192;
-        auto finish = [&](auto act) {
+        auto finish = [&](auto act, auto stats_mode) {
             constexpr int ACT = decltype(act)::value;
+            constexpr int ST = decltype(stats_mode)::value;
 #pragma unroll
             for (int bj = 0; bj < 4; ++bj) {
                 a16_t *yp = (a16_t *)yb + (pix0 + bj * p.OW) * p.y_cs + p.y_co + nw + fq * 4;
@@ -396,8 +423,8 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (rows) {
-                        const uint2 o = conv_epi_fast_value<ACT>(p, acc[i][bj >> 1][bj & 1], bias[i], res[bj][i], ssum[i],
-                                                                 ssq[i], ssum_hi[i], ssq_hi[i]);
+                        const uint2 o = conv_epi_fast_value<ACT, ST>(p, acc[i][bj >> 1][bj & 1], bias[i], res[bj][i], ssum[i],
+                                                                     ssq[i], ssum_hi[i], ssq_hi[i]);
                         const int s8 = i * 4 + fq;             // 8-byte slot of the pixel's 128-byte row
                         *(__attribute__((address_space(3))) u32x2_t *)(my + px * 128 + (((s8 >> 1) ^ (px & 7)) << 4) + (s8 & 1) * 8) = u32x2_t{o.x, o.y};
                     } else if (ok[i]) {
@@ -407,9 +434,16 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
                 }
             }
         };
-        if (p.epi == ONEDC_EPI_SILU) finish(std::integral_constant<int, ONEDC_EPI_SILU>());
-        else if (p.epi == ONEDC_EPI_LEAKY) finish(std::integral_constant<int, ONEDC_EPI_LEAKY>());
-        else finish(std::integral_constant<int, ONEDC_EPI_LINEAR>());
+        // (activation, statistics mode) are compile-time parameters of the 64-quad loop: the run-time form costs six
+        // selects per quad, a fifth of the epilogue's instructions
+        auto with_stats = [&](auto act) {
+            if (!p.stats) finish(act, std::integral_constant<int, 0>());
+            else if (p.stats_gran == 2) finish(act, std::integral_constant<int, 2>());
+            else finish(act, std::integral_constant<int, 4>());
+        };
+        if (p.epi == ONEDC_EPI_SILU) with_stats(std::integral_constant<int, ONEDC_EPI_SILU>());
+        else if (p.epi == ONEDC_EPI_LEAKY) with_stats(std::integral_constant<int, ONEDC_EPI_LEAKY>());
+        else with_stats(std::integral_constant<int, ONEDC_EPI_LINEAR>());
         TL(4);
         if (rows) {
             const int c = lane & 7;
@@ -508,16 +542,17 @@ int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st) {
     const int Ktot = 9 * p.Cin;
     const int64_t blocks = (int64_t)tiles_n * tiles_x * tiles_y * p.B;
     if (blocks > 0x7fffffff) return -1;
+    const OnedcFastDiv dv_n((uint32_t)tiles_n), dv_pi((uint32_t)(tiles_x * tiles_y)), dv_x((uint32_t)tiles_x);
     if (p.gn_ab) {
         if (!onedc_conv_win_gn_ok(p)) return -13;
         hipLaunchKernelGGL((conv_win_kernel<false, true>), dim3((unsigned)blocks), dim3(512), WIN_LDS + p.Cin * 8, st, p,
-                           tiles_n, tiles_x, tiles_y, Ktot);
+                           tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x);
     } else if (p.up) {
         hipLaunchKernelGGL((conv_win_kernel<true, false>), dim3((unsigned)blocks), dim3(512), WIN_LDS, st, p, tiles_n, tiles_x,
-                           tiles_y, Ktot);
+                           tiles_y, Ktot, dv_n, dv_pi, dv_x);
     } else {
         hipLaunchKernelGGL((conv_win_kernel<false, false>), dim3((unsigned)blocks), dim3(512), WIN_LDS, st, p, tiles_n, tiles_x,
-                           tiles_y, Ktot);
+                           tiles_y, Ktot, dv_n, dv_pi, dv_x);
     }
     ONEDC_LAUNCH_CHECK();
     return 0;

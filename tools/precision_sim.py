@@ -8,6 +8,7 @@ picture with the pure-fp32 oracle.  Formats: f32, bf16, f16.
 """
 import argparse
 import os
+import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,13 +22,31 @@ from oracle import torch_ref as R
 FMT = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}
 
 
-def q(x, fmt):
+def q(x, fmt, dim=1):
+    """Round to a storage / operand format.  mxfp8 / mxfp4-style: OCP e4m3 elements with one power-of-two scale per block
+    of 32 consecutive elements along `dim` (the K direction of the contraction), as v_mfma_scale_f32_*_f8f6f4 consumes."""
+    if fmt in ("mxfp8", "fp8"):
+        if fmt == "fp8":                               # one scale for the whole tensor
+            amax = x.abs().max().clamp_min(1e-30)
+            sc = torch.exp2(torch.floor(torch.log2(amax)) - 8)
+            return (x / sc).clamp(-448, 448).to(torch.float8_e4m3fn).float() * sc
+        xm = x.movedim(dim, -1)
+        shp = xm.shape
+        pad = (-shp[-1]) % 32
+        xp = torch.nn.functional.pad(xm, (0, pad)).reshape(*shp[:-1], -1, 32)
+        amax = xp.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+        sc = torch.exp2(torch.floor(torch.log2(amax)) - 8)
+        xq = ((xp / sc).clamp(-448, 448).to(torch.float8_e4m3fn).float() * sc).reshape(*shp[:-1], -1)[..., :shp[-1]]
+        return xq.movedim(-1, dim)
     return x if FMT[fmt] is None else x.to(FMT[fmt]).float()
 
 
 class Sim:
-    def __init__(self, op, w, store, stream):
+    def __init__(self, op, w, store, stream, low=None, low_layers=None):
+        """low = (op, w) formats for the layers whose name matches the regular expression `low_layers` (the fp8
+        experiment: only some VAE up-block convolutions drop to 8 bits)."""
         self.op, self.w, self.store, self.stream = op, w, store, stream
+        self.low, self.low_layers = low, (re.compile(low_layers) if low_layers else None)
         self.on = True
 
     def install(self):
@@ -38,8 +57,11 @@ class Sim:
         def conv(sd, p, x, stride=1, padding=0, groups=1):
             if not sim.on:
                 return sim.orig["conv"](sd, p, x, stride, padding, groups)
-            wt = sd[f"{p}.weight"] if groups > 1 else q(sd[f"{p}.weight"], sim.w)
-            y = F.conv2d(q(x, sim.op), wt, sd.get(f"{p}.bias"), stride=stride, padding=padding, groups=groups)
+            op, wf = sim.op, sim.w
+            if sim.low_layers is not None and sim.low_layers.search(p) and sd[f"{p}.weight"].shape[-1] == 3:
+                op, wf = sim.low
+            wt = sd[f"{p}.weight"] if groups > 1 else q(sd[f"{p}.weight"], wf)
+            y = F.conv2d(q(x, op), wt, sd.get(f"{p}.bias"), stride=stride, padding=padding, groups=groups)
             return q(y, sim.store)
 
         def linear(sd, p, x):
@@ -78,6 +100,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--stage", default="vae", choices=["vae", "synthesis", "unet", "all"])
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--x0-rms", type=float, default=0.0,
+                    help="vae stage: rescale the oracle's x0 to this rms first (random-init weights produce x0 ~ 6e4, where the "
+                         "decoder's residual branches hardly matter; trained models have x0 ~ 1)")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     S = a.size
@@ -87,6 +112,11 @@ def main():
     z_sem = torch.randn(1, 128, S // 64, S // 64, generator=g)
     with torch.no_grad():
         ref = R.decode_from_latents(codec_sd, unet_sd, vae_sd, y_hat, z_sem)
+    if a.x0_rms > 0 and a.stage == "vae":
+        with torch.no_grad():
+            ref["x0"] = ref["x0"] * (a.x0_rms / ref["x0"].pow(2).mean().sqrt())
+            ref["image"] = R.vae_decode(vae_sd, ref["x0"], 16)
+        print(f"x0 rescaled to rms {a.x0_rms}; image rms {float(ref['image'].pow(2).mean().sqrt()):.3f}")
     ref_img = R.to_unit_range(ref["image"])
     t = torch.full((1,), 999, dtype=torch.long)
     acp = R.ddim_alphas_cumprod().double()
@@ -123,8 +153,12 @@ def main():
     if ap_cfg:
         configs = [tuple(c.split("/")) for c in ap_cfg.split(",")]
     print(f"stage {a.stage} at {S}x{S}: conv operand / weights / conv-output store / residual stream")
+    low_layers = os.environ.get("SIM_LOW_LAYERS")            # e.g. "up_blocks\\.[23]\\.resnets" with SIM_LOW=mxfp8/mxfp8
+    low = tuple(os.environ.get("SIM_LOW", "mxfp8/mxfp8").split("/"))
+    if low_layers:
+        print(f"layers matching /{low_layers}/ (3x3 convs): operand {low[0]}, weights {low[1]}")
     for op, w, store, stream in configs:
-        sim = Sim(op, w, store, stream)
+        sim = Sim(op, w, store, stream, low, low_layers)
         sim.install()
         try:
             img = R.to_unit_range(run(a.stage))
