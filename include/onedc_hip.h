@@ -81,7 +81,9 @@ typedef struct onedc_conv_params {
                                            silu(a*x + b) -- the normalisation is applied while the operand is staged
                                            (only the 3x3 window kernel does it: ask onedc_conv_win_takes first) */
     int32_t gn_silu;
-    int32_t reserved0;
+    int32_t out_bf16;                   /* 1: a 16-bit output is stored as bf16 whatever the library's activation format (the
+                                           IEEE-half build hands V^T to onedc_flash_attn's d = 40 kernel this way: its P / V^T
+                                           product stays bf16 for the exponent range); ignored with out_f32 */
 } onedc_conv_params;
 int onedc_conv_gemm(const onedc_conv_params *p, void *stream);
 /* 1 if onedc_conv_gemm would run p on the 3x3 window kernel AND that kernel can apply a GroupNorm in front of the conv
@@ -162,6 +164,9 @@ int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, 
  * analysis UNet2DModel of the encode side), zero-padded by the packed projection weights.  scale multiplies q.k before the softmax. */
 int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
                      int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream);
+/* 1 if onedc_flash_attn reads vt as bf16 for this shape whatever the library's activation format (head dim 40 with at
+ * least 64 keys: P and V^T of that kernel are bf16, see attention.hip); the producer sets onedc_conv_params.out_bf16 */
+int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk);
 
 /* ---- elementwise heads ------------------------------------------------------------------- */
 /* FSQ.indices_to_codes, levels [4]*7 (codec_module.py:431): idx int32 [n] -> f32 codes [n][8]

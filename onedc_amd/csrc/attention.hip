@@ -281,15 +281,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const a16_t *__restrict
 //     constant page: the DMA source of that LDS row is redirected, V^T itself is read-only
 //   * 4 waves / 42 KB per workgroup -> two workgroups per CU drift apart, so one SIMD overlaps the exp
 //     phase of one wave with the MFMA phase of another
+// (bf16 ones in either build: V^T and P of this kernel are bf16)
 __device__ const uint32_t g_ones_page[64] = {
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2,
-    ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2};
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u,
+    0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
 
 // bf16 {1, 0, 0, 0, 0, 0, 0, 0}: stands in for chunk 5 (the all-padding dims 40..47) of every K row, so
 // that dim 40 of the S product is a free "+ 1 * q[40]" term: q[40] carries -m_run
@@ -414,12 +415,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
     // moved only when a later tile holds a score more than 2^FA64_THR above it; the move is applied AFTER
     // that tile's PV product (O and the riding row sum are scaled together), so no register between the
     // S product and the PV product is ever touched by the rare path.
-#ifdef ONEDC_ACT_F16
-    constexpr float FA64_THR = 8.f;                  // the reference follows the scores more closely than with bf16 ...
-    constexpr float FA64_CLAMP = 15.f;               // ... and no P element can leave the IEEE-half range
-#else
+    // P and V^T are ALWAYS bf16 in this kernel, also in the IEEE-half build (Q, K and the S product are the build's
+    // format): exp2 of a score that jumped far above the lazily moved reference is only representable with f32's
+    // exponent range, and a pre-check in front of the PV product costs registers the loop does not have (it spilled:
+    // 4.2 instead of 2.7 ms at 9216 tokens).  The host hands V^T over in bf16 (onedc_conv_params.out_bf16).
     constexpr float FA64_THR = 12.f;
-#endif
     auto s_chain = [&](const char *ldsK, f32x4 (&s)[4][QT]) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -500,47 +500,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#ifdef ONEDC_ACT_F16
-                    s[kt][t][e] = __builtin_amdgcn_exp2f(fminf(s[kt][t][e], FA64_CLAMP));     // P <= 2^15 < 65504
-#else
-                    s[kt][t][e] = __builtin_amdgcn_exp2f(s[kt][t][e]);
-#endif
-                }
+                for (int e = 0; e < 4; ++e) s[kt][t][e] = __builtin_amdgcn_exp2f(s[kt][t][e]);
         }
-#ifdef ONEDC_ACT_F16
-        // IEEE-half P cannot hold exp2 of an arbitrary excess over the reference (bf16 can: f32's exponent range).  The
-        // exponentials above are clamped at 2^15 and do not wait for the row maxima; only if a score really exceeded the
-        // clamp (a jump of more than 2^15 between the reference and a later tile: next to never) the reference moves
-        // NOW, before the PV product, and the tile's scores are recomputed against it.
-        {
-            const float wmax0 = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
-            if (__any(wmax0 > FA64_CLAMP)) {        // wave-uniform
-#pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
-                    tmax[t] = 0.f;
-                }
-                s_chain(ldsK, s);
-                if (MASK) mask_tail(s, k0);
-#pragma unroll
-                for (int t = 0; t < QT; ++t)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[kt][t][e] = __builtin_amdgcn_exp2f(fminf(s[kt][t][e], FA64_CLAMP));
-            }
-        }
-#endif
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 union { a16x8 v; uint32_t u[4]; } pk;
-                pk.u[0] = pack_a2(s[2 * st][t][0], s[2 * st][t][1]);
-                pk.u[1] = pack_a2(s[2 * st][t][2], s[2 * st][t][3]);
-                pk.u[2] = pack_a2(s[2 * st + 1][t][0], s[2 * st + 1][t][1]);
-                pk.u[3] = pack_a2(s[2 * st + 1][t][2], s[2 * st + 1][t][3]);
+                pk.u[0] = pack_bf16_2(s[2 * st][t][0], s[2 * st][t][1]);
+                pk.u[1] = pack_bf16_2(s[2 * st][t][2], s[2 * st][t][3]);
+                pk.u[2] = pack_bf16_2(s[2 * st + 1][t][0], s[2 * st + 1][t][1]);
+                pk.u[3] = pack_bf16_2(s[2 * st + 1][t][2], s[2 * st + 1][t][3]);
                 pf[t][st] = pk.v;
             }
         }
@@ -552,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
                 const a16x8 vf = *(const a16x8 *)(ldsV + d * 2048 + vfo[st]);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    o[d][t] = ONEDC_MFMA16(vf, pf[t][st], o[d][t]);
+                    o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][st], o[d][t], 0, 0, 0);
             }
         const float wmax = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
         if (__any(wmax > FA64_THR)) {               // wave-uniform, rare
@@ -612,6 +582,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
 }
 
 }  // namespace
+
+// 1 when the kernel onedc_flash_attn picks for (DQ, DV, Nk) reads V^T as bf16 in EITHER build of the library (the d = 40
+// kernel: flash_attn64_kernel), 0 when V^T is in the library's own 16-bit format
+extern "C" int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk) { return DQ == 64 && DV == 48 && Nk >= 64; }
 
 extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
                                 int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream) {

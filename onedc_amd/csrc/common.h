@@ -55,6 +55,12 @@ __device__ __forceinline__ uint32_t pack_a2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, a16x2_t));
 }
+// bf16 pair in either build (flash_attn64's P, and what its V^T producer stores: onedc_conv_params.out_bf16)
+__device__ __forceinline__ uint32_t pack_bf16_2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_always_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_always_t));
+}
 __device__ __forceinline__ a16_t f2a(float f) { return (a16_t)(pack_a2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }

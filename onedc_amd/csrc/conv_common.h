@@ -210,7 +210,7 @@ __host__ __device__ __forceinline__ bool conv_epi_mode_fast(const onedc_conv_par
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     const int cout_store = glu ? p.Cout / 2 : p.Cout;
     // bf16 in / bf16 out, or the exact-f32 path with f32 output (16-byte stores: same 4-element alignment rule)
-    return (p.out_f32 != 0) == (p.in_f32 != 0) && !p.pixel_shuffle && ((p.y_cs | p.y_co | cout_store) & 3) == 0 &&
+    return (p.out_f32 != 0) == (p.in_f32 != 0) && !p.out_bf16 && !p.pixel_shuffle && ((p.y_cs | p.y_co | cout_store) & 3) == 0 &&
            (!p.res || ((p.r_cs | p.r_co) & 3) == 0) && p.epi >= ONEDC_EPI_LINEAR && p.epi <= ONEDC_EPI_GEGLU;
 }
 
@@ -369,7 +369,13 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
         }
     } else {
         a16_t *yp = (a16_t *)yb + yo;
-        if (e.full && ((p.y_cs | p.y_co) & 3) == 0) {
+        if (p.out_bf16) {                          // bf16 whatever the build's format (flash_attn64's V^T)
+            if (e.full && ((p.y_cs | p.y_co) & 3) == 0) {
+                *(uint2 *)yp = make_uint2(pack_bf16_2(v[0], v[1]), pack_bf16_2(v[2], v[3]));
+            } else {
+                for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = (a16_t)(pack_bf16_2(v[k], 0.f) & 0xffffu);
+            }
+        } else if (e.full && ((p.y_cs | p.y_co) & 3) == 0) {
             *(uint2 *)yp = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         } else {
             for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = f2a(v[k]);
@@ -384,7 +390,7 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
 // is: 4 fma, activation, residual add, statistics, pack, one 8-byte store at a precomputed address.
 // Same operations in the same order as conv_epi_finish: results are bit-identical to the general path.
 __host__ __device__ __forceinline__ bool conv_epi_fast_ok(const onedc_conv_params &p, bool glu) {
-    return !p.out_f32 && !p.pixel_shuffle && !glu && ((p.y_cs | p.y_co | p.Cout) & 3) == 0 &&
+    return !p.out_f32 && !p.out_bf16 && !p.pixel_shuffle && !glu && ((p.y_cs | p.y_co | p.Cout) & 3) == 0 &&
            (p.epi == ONEDC_EPI_LINEAR || p.epi == ONEDC_EPI_LEAKY || p.epi == ONEDC_EPI_SILU);
 }
 // STATS: -1 = decided at run time from p.stats / p.stats_gran (branch-free selects: 6 extra instructions per quad),

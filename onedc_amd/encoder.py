@@ -149,9 +149,11 @@ class GroupNormAttention:
         n_pad = (N + 63) // 64 * 64
         hn = self.norm(x, ws, False)
         q, k = self.q(hn), self.k(hn)
-        vt = torch.zeros(B * self.H * self.DV * n_pad, dtype=K.a16(), device=dev)
+        vt_dtype = K.flash_vt_dtype(self.DQ, self.DV, N)
+        vt = torch.zeros(B * self.H * self.DV * n_pad, dtype=vt_dtype, device=dev)
         K.conv_gemm(self.wv, hn.t, None, View(vt, 1, 1, self.H * self.DV, N, n_pad), Cin=self.C, Cout=N, batch=B,
-                    x_bs=0, w_bs=N * hn.cs, y_bs=self.H * self.DV * n_pad, flop_scale=self.d / self.DV)
+                    x_bs=0, w_bs=N * hn.cs, y_bs=self.H * self.DV * n_pad, flop_scale=self.d / self.DV,
+                    out_bf16=(vt_dtype == torch.bfloat16))
         o = new_view(B, x.H, x.W, self.H * self.DV, dev)
         K.flash_attn(q.t, k.t, vt, o.t, B, self.H, N, N, n_pad, self.DQ, self.DV, self.d ** -0.5)
         return self.o(o, y, res=x, stats=True)

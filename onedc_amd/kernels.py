@@ -75,7 +75,7 @@ class ConvParams(C.Structure):
         ("batch", C.c_int32), ("tile", C.c_int32), ("stats_gran", C.c_int32), ("patch16", C.c_int32),
         ("in_f32", C.c_int32),
         ("x_bs", _L), ("w_bs", _L), ("y_bs", _L), ("r_bs", _L),
-        ("gn_ab", _P), ("gn_silu", C.c_int32), ("reserved0", C.c_int32),
+        ("gn_ab", _P), ("gn_silu", C.c_int32), ("out_bf16", C.c_int32),
     ]
 
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "onedc_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "onedc_softmax_rows": (_I, [_P, _P, _L, _I, _I, _P]),
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_flash_attn_vt_is_bf16": (_I, [_I, _I, _I]),
     "onedc_fsq_codes": (_I, [_P, _P, _L, _P]),
     "onedc_fsq_quantize": (_I, [_P, _I, _I, _I, _P, _L, _P]),
     "onedc_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -272,7 +273,7 @@ def conv_kernel_name(p):
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
               pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0,
-              tile=0, stats=False, pad=None, gn=None):
+              tile=0, stats=False, pad=None, gn=None, out_bf16=False):
     """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None.
     gn = (gamma, beta, eps, silu, ws): the conv reads GroupNorm(x) (+SiLU).  On the 3x3 window kernel the
     normalisation is applied while the operand is staged (x is read raw, the normalised tensor never exists);
@@ -296,6 +297,7 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     p.stride, p.pad, p.up = stride, (KH // 2 if pad is None else pad), up
     p.epi, p.out_f32, p.pixel_shuffle = epi, int(y.f32), pixel_shuffle
     p.in_f32 = int(x.f32)
+    p.out_bf16 = int(bool(out_bf16))
     p.tile = tile
     if stats and y.stats is not None and not pixel_shuffle and batch <= 1 and y.co % 4 == 0 and y.C % 4 == 0:
         p.stats = y.stats.t.data_ptr()       # the epilogue leaves GroupNorm partial sums for the consumer
@@ -412,7 +414,15 @@ def softmax_rows(s, p, rows, n, n_pad):
     return p
 
 
+def flash_vt_dtype(DQ, DV, Nk):
+    """torch dtype in which onedc_flash_attn wants V^T for this shape: bf16 for the d = 40 kernel in either library
+    (its P / V^T product needs f32's exponent range), the current activation format otherwise."""
+    return torch.bfloat16 if lib().onedc_flash_attn_vt_is_bf16(DQ, DV, Nk) else a16()
+
+
 def flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale):
+    if vt.dtype != flash_vt_dtype(DQ, DV, Nk):
+        raise KernelError(f"flash_attn: V^T must be {flash_vt_dtype(DQ, DV, Nk)} for DQ={DQ}, DV={DV}, Nk={Nk}, not {vt.dtype}")
     _ok(lib().onedc_flash_attn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, Nq, Nk, Nk_pad,
                                DQ, DV, scale, stream()), "onedc_flash_attn")
     return o

@@ -280,10 +280,11 @@ class MultiHeadAttention:
         Nk_pad = (Nk + 63) // 64 * 64
         q = self.q(x)
         k = self.k(ctx)
-        vt = torch.zeros(B * self.H * self.DV * Nk_pad, dtype=K.a16(), device=dev)
+        vt_dtype = K.flash_vt_dtype(self.DQ, self.DV, Nk)
+        vt = torch.zeros(B * self.H * self.DV * Nk_pad, dtype=vt_dtype, device=dev)
         K.conv_gemm(self.wv, ctx.t, None, View(vt, 1, 1, self.H * self.DV, Nk, Nk_pad), Cin=self.ctx_dim,
                     Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=self.H * self.DV * Nk_pad,
-                    flop_scale=self.d / self.DV)
+                    flop_scale=self.d / self.DV, out_bf16=(vt_dtype == torch.bfloat16))
         o = new_view(x.B, x.H, x.W, self.H * self.DV, dev)
         K.flash_attn(q.t, k.t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, self.DQ, self.DV, self.d ** -0.5)
         return self.o(o, y, res=res)

@@ -224,7 +224,7 @@ def test_flash_attention(d, Nq, Nk):
     vt = torch.zeros(B, Hh, DV, Nk_pad)
     vt[:, :, :d, :Nk] = v.transpose(2, 3)
     o = torch.empty(B, Nq, Hh * DV, dtype=K.a16(), device=DEV)
-    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk_pad).to(K.a16()).to(DEV).contiguous(),
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk_pad).to(K.flash_vt_dtype(DQ, DV, Nk)).to(DEV).contiguous(),
                  o, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5)
     ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v               # (B,H,Nq,d)
     got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
@@ -555,7 +555,7 @@ def test_flash_attention_reference_point_moves():
     vt = torch.zeros(B, Hh, DV, Nk)
     vt[:, :, :d] = v.transpose(2, 3)
     o = torch.empty(B, Nq, Hh * DV, dtype=K.a16(), device=DEV)
-    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk).to(K.a16()).to(DEV).contiguous(),
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk).to(K.flash_vt_dtype(DQ, DV, Nk)).to(DEV).contiguous(),
                  o, B, Hh, Nq, Nk, Nk, DQ, DV, d ** -0.5)
     ref = torch.softmax(q.double() @ k.double().transpose(-1, -2) * d ** -0.5, -1) @ v.double()
     got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)

@@ -396,7 +396,7 @@ def test_flash_attention_head_dim_8():
     vt = torch.zeros(B, Hh, DV, n_pad)
     vt[:, :, :d, :N] = v.transpose(2, 3)
     o = torch.empty(B, N, Hh * DV, dtype=K.a16(), device=DEV)
-    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, n_pad).to(K.a16()).to(DEV).contiguous(),
+    K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, n_pad).to(K.flash_vt_dtype(DQ, DV, N)).to(DEV).contiguous(),
                  o, B, Hh, N, N, n_pad, DQ, DV, d ** -0.5)
     ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v
     got = o.float().cpu().view(B, N, Hh, DV)[..., :d].permute(0, 2, 1, 3)

@@ -23,7 +23,7 @@ def main():
         Nk_pad = (Nk + 63) // 64 * 64
         q = torch.randn(B * Nq * H * DQ, generator=g, device=DEV).to(K.a16())
         k = torch.randn(B * Nk * H * DQ, generator=g, device=DEV).to(K.a16())
-        vt = torch.randn(B * H * DV * Nk_pad, generator=g, device=DEV).to(K.a16())
+        vt = torch.randn(B * H * DV * Nk_pad, generator=g, device=DEV).to(K.flash_vt_dtype(DQ, DV, Nk))
         o = torch.empty(B * Nq * H * DV, dtype=K.a16(), device=DEV)
         for _ in range(2):
             K.flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5)
