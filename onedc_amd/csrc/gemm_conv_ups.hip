@@ -63,6 +63,18 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
     const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)((int64_t)w_rows * Ktot * 2));
     const unsigned wvoff = (unsigned)((int64_t)(n0 + wave * 8 + lrow) * Ktot * 2) + chunk * 16;
     const unsigned wrow64 = (unsigned)(64 * Ktot * 2);
+    // K-tile (chunk ci, tap k): weights are [row][tap][cin] -> byte offset (k * Cin + ci * 64) * 2 inside a row
+    auto stage_A = [&](int k, int ci) {
+        char *dst = lds_a + k * UPS_A + wave * 1024;
+        const unsigned so = (unsigned)(k * p.Cin + ci * 64) * 2;
+        glds16_buf(w_rsrc, wvoff, so, dst);
+        glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 8192);
+    };
+    // prologue, part 1 (same order as gemm_conv_win.hip): the first two weight tiles leave before the window offsets
+    // are decoded, the window before the fragment addresses -- address arithmetic runs under DMA latency
+    stage_A(0, 0);
+    stage_A(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
     const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
     const unsigned x_bytes = img_bytes < 0xfffff000ll ? (unsigned)img_bytes : 0xfffff000u;
     const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc((const char *)p.x + img * img_bytes, x_bytes);
@@ -77,17 +89,14 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
         woff[k] = ok ? (unsigned)((iy * p.IW + ix) * p.x_cs + p.x_co) * 2u + chunk * 16 : x_bytes;
     }
     const int nc = p.Cin >> 6;                       // 64-channel chunks
-
-    // K-tile (chunk ci, tap k): weights are [row][tap][cin] -> byte offset (k * Cin + ci * 64) * 2 inside a row
-    auto stage_A = [&](int k, int ci) {
-        char *dst = lds_a + k * UPS_A + wave * 1024;
-        const unsigned so = (unsigned)(k * p.Cin + ci * 64) * 2;
-        glds16_buf(w_rsrc, wvoff, so, dst);
-        glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 8192);
-    };
     auto stage_W = [&](unsigned off, int k, int ci, int wbuf) {      // block k of this wave, window of chunk ci
         glds16_buf(x_rsrc, off, (unsigned)ci * 128, lds_w + wbuf * UPS_W + (wave + 8 * k) * 1024);
     };
+#pragma unroll
+    for (int k = 0; k < MAXWB; ++k)
+        if (k < nwb) stage_W(woff[k], k, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
 
     // ---- accumulators: acc[i][b][j]: rows wr*64 + i*16.., low-res row 4 wc + 2 b + j, column frow -----------
     f32x4 acc[4][2][2];
@@ -99,8 +108,8 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
             for (int j = 0; j < 2; ++j) acc[i][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    const char *const fa0 = lds_a + wr * 64 * 128 + frow * 128 + ((fq ^ (lane & 7)) << 4);
-    const char *const fa1 = lds_a + wr * 64 * 128 + frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    int fao0 = wr * 64 * 128 + frow * 128 + ((fq ^ (lane & 7)) << 4);
+    int fao1 = wr * 64 * 128 + frow * 128 + (((4 + fq) ^ (lane & 7)) << 4);
     // tap k = (ty, tx) of phase (PY, PX) reads window row (4 wc + bj + PY + ty) * 18 + frow + PX + tx:
     // 5 x 2 LDS addresses per lane (r = bj + ty), computed once.  k 32..63 is the address ^ 64.
     int wrd[5][2];
@@ -112,13 +121,20 @@ __device__ __forceinline__ void ups_body(const onedc_conv_params &p, char *smem,
             wrd[r][tx] = UPS_NA * UPS_A + w * 128 + ((fq ^ (w & 7)) << 4);
         }
     a16x8 fa[4][2], fb[2][2];
-
-    // ---- prologue: window of chunk 0, weights of K-tiles 0 and 1 -------------------------------------------------
+    // addresses and zeroed accumulators exist before the wait (empty asm: the optimiser cannot sink them behind it)
+    asm volatile("" : "+v"(fao0), "+v"(fao1));
 #pragma unroll
-    for (int k = 0; k < MAXWB; ++k)
-        if (k < nwb) stage_W(woff[k], k, 0, 0);
-    stage_A(0, 0);
-    stage_A(1, 0);
+    for (int r = 0; r < 5; ++r) asm volatile("" : "+v"(wrd[r][0]), "+v"(wrd[r][1]));
+    const char *const fa0 = lds_a + fao0, *const fa1 = lds_a + fao1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][b][j]));
+
+    // ---- prologue, part 2: window of chunk 0 and the weights of K-tiles 0 and 1 are on their way -----------------------
+    __builtin_amdgcn_sched_barrier(0);
     ups_wait_vmcnt(0);
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();       // the two wave rows run one barrier apart
