@@ -99,7 +99,8 @@ enum {
     ONEDC_KERNEL_16X256 = 5,       /* conv_gemm_kernel<Tile<16,256>> */
     ONEDC_KERNEL_64X128 = 6,       /* conv_gemm_kernel<Tile<64,128>> */
     ONEDC_KERNEL_128X128 = 7,      /* conv_gemm_kernel<Tile<128,128>> */
-    ONEDC_KERNEL_F32_128X128 = 8   /* conv_gemm_kernel<Tile<128,128>, f32> (exact-f32 path) */
+    ONEDC_KERNEL_F32_128X128 = 8,  /* conv_gemm_kernel<Tile<128,128>, f32> (exact-f32 path) */
+    ONEDC_KERNEL_F32_64X128 = 9    /* conv_gemm_kernel<Tile<64,128>, f32>: the same for grids of less than two rounds */
 };
 int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
 const char *onedc_conv_kernel_name(int kernel_id);

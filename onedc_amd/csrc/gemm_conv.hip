@@ -305,8 +305,15 @@ static int conv_choose(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     // up == 2: x2 upsample + 3x3 decomposed into four 2x2 phase convolutions; w is the phase-packed matrix
     if (p.up == 2) return onedc_conv_ups_ok(p) ? ONEDC_KERNEL_UPS2X2 : -12;
-    if (p.in_f32) return ONEDC_KERNEL_F32_128X128;
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
+    if (p.in_f32) {
+        // the f32 matrix cores run at 1/16 of the 16-bit rate: a 128x128x256 tile is 15 us of MFMA time, and the prior
+        // networks' maps give 72 .. 576 such tiles for 512 workgroup slots.  Grids of less than two full rounds take the
+        // 64-row tile (twice the workgroups, half the work each; same k order, same bits): 256->256 at 48x48, B = 16:
+        // 64 -> 45 us (tools/bench_f32.py)
+        const int64_t blocks = ((p.Cout + 127) / 128) * ((M64 + 127) / 128) * (p.batch > 1 ? p.batch : 1);
+        return (blocks < 1024 && (p.Cout % 64) == 0 && p.tile != 128) ? ONEDC_KERNEL_F32_64X128 : ONEDC_KERNEL_F32_128X128;
+    }
     // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per 64-channel chunk):
     // 5-27 % faster than the 128x256 / 256x256 kernels on every 3x3 layer it can take (tools/bench_conv.py)
     if (conv_win_wanted(p)) return onedc_conv_win_gn_ok(p) ? ONEDC_KERNEL_WIN3X3 : -13;
@@ -352,6 +359,7 @@ extern "C" const char *onedc_conv_kernel_name(int id) {
         case ONEDC_KERNEL_64X128: return "64x128";
         case ONEDC_KERNEL_128X128: return "128x128";
         case ONEDC_KERNEL_F32_128X128: return "f32_128x128";
+        case ONEDC_KERNEL_F32_64X128: return "f32_64x128";
         default: return "?";
     }
 }
@@ -372,6 +380,7 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         case ONEDC_KERNEL_64X128: return launch<Tile<64, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_128X128: return launch<Tile<128, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_F32_128X128: return launch<Tile<128, 128, 2, 2>, true>(p, st);
+        case ONEDC_KERNEL_F32_64X128: return launch<Tile<64, 128, 2, 2>, true>(p, st);
         default: return id < 0 ? id : -14;
     }
 }

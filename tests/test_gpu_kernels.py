@@ -292,6 +292,12 @@ def test_conv_gemm_f32_exact(B, H, W, Cin, Cout, k):
                 b.to(DEV), y, KH=k, epi=K.EPI_LEAKY, slope=0.01, res=from_nchw(r.to(DEV), torch.float32))
     ref = F.leaky_relu(_f64_conv(x, w, b, padding=k // 2), 0.01) + r.double()
     close(y.torch_nchw(), ref, rms=2e-6, mx=2e-6, what="f32 conv")
+    # these grids are small: the dispatcher took the 64-row f32 tile; the 128-row tile (tile=128) must give the same BITS
+    # (same k order per output) -- the prior's decisions may not depend on which tile a map size selects
+    y2 = new_view(B, H, W, Cout, DEV, torch.float32)
+    K.conv_gemm(from_nchw(x.to(DEV), torch.float32), pack.pack_matrix(pack.conv_matrix(w), DEV, None, torch.float32),
+                b.to(DEV), y2, KH=k, epi=K.EPI_LEAKY, slope=0.01, res=from_nchw(r.to(DEV), torch.float32), tile=128)
+    assert torch.equal(y.torch_nchw(), y2.torch_nchw())
 
 
 def test_conv_gemm_f32_glu_and_shuffle():
