@@ -38,7 +38,10 @@ def build_coder(force=False):
 
 # attention.hip: finite inputs by construction; without this flag every fmaxf on an MFMA result gets a
 # canonicalising v_max_f32 in front (100+ VALU instructions per key tile in a VALU-bound kernel)
-FILE_FLAGS = {"attention.hip": ("-fno-honor-nans",)}
+# gemm_conv_win.hip: the SLP vectoriser packs the GroupNorm-on-load arithmetic into v_pk_fma_f32 / v_pk_mul_f32, which
+# cost more issue time than the scalar pair next to the other wave's MFMAs (MI355X_MICROARCH.md, "packed f32 VALU"):
+# fused 128->128 at 768x768 3.47 -> 3.38 ms, 256->128 5.80 -> 5.57 ms, plain variant unchanged (same results: IEEE fma)
+FILE_FLAGS = {"attention.hip": ("-fno-honor-nans",), "gemm_conv_win.hip": ("-fno-slp-vectorize",)}
 
 
 def hip_sources():
