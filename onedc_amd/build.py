@@ -38,10 +38,14 @@ def build_coder(force=False):
 
 # attention.hip: finite inputs by construction; without this flag every fmaxf on an MFMA result gets a
 # canonicalising v_max_f32 in front (100+ VALU instructions per key tile in a VALU-bound kernel)
-# gemm_conv_win.hip: the SLP vectoriser packs the GroupNorm-on-load arithmetic into v_pk_fma_f32 / v_pk_mul_f32, which
-# cost more issue time than the scalar pair next to the other wave's MFMAs (MI355X_MICROARCH.md, "packed f32 VALU"):
-# fused 128->128 at 768x768 3.47 -> 3.38 ms, 256->128 5.80 -> 5.57 ms, plain variant unchanged (same results: IEEE fma)
-FILE_FLAGS = {"attention.hip": ("-fno-honor-nans",), "gemm_conv_win.hip": ("-fno-slp-vectorize",)}
+# MFMA kernels are built without SLP vectorisation: the vectoriser packs epilogue / normalise-on-load / softmax arithmetic
+# into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, which cost more issue time than the scalar pairs next to the MFMAs of
+# the other wave on the SIMD (MI355X_MICROARCH.md, "packed f32 VALU").  Same results (IEEE fma either way).  Interleaved A/B
+# on one box: window kernel with GroupNorm on load 128->128 at 768x768 3.47 -> 3.38 ms, 256->128 5.80 -> 5.57; GEGLU
+# 320->2560 422 -> 410 us; d = 80 attention 0.951 -> 0.874 ms; everything else within noise.
+_NO_SLP = ("-fno-slp-vectorize",)
+FILE_FLAGS = {"attention.hip": ("-fno-honor-nans",) + _NO_SLP, "gemm_conv_win.hip": _NO_SLP, "gemm_conv.hip": _NO_SLP,
+              "gemm_conv256.hip": _NO_SLP, "gemm_conv_ups.hip": _NO_SLP}
 
 
 def hip_sources():
@@ -52,7 +56,8 @@ def build_hip(force=False, extra_flags=()):
     """Both builds of the kernel sources: bf16 activations (libonedc_hip.so) and IEEE-half activations
     (libonedc_hip_f16.so, -DONEDC_ACT_F16; csrc/common.h)."""
     srcs = hip_sources()
-    headers = glob.glob(os.path.join(_native.CSRC, "*.h")) + [os.path.join(ROOT, "include", "onedc_hip.h")]
+    # (this file is a dependency too: the per-file compiler flags live here)
+    headers = glob.glob(os.path.join(_native.CSRC, "*.h")) + [os.path.join(ROOT, "include", "onedc_hip.h"), os.path.abspath(__file__)]
     if not srcs:
         raise RuntimeError("no HIP sources found")
     variants = ((_native.HIP_SO, ".o", ()), (_native.HIP_F16_SO, ".f16.o", ("-DONEDC_ACT_F16",)))
