@@ -552,3 +552,34 @@ def test_z_only_cli_harness_on_a_folder(tmp_path):
     for name in sizes:
         assert np.array_equal(np.asarray(Image.open(tmp_path / "dec" / f"{name}.png")),
                               np.asarray(Image.open(out / "recon" / f"{name}.png")))
+
+
+def test_encode_decode_large_picture(full_model):
+    """A picture above 0.65 MP: the analysis transform's single-head attention runs over (H/16)(W/16) = 4096 tokens at
+    1024x1024, past the 2560 columns the register-resident row softmax holds (onedc_softmax_rows now streams longer rows);
+    the reference's folder loop handles any size (inference.py:109-127).  Round trip: the decoder recovers the encoder's
+    latent bit for bit and returns a finite picture of the original size."""
+    model = full_model
+    g = torch.Generator().manual_seed(91)
+    img = (torch.rand(1, 3, 1000, 1024, generator=g) * 2 - 1).to(DEV)        # padded to 1024 x 1024
+    noise = torch.randn(1, 128, 128, 4, generator=g).to(DEV)
+    blob, bpp = model.encode(img, noise=noise)
+    assert bpp["bits_z"] == ((16 * 16 * 14 + 7) // 8) * 8 and bpp["bits_total"] == len(blob) * 8
+    out = model.decode(stream=[blob])
+    assert out.shape == (1, 3, 1000, 1024) and bool(torch.isfinite(out).all())
+    again, _ = model.encode(img, noise=noise)
+    assert again == blob                                                      # deterministic
+
+
+def test_softmax_rows_long_rows_match_torch():
+    """onedc_softmax_rows beyond the register-resident width (n_pad > 2560): streaming kernel vs torch.softmax."""
+    rows, n = 37, 4099
+    n_pad = (n + 63) // 64 * 64
+    s = torch.randn(rows, n, generator=torch.Generator().manual_seed(92)) * 4
+    p = torch.empty(rows * n_pad, dtype=K.a16(), device=DEV)
+    K.softmax_rows(s.to(DEV).contiguous(), p, rows, n, n_pad)
+    got = p.view(rows, n_pad).float().cpu()
+    assert float(got[:, n:].abs().max()) == 0.0
+    ref = torch.softmax(s.double(), -1)
+    assert float((got[:, :n].double() - ref).abs().max()) <= 2e-3 * float(ref.max())
+    assert float((got[:, :n].double().sum(-1) - 1).abs().max()) <= 2e-3
