@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=None, help="picture size of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline (16 was the fastest of 16/32/64 on the 2x64-core host)")
+    ap.add_argument("--free-vae", action="store_true",
+                    help="let the VAE stages of the pipeline's streams overlap each other (default: serialised on the device)")
     ap.add_argument("--broadcast-weights", action="store_true",
                     help="rank 0 builds the weights, one flat RCCL broadcast hands them to the other ranks (the path a "
                          "real checkpoint takes); default: every rank builds the synthetic weights itself")
@@ -248,7 +250,7 @@ def main():
     # overlaps the UNet / VAE of batch n; all K batches start and finish inside the timed region).
     pipe = None
     if not args.sequential and mode != "encode_decode":
-        pipe = model.pipeline(s_streams=args.s_streams, z_only=(mode == "z_only"))
+        pipe = model.pipeline(s_streams=args.s_streams, z_only=(mode == "z_only"), serialise_vae=not args.free_vae)
 
     def one_sequential():
         if mode == "decode":

@@ -187,19 +187,25 @@ class SD15_1step_codec_stage1:
         return self
 
     # -- decode ---------------------------------------------------------------------------------
-    def decode_latents(self, h_detail_hat, y_semantic):
+    def decode_latents(self, h_detail_hat, y_semantic, vae_gate=None):
         with K.act_format(self.act):
-            return self._decode_latents(h_detail_hat, y_semantic)
+            return self._decode_latents(h_detail_hat, y_semantic, vae_gate)
 
     @torch.no_grad()
-    def _decode_latents(self, h_detail_hat, y_semantic):
-        """model...stage1.py:303-324 after the codec: UNet step, x0, VAE decode. Returns dict of Views."""
+    def _decode_latents(self, h_detail_hat, y_semantic, vae_gate=None):
+        """model...stage1.py:303-324 after the codec: UNet step, x0, VAE decode. Returns dict of Views.
+        vae_gate: optional context manager entered around the VAE decoder's launches (DecodePipeline serialises the VAE
+        stages of its streams with it)."""
         ctx = y_semantic                                            # 'b c h w -> b (h w) c' is the NHWC layout itself
         eps, reduced = self.feedforward_model(h_detail_hat, self.conditioning_timestep, ctx)
         x0 = new_view(eps.B, eps.H, eps.W, 4, self.device, torch.float32)
         n = eps.B * eps.H * eps.W * 4
         K.x0_from_noise(reduced.t[:n], eps.t[:n], x0.t[:n], float(self.alphas_cumprod[self.conditioning_timestep].double()))
-        image = self.vae_large.decode(x0)
+        if vae_gate is None:
+            image = self.vae_large.decode(x0)
+        else:
+            with vae_gate:
+                image = self.vae_large.decode(x0)
         return {"eps": eps, "reduced": reduced, "x0": x0, "image": image}
 
     def decode(self, fp=None, stream=None, unit_range=False):
@@ -215,11 +221,11 @@ class SD15_1step_codec_stage1:
             return self._decode_after_entropy(entropy_out, unit_range)
 
     @torch.no_grad()
-    def _decode_after_entropy(self, entropy_out, unit_range=False):
+    def _decode_after_entropy(self, entropy_out, unit_range=False, vae_gate=None):
         """Synthesis transform, UNet step, x0, VAE decoder, crop: everything after the rANS hops."""
         y_hat, z_semantic, orig_hw, pad_hw, pad_size = entropy_out
         h_detail_hat, y_semantic = self.codec_model.synthesis(y_hat, z_semantic)
-        out = self.decode_latents(h_detail_hat, y_semantic)
+        out = self.decode_latents(h_detail_hat, y_semantic, vae_gate)
         image = out["image"]
         H, W = orig_hw[0]
         if any(hw != (H, W) for hw in orig_hw):
@@ -228,9 +234,9 @@ class SD15_1step_codec_stage1:
         K.image_out(image, res, H, W, unit_range)
         return res
 
-    def pipeline(self, depth=2, s_streams=2, z_only=False):
+    def pipeline(self, depth=2, s_streams=2, z_only=False, serialise_vae=True):
         """z_only: the batches are indices-only containers of the ex-low-rate model (`decode_z_only_stream`)."""
-        return DecodePipeline(self, depth, s_streams, z_only)
+        return DecodePipeline(self, depth, s_streams, z_only, serialise_vae)
 
     def decode_z_only_stream(self, fp=None, stream=None, unit_range=False):
         """Decoder of the ex-low-rate model from files / byte strings: the 16 B + ceil(14 n / 8) B containers written by
@@ -270,7 +276,7 @@ class DecodePipeline:
     Hand-overs are HIP events; results are bit-identical to `decode` (same kernels, same order per batch;
     scratch buffers are per stream, layers.Workspace).  No inter-GPU traffic: one pipeline per process / GPU."""
 
-    def __init__(self, model, depth=2, s_streams=2, z_only=False):
+    def __init__(self, model, depth=2, s_streams=2, z_only=False, serialise_vae=True):
         import queue
         import threading
         self.model = model
@@ -279,6 +285,13 @@ class DecodePipeline:
         with torch.cuda.device(self.dev):
             self.stream_e = torch.cuda.Stream(device=self.dev, priority=-1)
             self.streams_s = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, s_streams))]
+        # The VAE decoders of the stage-S streams run one after the other ON THE GPU (each waits for the previous one's
+        # end-of-VAE event): two VAE decoders side by side only time-slice the same CUs -- every one of their kernels
+        # fills the chip on its own -- whereas a VAE next to the other batch's synthesis / UNet (hundreds of kernels of
+        # 72..720 workgroups) fills the CUs those leave idle.  No host thread blocks on it.
+        self.serialise_vae = serialise_vae and len(self.streams_s) > 1
+        self._vae_lock = threading.Lock()
+        self._vae_done = None
         self._in = queue.Queue()
         self._mid = queue.Queue(maxsize=max(1, depth, s_streams))
         self._worker = threading.Thread(target=self._entropy_loop, daemon=True)
@@ -335,7 +348,7 @@ class DecodePipeline:
                     stream.wait_event(ev)
                     for v in (out[0], out[1]):      # y_hat / z_semantic were allocated on the entropy stream
                         v.t.record_stream(stream)
-                    res = self.model._decode_after_entropy(out, unit_range)
+                    res = self.model._decode_after_entropy(out, unit_range, _VaeGate(self, stream) if self.serialise_vae else None)
                     ev_done = torch.cuda.Event()
                     ev_done.record(stream)
                 entry = (res, ev_done, stream, None)
@@ -381,6 +394,26 @@ class DecodePipeline:
         self._worker.join(timeout=10)
         for t in self._s_workers:
             t.join(timeout=10)
+
+
+class _VaeGate:
+    """Orders the VAE stages of a DecodePipeline's streams on the device: entering makes `stream` wait for the event the
+    previous VAE stage recorded at its end, leaving records this stage's.  The host lock only covers the enqueueing."""
+
+    def __init__(self, pipe, stream):
+        self.pipe, self.stream = pipe, stream
+
+    def __enter__(self):
+        self.pipe._vae_lock.acquire()
+        if self.pipe._vae_done is not None:
+            self.stream.wait_event(self.pipe._vae_done)
+
+    def __exit__(self, *exc):
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.pipe._vae_done = ev
+        self.pipe._vae_lock.release()
+        return False
 
 
 def check_state_dicts(ff, codec, vae):
