@@ -71,7 +71,30 @@ __global__ __launch_bounds__(512, 2) void conv_win_kernel(const onedc_conv_param
     const int pt = dv_n.div(logical);               // patch index over all images
     const int n0 = (logical - pt * tiles_n) * 128;
     const int img = dv_pi.div(pt), pin = pt - img * tiles_pi;
-    const int ty = dv_x.div(pin), tx = pin - ty * tiles_x;
+    // Patch order inside an image: bands of four patch rows, inside a band column by column from top to bottom.  The
+    // patch that follows on this XCD is then the one BELOW (its window shares two of eighteen rows with this one's and
+    // finds them in L2), left / right neighbours are four patches apart; in row-major order the vertical neighbour came
+    // a whole patch row later (48 patches x 82 KB at 768x768: the XCD's L2 had turned over).  `dv_x` divides by 4 * tiles_x.
+    int ty, tx;
+    {
+        const int band = dv_x.div(pin), inb = pin - band * 4 * tiles_x;
+        const int left = tiles_y - band * 4, rows = left < 4 ? left : 4;      // patch rows of this band
+        int r;
+        if (rows == 4) {
+            tx = inb >> 2;
+            r = inb & 3;
+        } else if (rows == 2) {
+            tx = inb >> 1;
+            r = inb & 1;
+        } else if (rows == 1) {
+            tx = inb;
+            r = 0;
+        } else {                                                               // 3: exact for inb < 32768
+            tx = (inb * 21846) >> 16;
+            r = inb - 3 * tx;
+        }
+        ty = band * 4 + r;
+    }
     const int y0 = ty * 16, x0 = tx * 16;           // output origin of the patch
 
     // ---- DMA geometry: buffer descriptors, per-lane byte offsets fixed for the whole kernel ------------------
@@ -542,7 +565,7 @@ int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st) {
     const int Ktot = 9 * p.Cin;
     const int64_t blocks = (int64_t)tiles_n * tiles_x * tiles_y * p.B;
     if (blocks > 0x7fffffff) return -1;
-    const OnedcFastDiv dv_n((uint32_t)tiles_n), dv_pi((uint32_t)(tiles_x * tiles_y)), dv_x((uint32_t)tiles_x);
+    const OnedcFastDiv dv_n((uint32_t)tiles_n), dv_pi((uint32_t)(tiles_x * tiles_y)), dv_x((uint32_t)(4 * tiles_x));
     if (p.gn_ab) {
         if (!onedc_conv_win_gn_ok(p)) return -13;
         hipLaunchKernelGGL((conv_win_kernel<false, true>), dim3((unsigned)blocks), dim3(512), WIN_LDS + p.Cin * 8, st, p,
