@@ -50,6 +50,41 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_native, "HIP_SO", "/nonexistent/libonedc_hip.so")
     with pytest.raises(_native.NativeLibraryError):
         _native.hip()
+    monkeypatch.setattr(_native, "_hip_f16", None)
+    monkeypatch.setattr(_native, "HIP_F16_SO", "/nonexistent/libonedc_hip_f16.so")
+    with pytest.raises(_native.NativeLibraryError):
+        _native.hip("f16")
+    monkeypatch.setattr(kernels, "_libs", {})
+    with pytest.raises(_native.NativeLibraryError):       # the default format's library is the one the product asks for
+        kernels.lib()
+    with pytest.raises(ValueError):
+        _native.hip("fp8")
+
+
+def test_activation_format_context_is_thread_local():
+    """`kernels.act_format` switches the 16-bit format for the calling thread only (the pipeline's worker threads set
+    their own), and `a16()` follows it."""
+    import threading
+    import torch
+    seen = {}
+    with kernels.act_format("bf16"):
+        assert kernels.act() == "bf16" and kernels.a16() == torch.bfloat16
+
+        def other():
+            seen["act"] = kernels.act()
+            kernels.set_act("f16")
+            seen["after"] = kernels.a16()
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert kernels.act() == "bf16"
+        with kernels.act_format("f16"):
+            assert kernels.a16() == torch.float16
+        assert kernels.act() == "bf16"
+    assert seen["act"] == kernels.DEFAULT_ACT and seen["after"] == torch.float16
+    assert kernels.act() == kernels.DEFAULT_ACT
+    with pytest.raises(ValueError):
+        kernels.set_act("fp8")
 
 
 def test_product_never_imports_the_oracle():
