@@ -112,7 +112,7 @@ def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, produ
     """Oracle encode + decode of ONE picture of the batch on the host (the same picture and latent noise the product
     coded), its stream size against the product's, and the prior's table-index decisions against the product's on the
     product's own symbols ("bpp delta and scale-index mismatch rate vs ref_cpu")."""
-    from onedc_amd.entropy.utils import decode_i
+    from onedc_amd.entropy.utils import decode_i, unpack_indices
     from oracle import rans_port
     from oracle import torch_ref as R
     cores = max(1, min(threads, os.cpu_count() or 1))
@@ -141,9 +141,7 @@ def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, produ
     d = decode_i(product_blob, 14, 64)
     # teacher-forced table-index agreement: the oracle's prior on the PRODUCT's z indices, fed the product's symbols
     trace = []
-    idx_p = torch.from_numpy(np.asarray(
-        __import__("onedc_amd.entropy.utils", fromlist=["unpack_indices"]).unpack_indices(d["bit_stream_z"], n_idx, 14)
-    ).reshape(idx.shape).astype(np.int64))
+    idx_p = torch.from_numpy(np.asarray(unpack_indices(d["bit_stream_z"], n_idx, 14)).reshape(idx.shape).astype(np.int64))
     model.codec_model.decompress([d["bit_stream_y"]], idx_p.to(model.device, torch.int32), trace=trace)
     mism = total = 0
     with torch.no_grad():
