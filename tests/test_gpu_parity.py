@@ -581,5 +581,6 @@ def test_softmax_rows_long_rows_match_torch():
     got = p.view(rows, n_pad).float().cpu()
     assert float(got[:, n:].abs().max()) == 0.0
     ref = torch.softmax(s.double(), -1)
-    assert float((got[:, :n].double() - ref).abs().max()) <= 2e-3 * float(ref.max())
-    assert float((got[:, :n].double().sum(-1) - 1).abs().max()) <= 2e-3
+    tol = 2e-3 if K.act() == "f16" else 1e-2                  # output rounding: 11 / 8 significant bits
+    assert float((got[:, :n].double() - ref).abs().max()) <= tol * float(ref.max())
+    assert float((got[:, :n].double().sum(-1) - 1).abs().max()) <= tol
