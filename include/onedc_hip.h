@@ -69,7 +69,8 @@ typedef struct onedc_conv_params {
     int32_t tile;                       /* 0: pick the kernel automatically.  Forcing one (tests, benchmarks):
                                            128 = 4-wave kernels (128x128 / 64x128 / 16x256 tiles),
                                            256 = 8-wave 256x256 tile, 129 = 8-wave 128(ch)x256(px) tile,
-                                           130 = 3x3 window kernel (16x16-pixel patches, stride 1, pad 1) */
+                                           130 = 3x3 window kernel (16x16-pixel patches, stride 1, pad 1), 8 waves,
+                                           131 = the same layer on the 4-wave window kernel (two workgroups per CU) */
     int32_t stats_gran;                 /* channels per statistics entry: 4 (quads), or 2 (pairs) for buffers whose
                                            GroupNorm groups are not multiples of 4 channels (320, 960 channels) */
     int32_t patch16;                    /* set by onedc_conv_gemm (callers leave 0): pixel tiles are 16x16 patches */
@@ -100,7 +101,8 @@ enum {
     ONEDC_KERNEL_64X128 = 6,       /* conv_gemm_kernel<Tile<64,128>> */
     ONEDC_KERNEL_128X128 = 7,      /* conv_gemm_kernel<Tile<128,128>> */
     ONEDC_KERNEL_F32_128X128 = 8,  /* conv_gemm_kernel<Tile<128,128>, f32> (exact-f32 path) */
-    ONEDC_KERNEL_F32_64X128 = 9    /* conv_gemm_kernel<Tile<64,128>, f32>: the same for grids of less than two rounds */
+    ONEDC_KERNEL_F32_64X128 = 9,   /* conv_gemm_kernel<Tile<64,128>, f32>: the same for grids of less than two rounds */
+    ONEDC_KERNEL_WIN3X3_4W = 10    /* conv_win4_kernel: the window kernel as 4-wave workgroups, two per CU */
 };
 int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
 const char *onedc_conv_kernel_name(int kernel_id);

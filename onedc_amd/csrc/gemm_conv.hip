@@ -259,6 +259,8 @@ int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st);  
 bool onedc_conv_win_ok(const onedc_conv_params &p);                             // gemm_conv_win.hip
 int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
 bool onedc_conv_win_gn_ok(const onedc_conv_params &p);                          // gn_ab (if set) can be honoured
+bool onedc_conv_win4_ok(const onedc_conv_params &p);                            // gemm_conv_win4.hip
+int onedc_conv_win4_launch(const onedc_conv_params &p, hipStream_t st);
 bool onedc_conv_ups_ok(const onedc_conv_params &p);                             // gemm_conv_ups.hip
 int onedc_conv_ups_launch(const onedc_conv_params &p, hipStream_t st);
 
@@ -297,7 +299,7 @@ static int conv_validate(onedc_conv_params &p) {
 static bool conv_win_wanted(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     const int rows128w = (p.Cout + 127) / 128 * 128;
-    return (p.tile == 0 || p.tile == 130) && p.up != 2 && !p.in_f32 && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) &&
+    return (p.tile == 0 || p.tile == 130 || p.tile == 131) && p.up != 2 && !p.in_f32 && onedc_conv_win_ok(p) && !(p.Cout <= 16 && !glu) &&
            rows128w * 5 <= p.Cout * 6;
 }
 
@@ -316,8 +318,11 @@ static int conv_choose(const onedc_conv_params &p) {
     }
     // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per 64-channel chunk):
     // 5-27 % faster than the 128x256 / 256x256 kernels on every 3x3 layer it can take (tools/bench_conv.py)
-    if (conv_win_wanted(p)) return onedc_conv_win_gn_ok(p) ? ONEDC_KERNEL_WIN3X3 : -13;
-    if (p.tile == 130) return -11;
+    if (conv_win_wanted(p)) {
+        if (p.tile == 131) return onedc_conv_win4_ok(p) ? ONEDC_KERNEL_WIN3X3_4W : -11;
+        return onedc_conv_win_gn_ok(p) ? ONEDC_KERNEL_WIN3X3 : -13;
+    }
+    if (p.tile == 130 || p.tile == 131) return -11;
     if (p.gn_ab) return -13;                       // only the window kernel normalises on load
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
@@ -360,6 +365,7 @@ extern "C" const char *onedc_conv_kernel_name(int id) {
         case ONEDC_KERNEL_128X128: return "128x128";
         case ONEDC_KERNEL_F32_128X128: return "f32_128x128";
         case ONEDC_KERNEL_F32_64X128: return "f32_64x128";
+        case ONEDC_KERNEL_WIN3X3_4W: return "win3x3_4w";
         default: return "?";
     }
 }
@@ -373,6 +379,7 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
     const int id = conv_choose(p);
     switch (id) {
         case ONEDC_KERNEL_WIN3X3: return onedc_conv_win_launch(p, st);
+        case ONEDC_KERNEL_WIN3X3_4W: return onedc_conv_win4_launch(p, st);
         case ONEDC_KERNEL_UPS2X2: return onedc_conv_ups_launch(p, st);
         case ONEDC_KERNEL_256X256: return onedc_conv_gemm256_launch(p, st);
         case ONEDC_KERNEL_128X256: return onedc_conv_gemm128x256_launch(p, st);
@@ -394,5 +401,6 @@ extern "C" int onedc_conv_win_takes(const onedc_conv_params *pp) {
     if (!conv_win_wanted(p)) return 0;
     static const float2 dummy = {0.f, 0.f};
     if (!p.gn_ab) p.gn_ab = (const float *)&dummy; // the question is about the normalising variant
+    if (p.tile == 131) return onedc_conv_win4_ok(p) ? 1 : 0;
     return onedc_conv_win_gn_ok(p) ? 1 : 0;
 }

@@ -1,0 +1,482 @@
+// gemm_conv_win4.hip — the 3x3 window convolution (gemm_conv_win.hip) re-cut so that TWO workgroups share a CU.
+//
+// The 8-wave window kernel owns a CU alone (133 KB of LDS): nothing runs while a workgroup fetches its first window
+// (2.4 us), finishes its outputs (2.7 us) or hands the CU to its successor (1.3 us) -- 6-7 us of a 19 us tile on the
+// 128-channel layers at 768x768.  Here a workgroup is 4 waves and 74 KB of LDS, two of them are resident per CU, and each
+// SIMD holds one wave of either: while one workgroup is in its prologue or epilogue the other one's K loop has the
+// matrix cores to itself.  What makes that fit:
+//   K-tile       one tap of one 32-CHANNEL chunk (one MFMA k step): window 21 KB instead of 41 KB, weight tile 8 KB
+//   wave tile    64 channels x 128 pixels (8 patch rows): 128 accumulator registers, 12 fragment reads per 32 MFMAs
+//                (the 8-wave kernel: 16 per 32), weights staged once per 16x16 patch as before
+//   LDS images   window: pixel-major, 64 B per pixel = four 16-byte granules (8-channel groups fq) stored at fq ^ s(x),
+//                s(x) = 2 * ((x >> 2) & 1) with x the window column: a fragment read (16 consecutive pixels of a window row,
+//                two fq values per hardware lane group) then covers all 16 bank groups, and because s depends on the column
+//                only, every (row, tap) address is ONE per-lane base per kx plus an instruction immediate.  Weights: a DMA
+//                block is 16 rows x 64 B and granule == lane on both sides (DMA lane l writes it, fragment lane l reads it)
+//   pipeline     inside a wave: fragments of K-tile t + 1 are read while the second half of K-tile t multiplies (A
+//                double-buffered, the two pixel halves alternate), ONE barrier and one counted vmcnt per K-tile; weights
+//                ride a ring of four tiles, issued four K-tiles ahead
+// Same arithmetic contract as the 8-wave kernel's fast path (16-bit output, bias / activation / residual / GroupNorm
+// statistics in the epilogue, line stores through LDS); k order (32-channel chunk, tap): sums round differently from the
+// other kernels, each kernel alone is deterministic and batch-invariant.
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int W4_A = 8192;                   // one weight tile: 128 rows x 32 channels
+constexpr int W4_NA = 4;                     // weight ring
+constexpr int W4_NWB = 21;                   // window blocks of 16 pixels (18 x 18 = 324 -> 336)
+constexpr int W4_W = W4_NWB * 1024;          // 21504 B per window
+constexpr int W4_WOFF = 0;                   // windows first, then the ring
+constexpr int W4_AOFF = 2 * W4_W;            // 43008
+constexpr int W4_LDS = W4_AOFF + W4_NA * W4_A;   // 75776 B: two workgroups per CU
+
+#define W4_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define W4_WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define W4_PIN(x) asm volatile("" : "+v"(x))
+#define W4_WAIT_VMCNT_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int I, int N, class F>
+__device__ __forceinline__ void w4_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        w4_static_for<I + 1, N>(f);
+    }
+}
+
+// ST: GroupNorm statistics of the epilogue (0 none, 4 per channel quad, 2 per channel pair) -- a template parameter of the
+// kernel, not a branch inside it: with the variants side by side in one kernel the compiler hoists their common head
+// (128 fma + the residual conversions) above the branch and spills accumulators around it
+template <bool NORM, int ST>
+__global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_params p, int tiles_n, int tiles_x, int tiles_y,
+                                                           int Ktot, OnedcFastDiv dv_n, OnedcFastDiv dv_pi,
+                                                           OnedcFastDiv dv_x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;        // channel half, pixel half (patch rows 8 wc ..)
+
+    // ---- patch of this workgroup (same order as the 8-wave kernel: channel tile fastest, bands of four patch rows) ----
+    const int tiles_pi = tiles_x * tiles_y;
+    const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_pi * p.B);
+    const int pt = dv_n.div(logical);
+    const int n0 = (logical - pt * tiles_n) * 128;
+    const int img = dv_pi.div(pt), pin = pt - img * tiles_pi;
+    int ty, tx;
+    {
+        const int band = dv_x.div(pin), inb = pin - band * 4 * tiles_x;
+        const int left = tiles_y - band * 4, rows = left < 4 ? left : 4;
+        int r;
+        if (rows == 4) {
+            tx = inb >> 2;
+            r = inb & 3;
+        } else if (rows == 2) {
+            tx = inb >> 1;
+            r = inb & 1;
+        } else if (rows == 1) {
+            tx = inb;
+            r = 0;
+        } else {
+            tx = (inb * 21846) >> 16;
+            r = inb - 3 * tx;
+        }
+        ty = band * 4 + r;
+    }
+    const int y0 = ty * 16, x0 = tx * 16;
+
+    // ---- DMA geometry ------------------------------------------------------------------------------------------------
+    // lane l of a DMA instruction moves granule l of a 1 KB block: row (l & 15) of the block, channel group l >> 4
+    const int drow = lane & 15, dfq = lane >> 4;    // (weights)
+    const int w_rows = tiles_n * 128;
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)((int64_t)w_rows * Ktot * 2));
+    const unsigned wvoff = (unsigned)((int64_t)(n0 + wave * 16 + drow) * Ktot * 2) + dfq * 16;
+    const unsigned wrow64 = (unsigned)(64 * Ktot * 2);
+    char *const lds_a = smem + W4_AOFF;
+    // weights of K-tile (32-channel chunk c32, tap) into ring slot `slot`: row blocks `wave` and `wave + 4`
+    auto stage_A = [&](int tap, int c32, int slot) {
+        char *dst = lds_a + slot * W4_A + wave * 1024;
+        const unsigned so = (unsigned)(tap * p.Cin + c32 * 32) * 2;
+        glds16_buf(w_rsrc, wvoff, so, dst);
+        glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 4096);
+    };
+    stage_A(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
+    const unsigned x_bytes = img_bytes < 0xfffff000ll ? (unsigned)img_bytes : 0xfffff000u;
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc((const char *)p.x + img * img_bytes, x_bytes);
+    constexpr int MAXWB = 6;                          // window blocks wave + 4 k: wave 0 has six, the others five
+    const int nwb = wave == 0 ? 6 : 5;
+    // window block: 16 pixels x 64 B, lane l moves granule (l & 3) of pixel l >> 2: source channel group (l & 3) ^ s(x)
+    unsigned woff[MAXWB];
+    unsigned sbits = 0;                               // bit k: s(x) != 0 for this lane's pixel of block k (NORM: which channels)
+#pragma unroll
+    for (int k = 0; k < MAXWB; ++k) {
+        const int w = (wave + 4 * k) * 16 + (lane >> 2);
+        const int wy = (w * 3641) >> 16, wx = w - wy * 18;           // w / 18, exact for w < 1 << 12
+        const int iy = y0 - 1 + wy, ix = x0 - 1 + wx;
+        const bool ok = w < 324 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        const int sfq = (lane & 3) ^ (((wx >> 2) & 1) << 1);
+        sbits |= (unsigned)((wx >> 2) & 1) << k;
+        woff[k] = ok ? (unsigned)((iy * p.IW + ix) * p.x_cs + p.x_co) * 2u + sfq * 16 : x_bytes;
+    }
+    auto stage_W = [&](int k, int c32, int wbuf) {
+        glds16_buf(x_rsrc, woff[k], (unsigned)c32 * 64, smem + W4_WOFF + wbuf * W4_W + (wave + 4 * k) * 1024);
+    };
+#pragma unroll
+    for (int k = 0; k < MAXWB; ++k)
+        if (k < nwb) stage_W(k, 0, 0);
+    stage_A(1, 0, 1);
+    stage_A(2, 0, 2);
+    stage_A(3, 0, 3);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // NORM: x is the raw tensor in front of a GroupNorm (+SiLU); a window block is normalised IN PLACE two or more taps
+    // after its DMA was issued: the lane that moved a granule reads it back, applies v = silu(a[c] * x + b[c]) -- the
+    // operations of onedc_scale_shift_act in the same order, so the conv sees bit-identical operands -- and writes it
+    // again; halo granules stay zero (the conv pads the NORMALISED tensor).  (a, b) of the image sit behind the ring.
+    auto norm_block = [&](int k, int c32, int wbuf) {
+        const int addr = W4_WOFF + wbuf * W4_W + (wave + 4 * k) * 1024 + lane * 16;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        // (all LDS traffic of this lambda is asm: in front of an LDS access it can see, the compiler drains vmcnt --
+        // it cannot prove that the LDS-DMA in flight does not alias it -- and with it the prefetch distance of the loop)
+        u32x4_t raw;
+        f32x4 ab[2];                                 // (a, b) pairs of four of the lane's 8 channels
+        const int cbase = c32 * 32 + ((lane & 3) ^ (((sbits >> k) & 1) << 1)) * 8;
+        const int abaddr = W4_LDS + cbase * 8;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(raw) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ab[0]) : "v"(abaddr));
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(ab[1]) : "v"(abaddr));
+        const bool live = woff[k] != x_bytes;
+        u32x4_t o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1) {                            // second four channels into the same registers
+                asm volatile("ds_read_b128 %0, %1 offset:32" : "+v"(ab[0]) : "v"(abaddr));
+                asm volatile("ds_read_b128 %0, %1 offset:48" : "+v"(ab[1]) : "v"(abaddr));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw), "+v"(ab[0]), "+v"(ab[1]));
+            const f32x4 ab0 = ab[0], ab1 = ab[1];     // (a, b) of channels 4 h .. 4 h + 3
+            const uint32_t w0 = h ? raw[2] : raw[0], w1 = h ? raw[3] : raw[1];
+            float v0 = __builtin_fmaf(a2f((a16_t)(w0 & 0xffff)), ab0[0], ab0[1]);
+            float v1 = __builtin_fmaf(a2f((a16_t)(w0 >> 16)), ab0[2], ab0[3]);
+            float v2 = __builtin_fmaf(a2f((a16_t)(w1 & 0xffff)), ab1[0], ab1[1]);
+            float v3 = __builtin_fmaf(a2f((a16_t)(w1 >> 16)), ab1[2], ab1[3]);
+            if (p.gn_silu) {
+                v0 = silu_f(v0);
+                v1 = silu_f(v1);
+                v2 = silu_f(v2);
+                v3 = silu_f(v3);
+            }
+            o[2 * h] = live ? pack_a2(v0, v1) : 0u;
+            o[2 * h + 1] = live ? pack_a2(v2, v3) : 0u;
+        }
+        asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(o) : "memory");
+    };
+    if (NORM) {
+        float2 *const lds_ab = (float2 *)(smem + W4_LDS);
+        for (int c = tid; c < p.Cin; c += 256) lds_ab[c] = ((const float2 *)p.gn_ab)[(int64_t)img * p.Cin + c];
+        W4_WAIT_VMCNT(6);                            // this wave's blocks of window 0 are in (weights 1 .. 3 may fly on)
+        __syncthreads();                             // (a, b) are in LDS
+#pragma unroll
+        for (int k = 0; k < MAXWB; ++k)
+            if (k < nwb) norm_block(k, 0, 0);
+        W4_WAIT_LGKMCNT(0);
+    }
+
+    // ---- fragment addresses --------------------------------------------------------------------------------------------
+    const int frow = lane & 15, fq = lane >> 4;
+    // weights: row block wr * 4 + i of the slot, granule == lane
+    int fao = W4_AOFF + wr * 4096 + lane * 16;
+    // pixels: output (patch row 8 wc + r, column frow) under tap (ky, kx) reads window pixel (8 wc + r + ky) * 18 + frow + kx:
+    // base of the lane for kx, immediate ((r + ky) * 18 + kx) * 64
+    int wrd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+        wrd[kx] = W4_WOFF + (8 * wc * 18 + frow) * 64 + ((fq ^ ((((frow + kx) >> 2) & 1) << 1)) << 4);
+    W4_PIN(fao);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) W4_PIN(wrd[kx]);
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            acc[i][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(acc[i][r]));
+        }
+
+    // Fragment registers.  Every LDS read below is an asm statement whose destination is a READ-WRITE operand: old and new
+    // value of a fragment variable then share one register for the whole kernel.  (With plain loads the 18 statically
+    // unrolled K-tiles are 18 x 12 independent values for the register allocator, which lets them wander, renames the
+    // accumulators around them and ends up spilling accumulators -- and a scratch reload in the loop drains vmcnt.)
+    // The compiler does not track these reads: the lgkmcnt waits are explicit and carry the fragments as operands, so
+    // no MFMA that uses them can be moved in front of the wait.
+    a16x8 fa[2][4], fbA[4], fbB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fa[0][i] = fa[1][i] = fbA[i] = fbB[i] = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#define W4_RD(dst, addr, off)                                                                                 \
+    do {                                                                                                      \
+        a16x8 &d__ = (dst);                                                                                   \
+        const int a__ = (addr);                                                                               \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(d__) : "v"(a__), "n"(off));                        \
+    } while (0)
+    // The MFMAs are asm as well, accumulating in place: as builtins the allocator renamed accumulators from K-tile to
+    // K-tile (dst != src C), which took 56 more registers and pushed the DMA offsets into scratch.  What the compiler no
+    // longer sees: the accumulators are matrix-core results (wait states in front of the epilogue's first VALU read).
+#ifdef ONEDC_ACT_F16
+#define W4_MFMA(c, a, b)                                                                                      \
+    do {                                                                                                      \
+        f32x4 &c__ = (c);                                                                                     \
+        const a16x8 &a__ = (a), &b__ = (b);                                                                   \
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c__) : "v"(a__), "v"(b__));               \
+    } while (0)
+#else
+#define W4_MFMA(c, a, b)                                                                                      \
+    do {                                                                                                      \
+        f32x4 &c__ = (c);                                                                                     \
+        const a16x8 &a__ = (a), &b__ = (b);                                                                   \
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c__) : "v"(a__), "v"(b__));              \
+    } while (0)
+#endif
+#define W4_WAIT_LGKM4(n, q)                                                                                   \
+    do {                                                                                                      \
+        a16x8 &q0__ = (q)[0], &q1__ = (q)[1], &q2__ = (q)[2], &q3__ = (q)[3];                                 \
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(q0__), "+v"(q1__), "+v"(q2__), "+v"(q3__) : "n"(n));       \
+    } while (0)
+    const int nc32 = p.Cin >> 5;                     // even: Cin is a multiple of 64
+    __builtin_amdgcn_sched_barrier(0);
+    // window of chunk 0 and the weights of K-tile 0 (issued first) are in; weights 1 .. 3 (six instructions) may fly on
+    W4_WAIT_VMCNT(6);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W4_RD(fa[0][i], fao, i * 1024);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W4_RD(fbA[r], wrd[0], r * 18 * 64);
+    __builtin_amdgcn_sched_barrier(0);
+
+    int slot = 0;                                    // ring slot of the K-tile being multiplied (wave-uniform)
+    // two chunks (18 K-tiles) per pass: window buffer, tap and fragment buffer are compile-time.  LAST: no chunk behind the
+    // odd one of the pair -- its own copy of the body, so that nothing in the loop is decided at run time
+    auto chunk_pair = [&](int c2, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool last2 = decltype(last_tag)::value;
+        w4_static_for<0, 18>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            constexpr int cp = j / 9, tap = j % 9;   // chunk parity (window buffer), tap
+            constexpr int ky = tap / 3, kx = tap % 3;
+            constexpr int cur = j & 1, nxt = cur ^ 1;
+            constexpr bool more = cp == 0 ? true : !last2;           // is there a chunk after this one?
+            constexpr int wb_off = cp * W4_W;                        // this chunk's window buffer
+            const int c32 = c2 + cp;
+            a16x8(&FA)[2][4] = fa;
+            f32x4(&ACC)[4][8] = acc;
+            a16x8(&FBA)[4] = fbA;
+            a16x8(&FBB)[4] = fbB;
+            const int(&WRD)[3] = wrd;
+            // (a) second pixel half of this K-tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W4_RD(FBB[r], WRD[kx], ((4 + r + ky) * 18 + kx) * 64 + wb_off);
+            // (b) first half: patch rows 0 .. 3 of the wave; its fragments were read during the previous K-tile
+            W4_WAIT_LGKM4(4, FA[cur]);
+            W4_WAIT_LGKM4(4, FBA);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W4_MFMA(ACC[i][r], FA[cur][i], FBA[r]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // (c) the weights of K-tile t + 1 (and at tap 8 the whole next window) have landed -- everywhere.
+            //     Issue order per K-tile: weights of K-tile t + 4 (two instructions), then the window blocks of the next
+            //     chunk: blocks 0, 1 at tap 0, blocks 2, 3 at tap 1, block 4 (and 5: wave 0 only) at tap 2.
+            //     Younger than the weights of t + 1: blocks of t - 3, weights t + 2, blocks of t - 2, weights t + 3, blocks
+            //     of t - 1.  NORM normalises block k at tap k + 2 and needs IT landed: fewer may stay in flight.
+            {
+                constexpr auto x2 = [](int k) { return (k == 0 || k == 1) ? 2 : (k == 2 ? 1 : 0); };   // + 1 at tap 2 for wave 0
+                constexpr auto has5 = [](int k) { return k == 2; };
+                constexpr int n_w = 4 + x2(tap - 3) + x2(tap - 2) + x2(tap - 1);
+                constexpr bool w5 = has5(tap - 3) || has5(tap - 2) || has5(tap - 1);
+                // NORM: block tap - 2 and what may follow it in the queue (derivation in DESIGN.md section 3)
+                constexpr int n_n = tap == 2 ? 5 : tap == 3 ? 7 : tap == 4 ? 6 : tap == 5 ? 5 : 63;
+                constexpr bool n5 = tap == 3 || tap == 4 || tap == 5;
+                if constexpr (more) {
+                    if constexpr (NORM && n_n < n_w) {
+                        if (n5 && wave == 0) W4_WAIT_VMCNT_N(n_n + 1);
+                        else W4_WAIT_VMCNT_N(n_n);
+                    } else if constexpr (w5) {
+                        if (wave == 0) W4_WAIT_VMCNT_N(n_w + 1);
+                        else W4_WAIT_VMCNT_N(n_w);
+                    } else {
+                        W4_WAIT_VMCNT_N(n_w);
+                    }
+                } else {                             // last chunk: no window blocks; weights t + 2 / t + 3 exist up to tap 6 / 5
+                    W4_WAIT_VMCNT_N(tap <= 5 ? 4 : tap == 6 ? 2 : 0);
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // (d) DMA: weights of K-tile t + 4 into the slot of K-tile t (every wave is past its reads of it), window
+            //     blocks of the next chunk
+            {
+                constexpr int tap4 = (tap + 4) % 9, over = (tap + 4) / 9;
+                if constexpr (over == 0 || more) stage_A(tap4, c32 + over, slot);
+                if constexpr (tap < 3 && more) {
+                    stage_W(2 * tap, c32 + 1, cp ^ 1);
+                    if (tap < 2 || wave == 0) stage_W(2 * tap + 1, c32 + 1, cp ^ 1);
+                }
+                if constexpr (NORM && more && tap >= 2 && tap - 2 < MAXWB) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap - 2 < 5 || wave == 0) norm_block(tap - 2, c32 + 1, cp ^ 1);
+                }
+            }
+            slot = (slot + 1) & 3;
+            __builtin_amdgcn_sched_barrier(0);
+            // (e) fragments of K-tile t + 1: weights and the first pixel half
+            if constexpr (tap < 8 || more) {
+                constexpr int tap1 = (tap + 1) % 9;
+                constexpr int wb1 = (tap == 8 ? cp ^ 1 : cp) * W4_W;
+                const int a_rd = fao + slot * W4_A;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) W4_RD(FA[nxt][i], a_rd, i * 1024);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W4_RD(FBA[r], WRD[tap1 % 3], ((r + tap1 / 3) * 18 + tap1 % 3) * 64 + wb1);
+                W4_WAIT_LGKM4(8, FBB);
+            } else {
+                W4_WAIT_LGKM4(0, FBB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (f) second half: patch rows 4 .. 7
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W4_MFMA(ACC[i][4 + r], FA[cur][i], FBB[r]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    int c2 = 0;
+    for (; c2 + 2 < nc32; c2 += 2) chunk_pair(c2, std::false_type());
+    chunk_pair(c2, std::true_type());
+
+    // ---- epilogue --------------------------------------------------------------------------------------------------------
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (asm: the compiler does not count wait states)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(acc[i][r]));
+    const int nw = n0 + wr * 64;
+    const bool have = nw + 64 <= p.Cout;             // Cout is a multiple of 64: a wave's channels all exist or none does
+    char *yb = (char *)p.y;
+    const char *rb = (const char *)p.res;
+    float4 bias[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        bias[i] = (p.bias && have) ? *(const float4 *)(p.bias + nw + i * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t pix0 = ((int64_t)img * p.OH + y0 + 8 * wc) * p.OW + x0 + frow;
+    // residual: rows 0 .. 3 now; rows 4 .. 7 are fetched while the first rows are finished, into registers their
+    // accumulators have left (all eight at once would be 64 registers on top of the 128 accumulators)
+    uint2 res[8][4];
+    auto load_res_row = [&](int r) {
+        const a16_t *rp = (const a16_t *)rb + (pix0 + r * p.OW) * p.r_cs + p.r_co + nw + fq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res[r][i] = (rb && have) ? *(const uint2 *)(rp + i * 16) : make_uint2(0u, 0u);
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) load_res_row(r);
+    // every wave is done with the windows and the ring: a wave's 64 x 128 outputs go through 16 KB of them
+    W4_WAIT_LGKMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    lds_char *const my = (lds_char *)smem + wave * 16384;
+    float ssum[2][4], ssq[2][4], ssum_hi[2][4], ssq_hi[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ssum[b][i] = ssq[b][i] = ssum_hi[b][i] = ssq_hi[b][i] = 0.f;
+    if (have) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int px = r * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint2 o = conv_epi_fast_value<ONEDC_EPI_LINEAR, ST>(p, acc[i][r], bias[i], res[r][i], ssum[r >> 2][i],
+                                                                           ssq[r >> 2][i], ssum_hi[r >> 2][i], ssq_hi[r >> 2][i]);
+                const int s8 = i * 4 + fq;
+                *(__attribute__((address_space(3))) u32x2_t *)(my + px * 128 + (((s8 >> 1) ^ (px & 7)) << 4) + (s8 & 1) * 8) =
+                    u32x2_t{o.x, o.y};
+            }
+            if (r == 1 || r == 3) {
+                load_res_row(r + 3);
+                load_res_row(r + 4);
+            }
+        }
+        const int c = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int px = it * 8 + (lane >> 3);           // pixel (row 8 wc + (px >> 4), column px & 15) of the patch
+            const u32x4_t o = *(const __attribute__((address_space(3))) u32x4_t *)(my + px * 128 + ((c ^ (px & 7)) << 4));
+            const int64_t pix = ((int64_t)img * p.OH + y0 + 8 * wc + (px >> 4)) * p.OW + x0 + (px & 15);
+            *(u32x4_t *)((a16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
+        }
+        if (ST != 0) {                                 // two 64-pixel statistics blocks per wave: patch rows 8 wc + 4 b ..
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    conv_stats_store_row(p, ssum[b][i], ssq[b][i], pt * 4 + wc * 2 + b, nw + i * 16 + fq * 4, p.Cout, lane,
+                                         ssum_hi[b][i], ssq_hi[b][i]);
+        }
+    }
+}
+
+}  // namespace
+
+// Layers of the window kernel (onedc_conv_win_ok) whose epilogue is the fast linear one on whole 64-channel wave tiles;
+// with gn_ab, room for the image's (a, b) pairs behind the ring while two workgroups still fit a CU.
+bool onedc_conv_win4_ok(const onedc_conv_params &p) {
+    return !p.up && conv_epi_fast_ok(p, false) && p.epi == ONEDC_EPI_LINEAR && (p.Cout & 63) == 0 &&
+           ((p.y_cs | p.y_co) & 7) == 0 && (!p.res || ((p.r_cs | p.r_co) & 3) == 0) &&
+           (!p.gn_ab || W4_LDS + (int64_t)p.Cin * 8 <= 80 * 1024);
+}
+
+template <bool NORM>
+static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
+    const int tiles_n = (p.Cout + 127) / 128;
+    const int tiles_x = p.OW / 16, tiles_y = p.OH / 16;
+    const int Ktot = 9 * p.Cin;
+    const int64_t blocks = (int64_t)tiles_n * tiles_x * tiles_y * p.B;
+    if (blocks > 0x7fffffff) return -1;
+    const OnedcFastDiv dv_n((uint32_t)tiles_n), dv_pi((uint32_t)(tiles_x * tiles_y)), dv_x((uint32_t)(4 * tiles_x));
+    const dim3 grid((unsigned)blocks), block(256);
+    if (!p.stats)
+        hipLaunchKernelGGL((conv_win4_kernel<NORM, 0>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x);
+    else if (p.stats_gran == 2)
+        hipLaunchKernelGGL((conv_win4_kernel<NORM, 2>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x);
+    else
+        hipLaunchKernelGGL((conv_win4_kernel<NORM, 4>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+int onedc_conv_win4_launch(const onedc_conv_params &p, hipStream_t st) {
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_win4_kernel<false, 0>, W4_LDS},
+                 {(const void *)conv_win4_kernel<false, 2>, W4_LDS},
+                 {(const void *)conv_win4_kernel<false, 4>, W4_LDS},
+                 {(const void *)conv_win4_kernel<true, 0>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<true, 2>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<true, 4>, 80 * 1024}});
+    if (p.gn_ab) return win4_launch<true>(p, st, W4_LDS + p.Cin * 8);
+    return win4_launch<false>(p, st, W4_LDS);
+}

@@ -587,6 +587,118 @@ def test_conv_win3x3_plain(B, H, W, Cin, Cout):
     close(y.torch_nchw(), y2.torch_nchw(), rms=3e-3, mx=2e-2, what="win3x3 vs generic")
 
 
+# ---- the same layers on the 4-wave window kernel (two workgroups per CU; tile=131) --------------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 16, 16, 64, 128),         # one patch, two 32-channel chunks, borders on all four sides
+    (2, 32, 48, 128, 128),        # interior patches, four chunks (two passes of the chunk-pair loop)
+    (1, 48, 32, 192, 320),        # six chunks, 320 channels (the last channel tile has one live wave row)
+    (3, 16, 32, 256, 256),        # two channel tiles, batch
+])
+def test_conv_win3x3_4wave_plain(B, H, W, Cin, Cout):
+    x, w, b = rnd(B, Cin, H, W, seed=321), rnd(Cout, Cin, 3, 3, seed=322, scale=(Cin * 9) ** -0.5), rnd(Cout, seed=323)
+    y = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y, KH=3, tile=131)
+    close(y.torch_nchw(), F.conv2d(x, w, b, padding=1), what="win3x3 4-wave")
+    y2 = new_view(B, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x.to(DEV)), packed(w), b.to(DEV), y2, KH=3, tile=130)
+    close(y.torch_nchw(), y2.torch_nchw(), rms=3e-3, mx=2e-2, what="win3x3 4-wave vs 8-wave")
+
+
+@pytest.mark.parametrize("gran", [4, 2])
+def test_conv_win3x3_4wave_residual_stats_slices(gran):
+    """Residual, bias, input and output in channel slices, GroupNorm statistics (quads; pairs for a 320-channel buffer)
+    left by the epilogue and consumed by group_norm without a statistics pass."""
+    B, H, W, Cin = 2, 32, 16, 128
+    Cout = 128 if gran == 4 else 320
+    x, w, b = rnd(B, Cin, H, W, seed=324), rnd(Cout, Cin, 3, 3, seed=325, scale=1 / 34), rnd(Cout, seed=326)
+    r = rnd(B, Cout, H, W, seed=327)
+    xbuf = from_nchw(torch.cat([rnd(B, 64, H, W, seed=328), x], 1).to(DEV))
+    if gran == 4:
+        ybuf = new_view(B, H, W, Cout + 64, DEV, stats=True)
+        ybuf.t.zero_()
+        yv = ybuf.slice(64, Cout)
+    else:
+        ybuf = new_view(B, H, W, Cout, DEV, stats=True)
+        assert ybuf.stats.gran == 2
+        yv = ybuf
+    K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), yv, KH=3, tile=131, res=from_nchw(r.to(DEV)), stats=True)
+    ref = F.conv2d(x, w, b, padding=1) + r
+    close(yv.torch_nchw(), ref, what="win3x3 4-wave res")
+    if gran == 4:
+        assert float(ybuf.slice(0, 64).torch_nchw().abs().max()) == 0.0
+    g, be = rnd(Cout, seed=329), rnd(Cout, seed=330)
+    out = new_view(B, H, W, Cout, DEV)
+    ws = _WS()
+    K.group_norm(yv, g.to(DEV), be.to(DEV), out, 1e-6, True, ws)
+    assert "gn_partial" not in ws.t
+    close(out.torch_nchw(), F.silu(F.group_norm(ref, 32, g, be, 1e-6)), rms=6e-3, mx=4e-2, what="win3x3 4-wave stats")
+    # the statistics are the 8-wave kernel's to the last bit wherever the outputs are (same 64 pixels, same order)
+    y8 = new_view(B, H, W, Cout, DEV, stats=True)
+    K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), y8, KH=3, tile=130, res=from_nchw(r.to(DEV)), stats=True)
+    close(yv.torch_nchw(), y8.torch_nchw(), rms=3e-3, mx=2e-2, what="4-wave vs 8-wave with residual")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,silu", [(2, 32, 16, 128, 128, True), (1, 16, 48, 320, 128, True),
+                                                 (2, 16, 16, 64, 128, False), (1, 48, 48, 512, 128, True)])
+def test_conv_win3x3_4wave_groupnorm_on_load(B, H, W, Cin, Cout, silu):
+    """conv(act(GroupNorm(x))) + residual on the 4-wave kernel (window blocks normalised in place in LDS): against
+    F.conv2d(F.group_norm), and bit for bit against the same kernel behind the separate scale/shift pass."""
+    x, w, b = rnd(B, Cin, H, W, seed=341), rnd(Cout, Cin, 3, 3, seed=342, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=343)
+    g, be, r = 1 + 0.2 * rnd(Cin, seed=344), 0.5 * rnd(Cin, seed=345), rnd(B, Cout, H, W, seed=346)
+    xbuf = from_nchw(torch.cat([rnd(B, 64, H, W, seed=347), x], 1).to(DEV))        # input is a channel slice
+    outs = []
+    for fuse in (True, False):
+        K.USE_GN_FUSION = fuse
+        try:
+            y = new_view(B, H, W, Cout, DEV, stats=True)
+            ws = _WS()
+            K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), y, KH=3, res=from_nchw(r.to(DEV)), stats=True,
+                        gn=(g.to(DEV), be.to(DEV), 1e-6, silu, ws), tile=131)
+        finally:
+            K.USE_GN_FUSION = True
+        outs.append((y.t[:B * H * W * Cout].clone(), y.stats.t.clone()))
+    n = F.group_norm(x, 32, g, be, 1e-6)
+    ref = F.conv2d(F.silu(n) if silu else n, w, b, padding=1) + r
+    close(y.torch_nchw(), ref, rms=6e-3, mx=4e-2, what="4-wave gn on load (unfused)")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_conv_win3x3_4wave_groupnorm_on_load_race_screen():
+    B, H, W, Cin, Cout = 4, 48, 48, 256, 128
+    x, w = rnd(B, Cin, H, W, seed=351), rnd(Cout, Cin, 3, 3, seed=352, scale=(9 * Cin) ** -0.5)
+    g, be = 1 + 0.2 * rnd(Cin, seed=353), 0.5 * rnd(Cin, seed=354)
+    xv, wp, ws = from_nchw(x.to(DEV)), packed(w), _WS()
+    ref = None
+    for it in range(40):
+        y = new_view(B, H, W, Cout, DEV)
+        K.conv_gemm(xv, wp, None, y, KH=3, gn=(g.to(DEV), be.to(DEV), 1e-6, True, ws), tile=131)
+        got = y.t[:B * H * W * Cout].clone()
+        if ref is None:
+            ref = got
+            close(y.torch_nchw(), F.conv2d(F.silu(F.group_norm(x, 32, g, be, 1e-6)), w, padding=1), rms=6e-3, mx=4e-2,
+                  what="4-wave gn on load race ref")
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"
+
+
+def test_conv_win3x3_4wave_race_screen_and_batch_invariance():
+    x, w = rnd(4, 256, 48, 48, seed=331), rnd(128, 256, 3, 3, seed=332, scale=1 / 48)
+    xv, wp = from_nchw(x.to(DEV)), packed(w)
+    ref = None
+    for it in range(40):
+        y = new_view(4, 48, 48, 128, DEV)
+        K.conv_gemm(xv, wp, None, y, KH=3, tile=131)
+        got = y.t[:4 * 48 * 48 * 128].clone()
+        if ref is None:
+            ref = got
+            close(y.torch_nchw(), F.conv2d(x, w, None, padding=1), what="win3x3 4-wave race ref")
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"
+    y1 = new_view(1, 48, 48, 128, DEV)
+    K.conv_gemm(from_nchw(x[2:3].to(DEV)), wp, None, y1, KH=3, tile=131)
+    assert torch.equal(y1.t[:48 * 48 * 128], ref.view(4, -1)[2])
+
+
 def test_conv_win3x3_upsample_residual_stats_slices():
     B, H, W, Cin, Cout = 2, 16, 24, 128, 128
     x, w, b = rnd(B, Cin, H, W, seed=124), rnd(Cout, Cin, 3, 3, seed=125, scale=1 / 34), rnd(Cout, seed=126)

@@ -29,7 +29,7 @@ SHAPES = [  # (name, B, H, W, Cin, Cout, k, up)
 ]
 
 
-TILES = (129, 256, 130)
+TILES = tuple(int(t) for t in os.environ.get("BENCH_TILES", "129,256,130,131").split(","))
 
 
 def main():
@@ -46,8 +46,8 @@ def main():
         fl = 2.0 * B * OH * OW * Cout * k * k * Cin
         res = []
         for tile in TILES:                      # interleaved in one process (same data, same clocks)
-            if ((tile == 256 and Cout % 256) or (tile in (129, 130) and (Cout + 127) // 128 * 128 * 5 > Cout * 6) or
-                    (tile == 130 and (k != 3 or OH % 16 or OW % 16))):
+            if ((tile == 256 and Cout % 256) or (tile in (129, 130, 131) and (Cout + 127) // 128 * 128 * 5 > Cout * 6) or
+                    (tile in (130, 131) and (k != 3 or OH % 16 or OW % 16)) or (tile == 131 and (up or Cout % 64))):
                 res.append(float("nan"))
                 continue
             for _ in range(2):

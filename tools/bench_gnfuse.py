@@ -33,18 +33,19 @@ for H, Cin, Cout in [(768, 128, 128), (768, 256, 128), (384, 256, 256)]:
     gam, bet = torch.ones(Cin, device=DEV), torch.zeros(Cin, device=DEV)
     y = K.new_view(B, H, H, Cout, DEV)
     ws = WS()
-    out = []
     K.GN_FUSION_MAX_COUT = 1 << 20
-    for fuse in (True, False):
-        K.USE_GN_FUSION = fuse
-        for _ in range(2):
-            K.conv_gemm(x, w, None, y, KH=3, gn=(gam, bet, 1e-6, True, ws))
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            K.conv_gemm(x, w, None, y, KH=3, gn=(gam, bet, 1e-6, True, ws))
-        e1.record()
-        torch.cuda.synchronize()
-        out.append(e0.elapsed_time(e1) / 5)
-    print(f"{H}^2 {Cin}->{Cout}: fused {out[0]:7.3f} ms   separate pass + conv {out[1]:7.3f} ms")
+    for tile in (130, 131):                          # 8-wave / 4-wave window kernel
+        out = []
+        for fuse in (True, False):
+            K.USE_GN_FUSION = fuse
+            for _ in range(2):
+                K.conv_gemm(x, w, None, y, KH=3, gn=(gam, bet, 1e-6, True, ws), tile=tile)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                K.conv_gemm(x, w, None, y, KH=3, gn=(gam, bet, 1e-6, True, ws), tile=tile)
+            e1.record()
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) / 5)
+        print(f"{H}^2 {Cin}->{Cout} tile {tile}: fused {out[0]:7.3f} ms   separate pass + conv {out[1]:7.3f} ms")
