@@ -318,8 +318,13 @@ static int conv_choose(const onedc_conv_params &p) {
     }
     // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per 64-channel chunk):
     // 5-27 % faster than the 128x256 / 256x256 kernels on every 3x3 layer it can take (tools/bench_conv.py)
+    // The 4-wave cut of it (two workgroups per CU hide each other's prologue and epilogue: 3-18 % faster, most on the
+    // 128-channel layers at 768x768) takes every such layer whose epilogue is the plain linear one on whole 64-channel
+    // wave tiles; the rest (fused upsample, activations, GLU, f32 / bf16 output, ragged channel counts) stays on the
+    // 8-wave kernel.  tile 130 / 131 force one or the other.
     if (conv_win_wanted(p)) {
-        if (p.tile == 131) return onedc_conv_win4_ok(p) ? ONEDC_KERNEL_WIN3X3_4W : -11;
+        if (p.tile != 130 && onedc_conv_win4_ok(p)) return ONEDC_KERNEL_WIN3X3_4W;
+        if (p.tile == 131) return -11;
         return onedc_conv_win_gn_ok(p) ? ONEDC_KERNEL_WIN3X3 : -13;
     }
     if (p.tile == 130 || p.tile == 131) return -11;
@@ -401,6 +406,7 @@ extern "C" int onedc_conv_win_takes(const onedc_conv_params *pp) {
     if (!conv_win_wanted(p)) return 0;
     static const float2 dummy = {0.f, 0.f};
     if (!p.gn_ab) p.gn_ab = (const float *)&dummy; // the question is about the normalising variant
-    if (p.tile == 131) return onedc_conv_win4_ok(p) ? 1 : 0;
+    if (p.tile != 130 && onedc_conv_win4_ok(p)) return 1;
+    if (p.tile == 131) return 0;
     return onedc_conv_win_gn_ok(p) ? 1 : 0;
 }

@@ -736,19 +736,21 @@ def test_conv_win3x3_race_screen_and_batch_invariance():
 
 
 def test_conv_win3x3_is_the_automatic_choice_whatever_the_batch():
-    """tile=0 (automatic) takes the window kernel for every eligible 3x3 layer, for one picture as for sixteen:
-    same bits as the forced window kernel, output and statistics."""
+    """tile=0 (automatic) takes a window kernel for every eligible 3x3 layer, for one picture as for sixteen -- the
+    4-wave one where the epilogue is the plain linear one, else the 8-wave one: same bits as the forced kernel, output
+    and statistics."""
     x, w, b = rnd(3, 128, 32, 32, seed=171), rnd(256, 128, 3, 3, seed=172, scale=1 / 34), rnd(256, seed=173)
-    for xs in (x, x[1:2]):
-        outs = []
-        for tile in (130, 0):
-            y = new_view(xs.shape[0], 32, 32, 256, DEV, stats=True)
-            K.conv_gemm(from_nchw(xs.to(DEV)), packed(w), b.to(DEV), y, KH=3, tile=tile, stats=True)
-            outs.append((y.t[:xs.shape[0] * 32 * 32 * 256].clone(), y.stats.t.clone()))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-        if xs.shape[0] == 3:
-            whole = outs[0][0].view(3, -1)[1].clone()
-    assert torch.equal(outs[0][0].view(-1), whole)
+    for epi, forced, name in ((K.EPI_LINEAR, 131, "win3x3_4w"), (K.EPI_SILU, 130, "win3x3")):
+        for xs in (x, x[1:2]):
+            outs = []
+            for tile in (forced, 0):
+                y = new_view(xs.shape[0], 32, 32, 256, DEV, stats=True)
+                K.conv_gemm(from_nchw(xs.to(DEV)), packed(w), b.to(DEV), y, KH=3, tile=tile, stats=True, epi=epi)
+                outs.append((y.t[:xs.shape[0] * 32 * 32 * 256].clone(), y.stats.t.clone()))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), name
+            if xs.shape[0] == 3:
+                whole = outs[0][0].view(3, -1)[1].clone()
+        assert torch.equal(outs[0][0].view(-1), whole), name
 
 
 # ---- x2 upsample + 3x3 as four 2x2 phase convolutions (up=2, gemm_conv_ups.hip) -------------------------------
@@ -891,7 +893,7 @@ def test_softmax_rows_long(n, n_pad):
     assert float(p[:, n:].float().abs().max() if n_pad > n else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("tile", [128, 129, 130])
+@pytest.mark.parametrize("tile", [128, 129, 130, 131])
 def test_group_norm_pair_statistics_320_and_960_channels(tile):
     """Group sizes of 10 / 30 channels (320 / 960-channel buffers of the UNet): the epilogue leaves one entry per
     channel PAIR; concat buffer 640 + 320 = 960 normalised as a whole, and its 320-channel tail on its own."""
