@@ -54,6 +54,15 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
                                                            int Ktot, OnedcFastDiv dv_n, OnedcFastDiv dv_pi,
                                                            OnedcFastDiv dv_x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef EXP_W4_TIMELINE
+    unsigned long long tl[6];
+    tl[0] = __builtin_amdgcn_s_memtime();
+#define W4_TL(i) tl[i] = __builtin_amdgcn_s_memtime()
+#define W4_RT(i) tl[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define W4_TL(i)
+#define W4_RT(i)
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,6 +271,8 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     for (int r = 0; r < 4; ++r) W4_RD(fbA[r], wrd[0], r * 18 * 64);
     __builtin_amdgcn_sched_barrier(0);
 
+    W4_TL(1);
+    W4_RT(4);
     int slot = 0;                                    // ring slot of the K-tile being multiplied (wave-uniform)
     // two chunks (18 K-tiles) per pass: window buffer, tap and fragment buffer are compile-time.  LAST: no chunk behind the
     // odd one of the pair -- its own copy of the body, so that nothing in the loop is decided at run time
@@ -367,6 +378,8 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     for (; c2 + 2 < nc32; c2 += 2) chunk_pair(c2, std::false_type());
     chunk_pair(c2, std::true_type());
 
+    W4_TL(2);
+    W4_RT(5);
     // ---- epilogue --------------------------------------------------------------------------------------------------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (asm: the compiler does not count wait states)
 #pragma unroll
@@ -399,22 +412,36 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     lds_char *const my = (lds_char *)smem + wave * 16384;
-    float ssum[2][4], ssq[2][4], ssum_hi[2][4], ssq_hi[2][4];
+    // Epilogue arithmetic on channel PAIRS (v_pk_fma_f32 / v_pk_add_f32: no MFMA of this wave is in flight any more, and
+    // a wave finishes 128 outputs per lane): value = alpha * acc + bias + residual; statistics are kept per pair -- (sum,
+    // sum of squares) of (v0, v1) and of (v2, v3) -- and folded to quads at the end where the buffer wants quads.  Fixed
+    // order, no atomics; the order is this kernel's own (its k order already is).
+    f32x2_t s_lo[2][4], q_lo[2][4], s_hi[2][4], q_hi[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ssum[b][i] = ssq[b][i] = ssum_hi[b][i] = ssq_hi[b][i] = 0.f;
+        for (int i = 0; i < 4; ++i) s_lo[b][i] = q_lo[b][i] = s_hi[b][i] = q_hi[b][i] = f32x2_t{0.f, 0.f};
     if (have) {
+        const f32x2_t alpha2 = {p.alpha, p.alpha};
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int px = r * 16 + frow;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint2 o = conv_epi_fast_value<ONEDC_EPI_LINEAR, ST>(p, acc[i][r], bias[i], res[r][i], ssum[r >> 2][i],
-                                                                           ssq[r >> 2][i], ssum_hi[r >> 2][i], ssq_hi[r >> 2][i]);
+                const f32x4 a = acc[i][r];
+                f32x2_t lo = __builtin_elementwise_fma(f32x2_t{a[0], a[1]}, alpha2, f32x2_t{bias[i].x, bias[i].y});
+                f32x2_t hi = __builtin_elementwise_fma(f32x2_t{a[2], a[3]}, alpha2, f32x2_t{bias[i].z, bias[i].w});
+                lo += f32x2_t{a2f_lo(res[r][i].x), a2f_hi(res[r][i].x)};
+                hi += f32x2_t{a2f_lo(res[r][i].y), a2f_hi(res[r][i].y)};
+                if (ST != 0) {
+                    s_lo[r >> 2][i] += lo;
+                    s_hi[r >> 2][i] += hi;
+                    q_lo[r >> 2][i] = __builtin_elementwise_fma(lo, lo, q_lo[r >> 2][i]);
+                    q_hi[r >> 2][i] = __builtin_elementwise_fma(hi, hi, q_hi[r >> 2][i]);
+                }
                 const int s8 = i * 4 + fq;
                 *(__attribute__((address_space(3))) u32x2_t *)(my + px * 128 + (((s8 >> 1) ^ (px & 7)) << 4) + (s8 & 1) * 8) =
-                    u32x2_t{o.x, o.y};
+                    u32x2_t{pack_a2(lo[0], lo[1]), pack_a2(hi[0], hi[1])};
             }
             if (r == 1 || r == 3) {
                 load_res_row(r + 3);
@@ -429,13 +456,30 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
             const int64_t pix = ((int64_t)img * p.OH + y0 + 8 * wc + (px >> 4)) * p.OW + x0 + (px & 15);
             *(u32x4_t *)((a16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
         }
+#ifdef EXP_W4_TIMELINE
+        W4_TL(3);
+        if (lane == 0) {     // diagnostic build: p.stats is a debug buffer [blocks][4 waves][8] of int64
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+            unsigned long long *dbg = (unsigned long long *)p.stats + ((int64_t)blockIdx.x * 4 + wave) * 8;
+            dbg[0] = ((unsigned long long)xcc << 32) | hwid;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dbg[1 + i] = tl[i];
+        }
+        return;
+#endif
         if (ST != 0) {                                 // two 64-pixel statistics blocks per wave: patch rows 8 wc + 4 b ..
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    conv_stats_store_row(p, ssum[b][i], ssq[b][i], pt * 4 + wc * 2 + b, nw + i * 16 + fq * 4, p.Cout, lane,
-                                         ssum_hi[b][i], ssq_hi[b][i]);
+                for (int i = 0; i < 4; ++i) {
+                    const float sl = s_lo[b][i][0] + s_lo[b][i][1], ql = q_lo[b][i][0] + q_lo[b][i][1];
+                    const float sh = s_hi[b][i][0] + s_hi[b][i][1], qh = q_hi[b][i][0] + q_hi[b][i][1];
+                    if (ST == 4)
+                        conv_stats_store_row(p, sl + sh, ql + qh, pt * 4 + wc * 2 + b, nw + i * 16 + fq * 4, p.Cout, lane);
+                    else
+                        conv_stats_store_row(p, sl, ql, pt * 4 + wc * 2 + b, nw + i * 16 + fq * 4, p.Cout, lane, sh, qh);
+                }
         }
     }
 }

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Diagnostic (EXP_W4_TIMELINE build only): phases of a 4-wave window-kernel workgroup from s_memtime stamps, and the
+shader clock the chip holds inside the K loop (delta s_memtime / delta s_memrealtime x 100 MHz, MI355X_MICROARCH.md
+'DVFS give-back' item 6), after two seconds of back-to-back launches on random data.
+usage: tools/exp_build.sh w4tl -DEXP_W4_TIMELINE; ONEDC_HIP_F16_SO=tools/exp/libonedc_hip_w4tl.so timeline_win4.py B H W Cin Cout"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from onedc_amd import kernels as K
+from onedc_amd import pack
+
+B, H, W, Cin, Cout = map(int, sys.argv[1:6])
+DEV = "cuda:0"
+g = torch.Generator(device=DEV).manual_seed(0)
+x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, W, Cin)
+w = pack.pack_matrix(torch.randn(Cout, 9 * Cin, generator=g, device=DEV) * (9 * Cin) ** -0.5, DEV)
+y = K.new_view(B, H, W, Cout, DEV)
+blocks = (Cout + 127) // 128 * (H // 16) * (W // 16) * B
+dbg = torch.zeros(blocks * 4 * 8, dtype=torch.int64, device=DEV)
+
+
+class FakeStats:
+    t = dbg
+    gran = 4
+
+    def mark(self, *a):
+        pass
+
+
+y.stats = FakeStats()
+t_end = time.time() + 2.0
+n = 0
+while time.time() < t_end:
+    for _ in range(20):
+        K.conv_gemm(x, w, None, y, KH=3, tile=131, stats=True)
+    torch.cuda.synchronize()
+    n += 20
+d = dbg.view(blocks, 4, 8).cpu().numpy().astype(np.int64)
+t0, t1, t2, t3 = d[:, :, 1].min(1), d[:, :, 2].max(1), d[:, :, 3].max(1), d[:, :, 4].max(1)
+clk = (d[:, :, 3] - d[:, :, 2]) / np.maximum(d[:, :, 6] - d[:, :, 5], 1) * 100.0      # MHz
+print(f"{blocks} workgroups, {n} launches; s_memtime ticks per workgroup (min start .. max end over its 4 waves):")
+print(f"  prologue (entry -> first fragments) {np.mean(t1 - t0):9.0f}")
+print(f"  K loop                              {np.mean(t2 - t1):9.0f}   ({(Cin // 32) * 9} K-tiles: {np.mean(t2 - t1) / ((Cin // 32) * 9):.0f} per K-tile)")
+print(f"  epilogue                            {np.mean(t3 - t2):9.0f}")
+print(f"  whole workgroup                     {np.mean(t3 - t0):9.0f}")
+print(f"  shader clock inside the K loop      median {np.median(clk):7.0f} MHz  (p10 {np.percentile(clk, 10):.0f}, p90 {np.percentile(clk, 90):.0f})")
+
+# ---- who shares a CU, and are the two resident workgroups in phase? ---------------------------------------------------
+hw = d[:, 0, 0]
+xcc, hwid = hw >> 32, hw & 0xffffffff
+wave_id, simd, cu, sh, se = hwid & 15, (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 12) & 1, (hwid >> 13) & 7
+cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+print("wave slot (HW_ID.WAVE_ID) of wave 0 over all workgroups:", np.bincount(wave_id, minlength=4)[:8])
+first = np.arange(blocks) < 512
+print("  ... of launch indices < 256:", np.bincount(wave_id[:256], minlength=4)[:4], " 256..511:", np.bincount(wave_id[256:512], minlength=4)[:4])
+print("distinct CUs:", len(np.unique(cu_key)))
+# K-loop interval overlap between the two slots of a CU: for every workgroup, the fraction of its prologue + epilogue time
+# during which the OTHER slot of its CU was inside a K loop
+ks, ke = d[:, 0, 2], d[:, 0, 3]
+st, en = d[:, 0, 1], d[:, 0, 4]
+frac = []
+for c in np.unique(cu_key)[:64]:
+    idx = np.where(cu_key == c)[0]
+    for s in (0, 1):
+        me = idx[(wave_id[idx] & 1) == s]
+        ot = idx[(wave_id[idx] & 1) != s]
+        for i in me[2:-2]:
+            oh = [(st[i], ks[i]), (ke[i], en[i])]
+            tot = sum(b - a for a, b in oh)
+            cov = 0
+            for a, b in oh:
+                for j in ot:
+                    cov += max(0, min(b, ke[j]) - max(a, ks[j]))
+            frac.append(cov / max(tot, 1))
+print(f"fraction of a workgroup's prologue + epilogue during which the CU's other slot is in its K loop: {np.mean(frac):.2f}")
