@@ -302,7 +302,7 @@ def main():
         dom = max(by_tile, key=lambda k: by_tile[k][1])
         flops, secs, launches, dom_bytes = by_tile[dom]
         kernel_symbol = {"256x256": "conv_gemm256_kernel", "128x256": "conv_gemm128x256_kernel", "win3x3": "conv_win_kernel",
-                         "win3x3_4w": "conv_win4_kernel",
+                         "win3x3_4w": "conv_win4_kernel", "ups2x2_4w": "conv_win4_kernel",
                          "ups2x2": "conv_ups_kernel"}.get(dom, f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
                                                            + (" f32" if dom.startswith("f32") else ""))
         # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in

@@ -102,7 +102,8 @@ enum {
     ONEDC_KERNEL_128X128 = 7,      /* conv_gemm_kernel<Tile<128,128>> */
     ONEDC_KERNEL_F32_128X128 = 8,  /* conv_gemm_kernel<Tile<128,128>, f32> (exact-f32 path) */
     ONEDC_KERNEL_F32_64X128 = 9,   /* conv_gemm_kernel<Tile<64,128>, f32>: the same for grids of less than two rounds */
-    ONEDC_KERNEL_WIN3X3_4W = 10    /* conv_win4_kernel: the window kernel as 4-wave workgroups, two per CU */
+    ONEDC_KERNEL_WIN3X3_4W = 10,   /* conv_win4_kernel: the window kernel as 4-wave workgroups, two per CU */
+    ONEDC_KERNEL_UPS2X2_4W = 11    /* conv_win4_kernel<2>: the upsample phases on the same 4-wave machinery */
 };
 int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
 const char *onedc_conv_kernel_name(int kernel_id);

@@ -261,6 +261,8 @@ int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
 bool onedc_conv_win_gn_ok(const onedc_conv_params &p);                          // gn_ab (if set) can be honoured
 bool onedc_conv_win4_ok(const onedc_conv_params &p);                            // gemm_conv_win4.hip
 int onedc_conv_win4_launch(const onedc_conv_params &p, hipStream_t st);
+bool onedc_conv_ups4_ok(const onedc_conv_params &p);                            // (given onedc_conv_ups_ok)
+int onedc_conv_ups4_launch(const onedc_conv_params &p, hipStream_t st);
 bool onedc_conv_ups_ok(const onedc_conv_params &p);                             // gemm_conv_ups.hip
 int onedc_conv_ups_launch(const onedc_conv_params &p, hipStream_t st);
 
@@ -306,7 +308,11 @@ static bool conv_win_wanted(const onedc_conv_params &p) {
 static int conv_choose(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     // up == 2: x2 upsample + 3x3 decomposed into four 2x2 phase convolutions; w is the phase-packed matrix
-    if (p.up == 2) return onedc_conv_ups_ok(p) ? ONEDC_KERNEL_UPS2X2 : -12;
+    if (p.up == 2) {
+        if (!onedc_conv_ups_ok(p)) return -12;
+        if (p.tile != 130 && onedc_conv_ups4_ok(p)) return ONEDC_KERNEL_UPS2X2_4W;
+        return p.tile == 131 ? -11 : ONEDC_KERNEL_UPS2X2;
+    }
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
     if (p.in_f32) {
         // the f32 matrix cores run at 1/16 of the 16-bit rate: a 128x128x256 tile is 15 us of MFMA time, and the prior
@@ -371,6 +377,7 @@ extern "C" const char *onedc_conv_kernel_name(int id) {
         case ONEDC_KERNEL_F32_128X128: return "f32_128x128";
         case ONEDC_KERNEL_F32_64X128: return "f32_64x128";
         case ONEDC_KERNEL_WIN3X3_4W: return "win3x3_4w";
+        case ONEDC_KERNEL_UPS2X2_4W: return "ups2x2_4w";
         default: return "?";
     }
 }
@@ -386,6 +393,7 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         case ONEDC_KERNEL_WIN3X3: return onedc_conv_win_launch(p, st);
         case ONEDC_KERNEL_WIN3X3_4W: return onedc_conv_win4_launch(p, st);
         case ONEDC_KERNEL_UPS2X2: return onedc_conv_ups_launch(p, st);
+        case ONEDC_KERNEL_UPS2X2_4W: return onedc_conv_ups4_launch(p, st);
         case ONEDC_KERNEL_256X256: return onedc_conv_gemm256_launch(p, st);
         case ONEDC_KERNEL_128X256: return onedc_conv_gemm128x256_launch(p, st);
         case ONEDC_KERNEL_16X256: return launch<Tile<16, 256, 1, 4>>(p, st);

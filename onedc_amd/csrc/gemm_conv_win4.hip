@@ -49,10 +49,16 @@ __device__ __forceinline__ void w4_static_for(F &&f) {
 // ST: GroupNorm statistics of the epilogue (0 none, 4 per channel quad, 2 per channel pair) -- a template parameter of the
 // kernel, not a branch inside it: with the variants side by side in one kernel the compiler hoists their common head
 // (128 fma + the residual conversions) above the branch and spills accumulators around it
-template <bool NORM, int ST>
+// MODE: 0 plain 3x3; 1 GroupNorm (+SiLU) applied to the window on load; 2 one output phase of the x2-upsample + 3x3
+// decomposition (gemm_conv_ups.hip: a 2x2 convolution of the low-resolution input with summed weights): tap (ty, tx) of
+// phase (PY, PX) reads exactly what tap (PY + ty, PX + tx) of the 3x3 kernel reads, so the phase is two per-lane base
+// addresses chosen at the start, four K-tiles per chunk instead of nine, and an output scatter to (2 y + PY, 2 x + PX).
+template <int MODE, int ST>
 __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_params p, int tiles_n, int tiles_x, int tiles_y,
                                                            int Ktot, OnedcFastDiv dv_n, OnedcFastDiv dv_pi,
-                                                           OnedcFastDiv dv_x) {
+                                                           OnedcFastDiv dv_x, OnedcFastDiv dv_c) {
+    constexpr bool NORM = MODE == 1, UPS = MODE == 2;
+    constexpr int TAPS = UPS ? 4 : 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef EXP_W4_TIMELINE
     unsigned long long tl[6];
@@ -94,7 +100,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         }
         ty = band * 4 + r;
     }
-    const int y0 = ty * 16, x0 = tx * 16;
+    const int y0 = ty * 16, x0 = tx * 16;           // patch origin (UPS: on the low-resolution grid)
+    const int phase = UPS ? dv_c.div(n0) : 0;       // a 128-row tile of the phase-packed matrix belongs to one phase
+    const int PY = phase >> 1, PX = phase & 1;
 
     // ---- DMA geometry ------------------------------------------------------------------------------------------------
     // lane l of a DMA instruction moves granule l of a 1 KB block: row (l & 15) of the block, channel group l >> 4
@@ -206,6 +214,12 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
         wrd[kx] = W4_WOFF + (8 * wc * 18 + frow) * 64 + ((fq ^ ((((frow + kx) >> 2) & 1) << 1)) << 4);
+    if (UPS) {                                       // tap (ty, tx) == 3x3 tap (PY + ty, PX + tx): bases of columns PX, PX + 1
+        const int shift = (PY * 18 + PX) * 64;
+        const int b0 = PX ? wrd[1] : wrd[0], b1 = PX ? wrd[2] : wrd[1];
+        wrd[0] = b0 + shift;
+        wrd[1] = b1 + shift;
+    }
     W4_PIN(fao);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) W4_PIN(wrd[kx]);
@@ -278,10 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     // odd one of the pair -- its own copy of the body, so that nothing in the loop is decided at run time
     auto chunk_pair = [&](int c2, auto last_tag) __attribute__((always_inline)) {
         constexpr bool last2 = decltype(last_tag)::value;
-        w4_static_for<0, 18>([&](auto J) __attribute__((always_inline)) {
+        w4_static_for<0, 2 * TAPS>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
-            constexpr int cp = j / 9, tap = j % 9;   // chunk parity (window buffer), tap
-            constexpr int ky = tap / 3, kx = tap % 3;
+            constexpr int cp = j / TAPS, tap = j % TAPS;   // chunk parity (window buffer), tap
+            constexpr int ky = UPS ? tap >> 1 : tap / 3, kx = UPS ? tap & 1 : tap % 3;
             constexpr int cur = j & 1, nxt = cur ^ 1;
             constexpr bool more = cp == 0 ? true : !last2;           // is there a chunk after this one?
             constexpr int wb_off = cp * W4_W;                        // this chunk's window buffer
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
             //     chunk: blocks 0, 1 at tap 0, blocks 2, 3 at tap 1, block 4 (and 5: wave 0 only) at tap 2.
             //     Younger than the weights of t + 1: blocks of t - 3, weights t + 2, blocks of t - 2, weights t + 3, blocks
             //     of t - 1.  NORM normalises block k at tap k + 2 and needs IT landed: fewer may stay in flight.
-            {
+            if constexpr (!UPS) {
                 constexpr auto x2 = [](int k) { return (k == 0 || k == 1) ? 2 : (k == 2 ? 1 : 0); };   // + 1 at tap 2 for wave 0
                 constexpr auto has5 = [](int k) { return k == 2; };
                 constexpr int n_w = 4 + x2(tap - 3) + x2(tap - 2) + x2(tap - 1);
@@ -331,18 +345,27 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
                 } else {                             // last chunk: no window blocks; weights t + 2 / t + 3 exist up to tap 6 / 5
                     W4_WAIT_VMCNT_N(tap <= 5 ? 4 : tap == 6 ? 2 : 0);
                 }
+            } else {
+                // four taps per chunk: the weights of K-tile t + 4 are the same tap of the next chunk, and a K-tile issues
+                // its window blocks BEFORE its weights (at tap 3 the whole next window must be in; only the weights issued
+                // at tap 2 may still fly).  Younger than the weights of t + 1 (issued at t - 3): blocks and weights of
+                // t - 2 and t - 1.  At tap 0 everything up to the blocks of the previous tap 2 has landed already (the
+                // tap-3 wait of the previous chunk), whichever chunk that was -- or the prologue.
+                if constexpr (more) W4_WAIT_VMCNT_N(tap == 0 ? 4 : tap == 1 ? 6 : tap == 2 ? 8 : 2);
+                else W4_WAIT_VMCNT_N(tap == 0 ? 4 : tap == 1 ? 2 : 0);
             }
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // (d) DMA: weights of K-tile t + 4 into the slot of K-tile t (every wave is past its reads of it), window
             //     blocks of the next chunk
             {
-                constexpr int tap4 = (tap + 4) % 9, over = (tap + 4) / 9;
-                if constexpr (over == 0 || more) stage_A(tap4, c32 + over, slot);
+                constexpr int tap4 = (tap + 4) % TAPS, over = (tap + 4) / TAPS;
+                if constexpr (!UPS && (over == 0 || more)) stage_A(tap4, c32 + over, slot);
                 if constexpr (tap < 3 && more) {
                     stage_W(2 * tap, c32 + 1, cp ^ 1);
                     if (tap < 2 || wave == 0) stage_W(2 * tap + 1, c32 + 1, cp ^ 1);
                 }
+                if constexpr (UPS && more) stage_A(tap4, c32 + over, slot);
                 if constexpr (NORM && more && tap >= 2 && tap - 2 < MAXWB) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (tap - 2 < 5 || wave == 0) norm_block(tap - 2, c32 + 1, cp ^ 1);
@@ -351,14 +374,15 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
             slot = (slot + 1) & 3;
             __builtin_amdgcn_sched_barrier(0);
             // (e) fragments of K-tile t + 1: weights and the first pixel half
-            if constexpr (tap < 8 || more) {
-                constexpr int tap1 = (tap + 1) % 9;
-                constexpr int wb1 = (tap == 8 ? cp ^ 1 : cp) * W4_W;
+            if constexpr (tap < TAPS - 1 || more) {
+                constexpr int tap1 = (tap + 1) % TAPS;
+                constexpr int ky1 = UPS ? tap1 >> 1 : tap1 / 3, kx1 = UPS ? tap1 & 1 : tap1 % 3;
+                constexpr int wb1 = (tap == TAPS - 1 ? cp ^ 1 : cp) * W4_W;
                 const int a_rd = fao + slot * W4_A;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) W4_RD(FA[nxt][i], a_rd, i * 1024);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) W4_RD(FBA[r], WRD[tap1 % 3], ((r + tap1 / 3) * 18 + tap1 % 3) * 64 + wb1);
+                for (int r = 0; r < 4; ++r) W4_RD(FBA[r], WRD[kx1], ((r + ky1) * 18 + kx1) * 64 + wb1);
                 W4_WAIT_LGKM4(8, FBB);
             } else {
                 W4_WAIT_LGKM4(0, FBB);
@@ -386,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(acc[i][r]));
-    const int nw = n0 + wr * 64;
+    const int nw = n0 - phase * p.Cout + wr * 64;    // (UPS: packed rows are [phase][channel])
     const bool have = nw + 64 <= p.Cout;             // Cout is a multiple of 64: a wave's channels all exist or none does
     char *yb = (char *)p.y;
     const char *rb = (const char *)p.res;
@@ -453,7 +477,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         for (int it = 0; it < 16; ++it) {
             const int px = it * 8 + (lane >> 3);           // pixel (row 8 wc + (px >> 4), column px & 15) of the patch
             const u32x4_t o = *(const __attribute__((address_space(3))) u32x4_t *)(my + px * 128 + ((c ^ (px & 7)) << 4));
-            const int64_t pix = ((int64_t)img * p.OH + y0 + 8 * wc + (px >> 4)) * p.OW + x0 + (px & 15);
+            const int py = y0 + 8 * wc + (px >> 4), pxx = x0 + (px & 15);
+            const int64_t pix = UPS ? ((int64_t)img * p.OH + 2 * py + PY) * p.OW + 2 * pxx + PX
+                                    : ((int64_t)img * p.OH + py) * p.OW + pxx;
             *(u32x4_t *)((a16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
         }
 #ifdef EXP_W4_TIMELINE
@@ -469,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         return;
 #endif
         if (ST != 0) {                                 // two 64-pixel statistics blocks per wave: patch rows 8 wc + 4 b ..
+            const int srow = (UPS ? (img * 4 + phase) * tiles_pi + pin : pt) * 4 + wc * 2;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -476,9 +503,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
                     const float sl = s_lo[b][i][0] + s_lo[b][i][1], ql = q_lo[b][i][0] + q_lo[b][i][1];
                     const float sh = s_hi[b][i][0] + s_hi[b][i][1], qh = q_hi[b][i][0] + q_hi[b][i][1];
                     if (ST == 4)
-                        conv_stats_store_row(p, sl + sh, ql + qh, pt * 4 + wc * 2 + b, nw + i * 16 + fq * 4, p.Cout, lane);
+                        conv_stats_store_row(p, sl + sh, ql + qh, srow + b, nw + i * 16 + fq * 4, p.Cout, lane);
                     else
-                        conv_stats_store_row(p, sl, ql, pt * 4 + wc * 2 + b, nw + i * 16 + fq * 4, p.Cout, lane, sh, qh);
+                        conv_stats_store_row(p, sl, ql, srow + b, nw + i * 16 + fq * 4, p.Cout, lane, sh, qh);
                 }
         }
     }
@@ -494,33 +521,50 @@ bool onedc_conv_win4_ok(const onedc_conv_params &p) {
            (!p.gn_ab || W4_LDS + (int64_t)p.Cin * 8 <= 80 * 1024);
 }
 
-template <bool NORM>
+template <int MODE>
 static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
-    const int tiles_n = (p.Cout + 127) / 128;
-    const int tiles_x = p.OW / 16, tiles_y = p.OH / 16;
-    const int Ktot = 9 * p.Cin;
+    constexpr bool UPS = MODE == 2;
+    const int tiles_n = UPS ? 4 * p.Cout / 128 : (p.Cout + 127) / 128;
+    const int tiles_x = (UPS ? p.IW : p.OW) / 16, tiles_y = (UPS ? p.IH : p.OH) / 16;
+    const int Ktot = (UPS ? 4 : 9) * p.Cin;
     const int64_t blocks = (int64_t)tiles_n * tiles_x * tiles_y * p.B;
     if (blocks > 0x7fffffff) return -1;
-    const OnedcFastDiv dv_n((uint32_t)tiles_n), dv_pi((uint32_t)(tiles_x * tiles_y)), dv_x((uint32_t)(4 * tiles_x));
+    const OnedcFastDiv dv_n((uint32_t)tiles_n), dv_pi((uint32_t)(tiles_x * tiles_y)), dv_x((uint32_t)(4 * tiles_x)),
+        dv_c((uint32_t)p.Cout);
     const dim3 grid((unsigned)blocks), block(256);
     if (!p.stats)
-        hipLaunchKernelGGL((conv_win4_kernel<NORM, 0>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x);
+        hipLaunchKernelGGL((conv_win4_kernel<MODE, 0>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x, dv_c);
     else if (p.stats_gran == 2)
-        hipLaunchKernelGGL((conv_win4_kernel<NORM, 2>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x);
+        hipLaunchKernelGGL((conv_win4_kernel<MODE, 2>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x, dv_c);
     else
-        hipLaunchKernelGGL((conv_win4_kernel<NORM, 4>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x);
+        hipLaunchKernelGGL((conv_win4_kernel<MODE, 4>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x, dv_c);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }
 
-int onedc_conv_win4_launch(const onedc_conv_params &p, hipStream_t st) {
+static void win4_attrs() {
     static OnedcLdsAttrOnce once;
-    once.ensure({{(const void *)conv_win4_kernel<false, 0>, W4_LDS},
-                 {(const void *)conv_win4_kernel<false, 2>, W4_LDS},
-                 {(const void *)conv_win4_kernel<false, 4>, W4_LDS},
-                 {(const void *)conv_win4_kernel<true, 0>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<true, 2>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<true, 4>, 80 * 1024}});
-    if (p.gn_ab) return win4_launch<true>(p, st, W4_LDS + p.Cin * 8);
-    return win4_launch<false>(p, st, W4_LDS);
+    once.ensure({{(const void *)conv_win4_kernel<0, 0>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 2>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 4>, W4_LDS},
+                 {(const void *)conv_win4_kernel<1, 0>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 2>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 4>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<2, 0>, W4_LDS},
+                 {(const void *)conv_win4_kernel<2, 2>, W4_LDS},
+                 {(const void *)conv_win4_kernel<2, 4>, W4_LDS}});
+}
+
+int onedc_conv_win4_launch(const onedc_conv_params &p, hipStream_t st) {
+    win4_attrs();
+    if (p.gn_ab) return win4_launch<1>(p, st, W4_LDS + p.Cin * 8);
+    return win4_launch<0>(p, st, W4_LDS);
+}
+
+// up == 2 (x2 upsample + 3x3 as four 2x2 phase convolutions, gemm_conv_ups.hip) with the linear epilogue
+bool onedc_conv_ups4_ok(const onedc_conv_params &p) { return p.epi == ONEDC_EPI_LINEAR && !p.gn_ab; }
+
+int onedc_conv_ups4_launch(const onedc_conv_params &p, hipStream_t st) {
+    win4_attrs();
+    return win4_launch<2>(p, st, W4_LDS);
 }

@@ -781,6 +781,18 @@ def test_conv_upsample_phases(B, H, W, Cin, C, epi):
     y1 = new_view(B, 2 * H, 2 * W, C, DEV)
     K.conv_gemm(xbuf.slice(64, Cin), packed(w), b.to(DEV), y1, KH=3, up=1, epi=e)
     close(ybuf.slice(64, C).torch_nchw(), y1.torch_nchw(), rms=4e-3, mx=3e-2, what="phases vs fused upsample")
+    # linear epilogue: the automatic choice is the 4-wave kernel (tile 131); the 8-wave one (tile 130) agrees to rounding
+    want = "ups2x2_4w" if epi == "linear" else "ups2x2"
+    y8 = new_view(B, 2 * H, 2 * W, C, DEV, stats=True)
+    K.conv_gemm(xbuf.slice(64, Cin), wp, b.to(DEV), y8, KH=3, up=2, epi=e, Cin=Cin, Cout=C, stats=True, tile=130)
+    close(ybuf.slice(64, C).torch_nchw(), y8.torch_nchw(), rms=3e-3, mx=2e-2, what="phases: 4 waves vs 8 waves")
+    assert K.PROFILE is None
+    K.PROFILE = []
+    try:
+        K.conv_gemm(xbuf.slice(64, Cin), wp, b.to(DEV), y8, KH=3, up=2, epi=e, Cin=Cin, Cout=C)
+        assert K.PROFILE[0][0] == want
+    finally:
+        K.PROFILE = None
 
 
 def test_conv_upsample_phases_race_screen_and_batch_invariance():

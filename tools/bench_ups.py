@@ -19,17 +19,17 @@ for name, B, H, W, C in [("vae 512 96->192", 16, 96, 96, 512), ("vae 512 192->38
     w2 = pack.pack_matrix(pack.upsample_phase_matrix(w), DEV)
     y = K.new_view(B, 2 * H, 2 * W, C, DEV)
     res = []
-    for up, wp in ((1, w1), (2, w2)):
+    for up, wp, tile in ((1, w1, 0), (2, w2, 130), (2, w2, 131)):      # fused upsample; phases on the 8-wave / 4-wave kernel
         for _ in range(2):
-            K.conv_gemm(x, wp, None, y, KH=3, up=up, Cin=C, Cout=C)
+            K.conv_gemm(x, wp, None, y, KH=3, up=up, Cin=C, Cout=C, tile=tile)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            K.conv_gemm(x, wp, None, y, KH=3, up=up, Cin=C, Cout=C)
+            K.conv_gemm(x, wp, None, y, KH=3, up=up, Cin=C, Cout=C, tile=tile)
         e1.record()
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 5)
     f9 = 2.0 * B * 4 * H * W * C * 9 * C
-    print(f"{name:20s} up=1 {res[0]:7.3f} ms {f9 / res[0] / 1e9:7.1f} TF | phases {res[1]:7.3f} ms "
-          f"{f9 * 4 / 9 / res[1] / 1e9:7.1f} TF executed  ({res[0] / res[1]:.2f}x)")
+    print(f"{name:20s} up=1 {res[0]:7.3f} ms {f9 / res[0] / 1e9:7.1f} TF | phases, 8 waves {res[1]:7.3f} ms "
+          f"{f9 * 4 / 9 / res[1] / 1e9:7.1f} TF executed | phases, 4 waves {res[2]:7.3f} ms {f9 * 4 / 9 / res[2] / 1e9:7.1f} TF")
