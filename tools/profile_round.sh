@@ -1,0 +1,25 @@
+#!/bin/bash
+# Measurement batch of a round, on the GPU box:  tools/profile_round.sh OUTDIR
+# bench lines of every mode, rocprofv3 kernel stats of the default bench command, PMC traffic passes (FETCH_SIZE and
+# WRITE_SIZE separately, kernel trace only -- never with other trace domains).  Every step has its own timeout and
+# no step reads stdin.
+out=${1:-gpurun_out/round}
+mkdir -p "$out"
+root=$(pwd)
+export TMPDIR=/tmp
+run() { name=$1; shift; timeout 600 "$@" > "$out/$name.json" 2> "$out/$name.err" < /dev/null; echo "$name rc=$?"; }
+run bench_line python3 bench.py
+run bench_line_bf16 env ONEDC_ACT=bf16 python3 bench.py --no-cpu-baseline
+run bench_line_sequential python3 bench.py --sequential --no-cpu-baseline
+run bench_line_zonly python3 bench.py --mode z_only --no-cpu-baseline
+run bench_line_encdec python3 bench.py --mode encode_decode
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r2 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$root/$out/pmc_$c" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --sequential > /dev/null 2> "$root/$out/pmc_$c.err" < /dev/null; echo "pmc $c rc=$?" )
+done
+find "$out" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \; < /dev/null
+f=$(find "$out/pmc_FETCH_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
+w=$(find "$out/pmc_WRITE_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
+if [ -n "$f" ] && [ -n "$w" ]; then python3 tools/pmc_traffic.py "$f" "$w" "$out/pmc_traffic.json" "folded on the box" < /dev/null; fi
+rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"
+ls -la "$out" < /dev/null
