@@ -157,6 +157,7 @@ def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, produ
               "bpp_product": round(len(product_blob) * 8 / (S * S), 5), "bpp_oracle": round(oracle_bytes * 8 / (S * S), 5),
               "bpp_delta_rel": round(len(product_blob) / oracle_bytes - 1, 5),
               "z_indices_equal": bool(torch.equal(idx_p, idx.long())),
+              "z_index_mismatches": int((idx_p != idx.long()).sum()), "z_index_decisions": int(idx_p.numel()),
               "scale_index_mismatch_rate": round(mism / max(total, 1), 6), "scale_index_decisions": total,
               "how": "free-running stream sizes from the same picture and latent noise; table indexes: the oracle's "
                      "prior on the product's z indices, teacher-forced with the product's symbols, hop by hop"}
@@ -302,7 +303,7 @@ def main():
         dom = max(by_tile, key=lambda k: by_tile[k][1])
         flops, secs, launches, dom_bytes = by_tile[dom]
         kernel_symbol = {"256x256": "conv_gemm256_kernel", "128x256": "conv_gemm128x256_kernel", "win3x3": "conv_win_kernel",
-                         "win3x3_4w": "conv_win4_kernel", "ups2x2_4w": "conv_win4_kernel",
+                         "win3x3_4w": "conv_win4_kernel", "ups2x2_4w": "conv_win4_kernel<ups>",
                          "ups2x2": "conv_ups_kernel"}.get(dom, f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
                                                            + (" f32" if dom.startswith("f32") else ""))
         # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in

@@ -581,11 +581,288 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// flash_attn80_kernel: head dim 80 as TWO half-heads of the d = 40 layout whose scores add before the softmax:
+// Q / K rows are [dims 0..39 | 24 pad | dims 40..79 | 24 pad] (DQ = 128), V^T rows [0..39 | ones row 40 | pad | 40..79 |
+// pad] (DV = 96).  Every LDS image, swizzle, fragment offset and the softmax (reference point in dim 40 of the first
+// half, denominator on the ones row) are flash_attn64_kernel's; what changes is the machine mapping: a K tile is two
+// 8 KB half tiles (the S chain runs four k steps), a V^T tile two 6 KB half tiles (six output row tiles), a wave owns
+// 32 queries (the accumulators of 64 would not fit) and a workgroup is EIGHT waves sharing one 3 x 28 KB ring, one
+// workgroup per CU: each K / V^T byte is staged once per 256 queries, as in the d = 40 kernel.
+constexpr int FA80_STAGE = 2 * FA64_K + 2 * FA64_V;      // 28 KB
+
+__global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__restrict__ Q,
+                                                              const a16_t *__restrict__ K,
+                                                              const a16_t *__restrict__ VT,
+                                                              a16_t *__restrict__ O, int H, int Nq, int Nk,
+                                                              int Nk_pad, float scale_log2e, int d_real) {
+    constexpr int DQ = 128, DV = 96, QT = 2;   // two half-heads of (64, 48): dims 0..39 | pad | 40..79 | pad
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    // all query blocks of one (image, head) run on ONE XCD, back to back: its K / V^T (2 MB at 9216 keys)
+    // stay in that XCD's L2 instead of being pulled through all eight
+    const int nqb = (Nq + 255) >> 8;                // 8 waves x 32 queries
+    const int logical = fa_xcd_logical(blockIdx.x, gridDim.x);
+    const int bh = logical / nqb;
+    const int h = bh % H, b = bh / H;
+    const int q0 = (logical - bh * nqb) * 256 + wave * 32;
+
+    // Q fragments (B operand): lane (g, r) holds Q[q0 + 16 t + r][32 ks + 8 g .. + 7], pre-multiplied by
+    // scale * log2(e): the S product then lands in the exp2 domain and needs no per-element multiply
+    a16x8 qf[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + t * 16 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            union { a16x8 v; uint32_t u[4]; } f;
+            f.v = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                f.u[e] = pack_a2(a2f((a16_t)(f.u[e] & 0xffff)) * scale_log2e, a2f((a16_t)(f.u[e] >> 16)) * scale_log2e);
+            qf[t][ks] = f.v;
+        }
+    }
+    f32x4 o[6][QT];                                 // o[3 hf + d]: rows 16 d + .. of half-head hf
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) o[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT];                                // running maximum (exp2 domain), identical in the 4 lanes of a query
+#pragma unroll
+    for (int t = 0; t < QT; ++t) m_run[t] = 0.f;
+
+    // ---- DMA geometry: a stage is [K half 0 | K half 1 | V^T half 0 | V^T half 1] = 28 blocks of 8 LDS rows: wave w moves
+    // K rows 8 w .. of both halves, V^T block w and (w < 4) block w + 8 (block vb: half vb / 6, rows 8 (vb % 6) ..)
+    const int lrow = lane >> 3, lch = lane & 7;
+    const char *Kb = (const char *)(K + (int64_t)b * Nk * (H * DQ) + h * DQ);
+    const char *Vb = (const char *)(VT + ((int64_t)b * H + h) * DV * Nk_pad);
+    const int64_t krow_bytes = (int64_t)H * DQ * 2;
+    const int64_t vrow_bytes = (int64_t)Nk_pad * 2;
+    const int krow = wave * 8 + lrow;                                         // key row inside the tile
+    const int kchunk = lch ^ ((krow & 3) | (((krow >> 3) & 1) << 2));
+    const int nvb = wave < 4 ? 2 : 1;                                         // V^T blocks of this wave
+    int vrow[2];
+    const char *vsrc[2];
+    bool vones[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int vb = wave + 8 * i, hf = vb >= 6 ? 1 : 0;                    // (vb < 12 for the blocks that exist)
+        vrow[i] = (vb - 6 * hf) * 8 + lrow;                                   // row inside the half: 0 .. 47
+        const int ch = lch ^ (vrow[i] & 7);
+        vones[i] = hf == 0 && vrow[i] == d_real;                              // the row that accumulates the denominator
+        vsrc[i] = vones[i] ? (const char *)g_ones_page + ch * 16 : Vb + (int64_t)(hf * 48 + vrow[i]) * vrow_bytes + ch * 16;
+    }
+    auto issue = [&](int tile, char *stage) {
+        const int k0 = tile * 64;
+        int key = k0 + krow;
+        key = key < Nk ? key : Nk - 1;                                        // tail rows: any valid row, masked below
+        const char *ksrc = Kb + (int64_t)key * krow_bytes + kchunk * 16;
+        fa_glds16(kchunk == 5 ? (const char *)g_kone_page : ksrc, stage + wave * 1024);      // half 0: dim 40 reads as 1
+        fa_glds16(ksrc + 128, stage + FA64_K + wave * 1024);                                 // half 1: dims 64 ..
+        fa_glds16(vsrc[0] + (vones[0] ? 0 : (int64_t)k0 * 2), stage + 2 * FA64_K + wave * 1024);
+        if (nvb == 2) fa_glds16(vsrc[1] + (vones[1] ? 0 : (int64_t)k0 * 2), stage + 2 * FA64_K + (wave + 8) * 1024);
+    };
+
+    // ---- fragment read offsets
+    // K A-fragment of (st, hh, ks): LDS row 32 st + 8 (r >> 2) + 4 hh + (r & 3), chunk (4 ks + g) ^ swzK(row)
+    int kfo[2][2];                                  // [hh][ks] for st = 0; st = 1 adds 32 rows (same swizzle bits)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int row = 8 * (r >> 2) + 4 * hh + (r & 3);
+        const int sw = (row & 3) | (((row >> 3) & 1) << 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kfo[hh][ks] = row * 128 + (((4 * ks + g) ^ sw) << 4);
+    }
+    // V^T A-fragment of (d, st): LDS row 16 d + r, chunk (4 st + g) ^ (row & 7)
+    int vfo[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) vfo[st] = r * 128 + (((4 * st + g) ^ (r & 7)) << 4);
+
+    // Softmax with a lazily moved reference point.  Dim 40 (head padding) of every K row reads as 1 and
+    // dim 40 of Q' holds -m_run (kept bf16-representable), so the MFMA chain itself delivers s - m_run and
+    // p = exp2(s - m_run) is ONE v_exp_f32 per element: no multiply, no subtract, no cross-lane traffic.
+    // m_run only has to keep exp2 in range (bf16 and f32 share the 8-bit exponent, and the relative
+    // precision of p does not depend on its magnitude), so it is set from the row maxima of tile 0 and
+    // moved only when a later tile holds a score more than 2^FA64_THR above it; the move is applied AFTER
+    // that tile's PV product (O and the riding row sum are scaled together), so no register between the
+    // S product and the PV product is ever touched by the rare path.
+    // P and V^T are ALWAYS bf16 in this kernel, also in the IEEE-half build (Q, K and the S product are the build's
+    // format): exp2 of a score that jumped far above the lazily moved reference is only representable with f32's
+    // exponent range, and a pre-check in front of the PV product costs registers the loop does not have (it spilled:
+    // 4.2 instead of 2.7 ms at 9216 tokens).  The host hands V^T over in bf16 (onedc_conv_params.out_bf16).
+    constexpr float FA64_THR = 12.f;
+    auto s_chain = [&](const char *ldsK, f32x4 (&s)[4][QT]) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const a16x8 kf = *(const a16x8 *)(ldsK + (ks >> 1) * FA64_K + (kt >> 1) * 4096 + kfo[kt & 1][ks & 1]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    s[kt][t] = ONEDC_MFMA16(kf, qf[t][ks], s[kt][t]);
+            }
+    };
+    auto mask_tail = [&](f32x4 (&s)[4][QT], int k0) {      // element (kt, e) is key k0 + 32 (kt >> 1) + 8 g + 4 (kt & 1) + e
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + e >= Nk) {
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) s[kt][t][e] = -1e30f;
+                }
+    };
+    auto lane_max = [&](const f32x4 (&s)[4][QT], float (&tmax)[QT]) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = fmaxf(fmaxf(s[0][t][0], s[0][t][1]), fmaxf(s[0][t][2], s[0][t][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt)
+                mx = fmaxf(fmaxf(mx, fmaxf(s[kt][t][0], s[kt][t][1])), fmaxf(s[kt][t][2], s[kt][t][3]));
+            tmax[t] = mx;
+        }
+    };
+    // move the reference point of query tile t by the row maximum `mx` (relative to the current one)
+    auto move_ref = [&](int t, float mx, bool scale_o) -> float {
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = a2f(f2a(m_run[t] + mx));              // bf16 grid: it must fit Q'[40] exactly
+        const float inc = m_new - m_run[t];                          // exact (both on the bf16 grid)
+        m_run[t] = m_new;
+        if (g == 1) {                                                // dim 40 = element 0 of the (ks = 1, g = 1) fragment
+            union { a16x8 v; uint32_t u[4]; } f;
+            f.v = qf[t][1];
+            f.u[0] = (f.u[0] & 0xffff0000u) | f2a(-m_new);
+            qf[t][1] = f.v;
+        }
+        if (scale_o) {
+            const float alpha = __builtin_amdgcn_exp2f(-inc);
+#pragma unroll
+            for (int d = 0; d < 6; ++d)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[d][t][e] *= alpha;
+        }
+        return inc;
+    };
+    auto first_reference = [&](const char *stage, bool mask) {      // dry run of the S product on tile 0
+        f32x4 s[4][QT];
+        s_chain(stage, s);
+        if (mask) mask_tail(s, 0);
+        float tmax[QT];
+        lane_max(s, tmax);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) move_ref(t, tmax[t], false);
+    };
+    auto tile_math = [&](const char *stage, int k0, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        const char *ldsK = stage, *ldsV = stage + 2 * FA64_K;
+        f32x4 s[4][QT];                             // S^T tiles s[kt][t], kt = 2 st + hh
+        s_chain(ldsK, s);
+        if (MASK) mask_tail(s, k0);
+        float tmax[QT];
+        lane_max(s, tmax);
+        a16x8 pf[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[kt][t][e] = __builtin_amdgcn_exp2f(s[kt][t][e]);
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                union { a16x8 v; uint32_t u[4]; } pk;
+                pk.u[0] = pack_bf16_2(s[2 * st][t][0], s[2 * st][t][1]);
+                pk.u[1] = pack_bf16_2(s[2 * st][t][2], s[2 * st][t][3]);
+                pk.u[2] = pack_bf16_2(s[2 * st + 1][t][0], s[2 * st + 1][t][1]);
+                pk.u[3] = pack_bf16_2(s[2 * st + 1][t][2], s[2 * st + 1][t][3]);
+                pf[t][st] = pk.v;
+            }
+        }
+        // O^T += V^T . P^T: lane (r, g) of the A operand holds V^T[16 d + r][keys 32 st + 8 g .. + 7]
+#pragma unroll
+        for (int d = 0; d < 6; ++d)                  // rows 16 (d % 3) .. of half d / 3: the halves are contiguous in LDS
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const a16x8 vf = *(const a16x8 *)(ldsV + d * 2048 + vfo[st]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][st], o[d][t], 0, 0, 0);
+            }
+        const float wmax = fmaxf(tmax[0], tmax[1]);
+        if (__any(wmax > FA64_THR)) {               // wave-uniform, rare
+#pragma unroll
+            for (int t = 0; t < QT; ++t) (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
+        }
+    };
+
+    const int ntiles = (Nk + 63) >> 6;
+    const bool ragged = (Nk & 63) != 0;
+    issue(0, smem);
+    if (ntiles > 1) issue(1, smem + FA80_STAGE);
+    int slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t has landed for this wave once at most the DMAs of tile t + 1 are outstanding
+        if (t + 1 < ntiles) {
+            if (nvb == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();               // every wave's part of tile t is in LDS; tile t - 1 is fully read
+        if (t + 2 < ntiles) issue(t + 2, smem + (slot >= 1 ? slot - 1 : 2) * FA80_STAGE);
+        const char *cur = smem + slot * FA80_STAGE;
+        if (t == 0) first_reference(cur, ragged && ntiles == 1);
+        if (ragged && t == ntiles - 1) tile_math(cur, t * 64, std::true_type{});
+        else tile_math(cur, t * 64, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+
+    // ---- normalise and store: lane (g, r) owns channels 16 d + 4 g + (0..3) of query q0 + 16 t + r
+    const int dt = d_real >> 4, dq = (d_real >> 2) & 3, de = d_real & 3;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float cand = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)                  // the denominator rides in half 0
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (d == dt && e == de) cand = o[d][t][e];
+        const float l = __shfl(cand, dq * 16 + r);
+        const float inv = 1.f / l;
+        const int qi = q0 + t * 16 + r;
+        if (qi >= Nq) continue;
+        a16_t *op = O + ((int64_t)b * Nq + qi) * (H * DV) + h * DV + g * 4;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = o[d][t][e] * inv;
+                if ((d % 3) * 16 + g * 4 + e >= d_real) v[e] = 0.f;
+            }
+            *(uint2 *)(op + d * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
+        }
+    }
+}
+
 }  // namespace
 
 // 1 when the kernel onedc_flash_attn picks for (DQ, DV, Nk) reads V^T as bf16 in EITHER build of the library (the d = 40
 // kernel: flash_attn64_kernel), 0 when V^T is in the library's own 16-bit format
-extern "C" int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk) { return DQ == 64 && DV == 48 && Nk >= 64; }
+extern "C" int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk) {
+    return ((DQ == 64 && DV == 48) || (DQ == 128 && DV == 96)) && Nk >= 64;
+}
 
 extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
                                 int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream) {
@@ -603,8 +880,14 @@ extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, vo
         hipLaunchKernelGGL(flash_attn64_kernel, dim3(((Nq + 255) / 256) * H * B), block, FA64_NST * FA64_STAGE, st,
                            (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
                            40);
+    } else if (DQ == 128 && DV == 96 && Nk >= 64) {
+        static OnedcLdsAttrOnce once;
+        once.ensure({{(const void *)flash_attn80_kernel, FA64_NST * FA80_STAGE}});
+        hipLaunchKernelGGL(flash_attn80_kernel, dim3(((Nq + 255) / 256) * H * B), dim3(512), FA64_NST * FA80_STAGE, st,
+                           (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
+                           40);
     } else if (DQ == 64 && DV == 48) FA_LAUNCH(64, 48, true, true, 40);
-    else if (DQ == 96 && DV == 80) FA_LAUNCH(96, 80, false, true, 80);
+    else if (DQ == 128 && DV == 96) FA_LAUNCH(128, 96, false, true, 80);      // (fewer than 64 keys; pad dims are zeros)
     else if (DQ == 160 && DV == 160) FA_LAUNCH(160, 160, false, false, 160);
     else if (DQ == 32 && DV == 16) FA_LAUNCH(32, 16, true, true, 8);
     else return -3;

@@ -3,7 +3,7 @@
 * conv / linear weights -> bf16 [rows padded to 128][KH*KW*Cin], k-contiguous with k = (ky, kx, cin)
 * GLU layers (ConvFFN3, GEGLU): rows interleaved in blocks of 16 (value block, gate block)
 * sub-pixel convs: rows ordered (dy*2+dx)*C' + c so the pixel-shuffle store is channel-contiguous
-* attention projections: heads zero-padded from d to DQ / DV (40->64/48, 80->96/80, 160->160)
+* attention projections: heads zero-padded from d to DQ / DV (40->64/48, 80->128/96 as two half-heads, 160->160)
 * peft LoRA: W += (alpha/r) * B @ A   (reference decoder_unet.py:360-367; config_inference.yaml:19-22)
 """
 import torch
@@ -93,19 +93,28 @@ def shuffle_perm(c_out):
     return torch.tensor([c * 4 + s for s in range(4) for c in range(cq)], dtype=torch.long)
 
 
+def head_positions(d, d_pad):
+    """Where the d real dims of a head sit inside its d_pad padded dims.  d = 80 is laid out as two half-heads of 40
+    (flash_attn80_kernel: [0..39 | pad | 40..79 | pad], halves of d_pad / 2); every other head dim is contiguous."""
+    if d == 80:
+        half = d_pad // 2
+        return torch.cat([torch.arange(40), half + torch.arange(40)])
+    return torch.arange(d)
+
+
 def pad_heads_rows(w, heads, d, d_pad):
-    """(heads*d, K) -> (heads*d_pad, K) with zero rows after each head."""
+    """(heads*d, K) -> (heads*d_pad, K): the rows of each head at head_positions(d, d_pad), zero rows elsewhere."""
     K = w.shape[1]
     out = w.new_zeros(heads, d_pad, K)
-    out[:, :d] = w.view(heads, d, K)
+    out[:, head_positions(d, d_pad).to(w.device)] = w.view(heads, d, K)
     return out.reshape(heads * d_pad, K)
 
 
 def pad_heads_cols(w, heads, d, d_pad):
-    """(N, heads*d) -> (N, heads*d_pad) with zero columns after each head."""
+    """(N, heads*d) -> (N, heads*d_pad): the columns of each head at head_positions(d, d_pad), zero columns elsewhere."""
     N = w.shape[0]
     out = w.new_zeros(N, heads, d_pad)
-    out[:, :, :d] = w.view(N, heads, d)
+    out[:, :, head_positions(d, d_pad).to(w.device)] = w.view(N, heads, d)
     return out.reshape(N, heads * d_pad)
 
 
@@ -117,4 +126,4 @@ def f32(t, device, perm=None):
     return t.float().contiguous().to(device)
 
 
-HEAD_PAD = {40: (64, 48), 80: (96, 80), 160: (160, 160), 8: (32, 16)}   # head dim -> (DQ, DV)
+HEAD_PAD = {40: (64, 48), 80: (128, 96), 160: (160, 160), 8: (32, 16)}   # head dim -> (DQ, DV)

@@ -208,28 +208,33 @@ def test_direct_conv_small_cin():
     close(y.torch_nchw(), F.conv2d(x / 0.18215, w, b, padding=1), what="direct conv")
 
 
-@pytest.mark.parametrize("d,Nq,Nk", [(40, 300, 300), (40, 200, 144), (80, 576, 576), (160, 144, 144), (160, 130, 77)])
+@pytest.mark.parametrize("d,Nq,Nk", [(40, 300, 300), (40, 200, 144), (80, 576, 576), (80, 300, 144), (80, 130, 16),
+                                     (160, 144, 144), (160, 130, 77)])
 def test_flash_attention(d, Nq, Nk):
+    """d = 80 is laid out as two half-heads (pack.head_positions); with fewer than 64 keys it takes the generic kernel."""
     B, Hh = 2, 8
     DQ, DV = pack.HEAD_PAD[d]
+    pq, pv = pack.head_positions(d, DQ), pack.head_positions(d, DV)
     g = torch.Generator().manual_seed(42)
     q, k, v = (torch.randn(B, Hh, n, d, generator=g).to(torch.bfloat16).float() for n in (Nq, Nk, Nk))
     Nk_pad = (Nk + 63) // 64 * 64
 
-    def padded(t, dp):                      # (B,H,N,d) -> (B,N,H*dp) bf16 with zero padding
+    def padded(t, dp):                      # (B,H,N,d) -> (B,N,H*dp) with zero padding
         out = torch.zeros(B, t.shape[2], Hh, dp)
-        out[..., :d] = t.permute(0, 2, 1, 3)
+        out[..., pq] = t.permute(0, 2, 1, 3)
         return out.reshape(B, t.shape[2], Hh * dp).to(K.a16()).to(DEV).contiguous()
 
     vt = torch.zeros(B, Hh, DV, Nk_pad)
-    vt[:, :, :d, :Nk] = v.transpose(2, 3)
+    vt[:, :, pv, :Nk] = v.transpose(2, 3)
     o = torch.empty(B, Nq, Hh * DV, dtype=K.a16(), device=DEV)
     K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk_pad).to(K.flash_vt_dtype(DQ, DV, Nk)).to(DEV).contiguous(),
                  o, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5)
     ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v               # (B,H,Nq,d)
-    got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
-    close(got, ref, rms=6e-3, mx=3e-2, what="flash attention")
-    assert float(o.float().cpu().view(B, Nq, Hh, DV)[..., d:].abs().max() if DV > d else 0.0) == 0.0
+    full = o.float().cpu().view(B, Nq, Hh, DV)
+    close(full[..., pv].permute(0, 2, 1, 3), ref, rms=6e-3, mx=3e-2, what="flash attention")
+    pad = torch.ones(DV, dtype=torch.bool)
+    pad[pv] = False
+    assert float(full[..., pad].abs().max() if bool(pad.any()) else 0.0) == 0.0
 
 
 def test_x0_and_image_out_and_fsq():
@@ -537,12 +542,14 @@ def test_conv_gemm128x256_variants_and_race_screen():
             assert torch.equal(got, ref), f"run {it} differs"
 
 
-def test_flash_attention_reference_point_moves():
-    """The d=40 kernel keeps a lazily moved softmax reference (set from tile 0, moved only when a later
+@pytest.mark.parametrize("d", [40, 80])
+def test_flash_attention_reference_point_moves(d):
+    """The d = 40 / 80 kernels keep a lazily moved softmax reference (set from tile 0, moved only when a later
     tile exceeds it by 2^12): force that rare path -- logits that grow tile after tile and one spiked key
     late in the sequence -- and an all-very-negative first tile; full-tensor check against fp64."""
-    B, Hh, d, Nq, Nk = 1, 8, 40, 320, 640
+    B, Hh, Nq, Nk = 1, 8, 320, 640
     DQ, DV = pack.HEAD_PAD[d]
+    pq, pv = pack.head_positions(d, DQ), pack.head_positions(d, DV)
     g = torch.Generator().manual_seed(77)
     q = torch.randn(B, Hh, Nq, d, generator=g)
     k = torch.randn(B, Hh, Nk, d, generator=g)
@@ -555,16 +562,16 @@ def test_flash_attention_reference_point_moves():
 
     def padded(t, dp):
         out = torch.zeros(B, t.shape[2], Hh, dp)
-        out[..., :d] = t.permute(0, 2, 1, 3)
+        out[..., pq] = t.permute(0, 2, 1, 3)
         return out.reshape(B, t.shape[2], Hh * dp).to(K.a16()).to(DEV).contiguous()
 
     vt = torch.zeros(B, Hh, DV, Nk)
-    vt[:, :, :d] = v.transpose(2, 3)
+    vt[:, :, pv] = v.transpose(2, 3)
     o = torch.empty(B, Nq, Hh * DV, dtype=K.a16(), device=DEV)
     K.flash_attn(padded(q, DQ), padded(k, DQ), vt.reshape(B, Hh * DV, Nk).to(K.flash_vt_dtype(DQ, DV, Nk)).to(DEV).contiguous(),
                  o, B, Hh, Nq, Nk, Nk, DQ, DV, d ** -0.5)
     ref = torch.softmax(q.double() @ k.double().transpose(-1, -2) * d ** -0.5, -1) @ v.double()
-    got = o.float().cpu().view(B, Nq, Hh, DV)[..., :d].permute(0, 2, 1, 3)
+    got = o.float().cpu().view(B, Nq, Hh, DV)[..., pv].permute(0, 2, 1, 3)
     assert torch.isfinite(got).all()
     close(got, ref, rms=1e-2, mx=4e-2, what="flash attention, moving reference")
 

@@ -13,6 +13,9 @@ def short(name):
     m = re.search(r"(conv_gemm_kernel)<.*Tile<(\d+), (\d+).*?>, (true|false)>", name)
     if m:
         return f"conv_gemm_kernel<{m.group(2)}x{m.group(3)}>" + (" f32" if m.group(4) == "true" else "")
+    m = re.search(r"conv_win4_kernel<(\d), \d>", name)
+    if m:                                            # MODE 2 = the upsample phases: their own row (4/9 of the taps, x4 outputs)
+        return "conv_win4_kernel" + ("<ups>" if m.group(1) == "2" else "")
     m = re.search(r"(conv_win_kernel)<(true|false)>", name)
     if m:
         return "conv_win_kernel" + ("<up>" if m.group(2) == "true" else "")
