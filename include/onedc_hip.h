@@ -164,12 +164,14 @@ int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, 
 /* Flash attention for the UNet's multi-head self/cross attention (diffusers Attention with
  * SDPA; call sites decoder_unet.py:204-293).  q [B][Nq][H*DQ], k [B][Nk][H*DQ] bf16,
  * vt [B][H*DV][Nk_pad] bf16 (V transposed, keys contiguous), o [B][Nq][H*DV].
- * (DQ, DV) in {(64,48), (96,80), (160,160), (32,16)}: head dims 40 / 80 / 160 (decoder UNet) and 8 (the
- * analysis UNet2DModel of the encode side), zero-padded by the packed projection weights.  scale multiplies q.k before the softmax. */
+ * (DQ, DV) in {(64,48), (128,96), (160,160), (32,16)}: head dims 40 / 80 / 160 (decoder UNet) and 8 (the
+ * analysis UNet2DModel of the encode side), zero-padded by the packed projection weights.  Head dim 80 is laid out as two
+ * half-heads of the d = 40 layout: q / k dims [0..39 | 24 zeros | 40..79 | 24 zeros], v rows [0..39 | 8 zeros | 40..79 |
+ * 8 zeros] (onedc_amd/pack.py: head_positions); o has the v layout.  scale multiplies q.k before the softmax. */
 int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
                      int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream);
-/* 1 if onedc_flash_attn reads vt as bf16 for this shape whatever the library's activation format (head dim 40 with at
- * least 64 keys: P and V^T of that kernel are bf16, see attention.hip); the producer sets onedc_conv_params.out_bf16 */
+/* 1 if onedc_flash_attn reads vt as bf16 for this shape whatever the library's activation format (head dims 40 and 80 with
+ * at least 64 keys: P and V^T of those kernels are bf16, see attention.hip); the producer sets onedc_conv_params.out_bf16 */
 int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk);
 
 /* ---- elementwise heads ------------------------------------------------------------------- */
