@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     constexpr int TAPS = UPS ? 4 : 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef EXP_W4_TIMELINE
-    unsigned long long tl[6];
+    unsigned long long tl[14];
     tl[0] = __builtin_amdgcn_s_memtime();
 #define W4_TL(i) tl[i] = __builtin_amdgcn_s_memtime()
 #define W4_RT(i) tl[i] = __builtin_amdgcn_s_memrealtime()
@@ -119,8 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         glds16_buf(w_rsrc, wvoff, so, dst);
         glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 4096);
     };
+    W4_TL(10);                                       // (diagnostic) tile decoded, weight offsets ready
     stage_A(0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    W4_TL(11);                                       // (diagnostic) first weight tile issued
 
     const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
     const unsigned x_bytes = img_bytes < 0xfffff000ll ? (unsigned)img_bytes : 0xfffff000u;
@@ -140,16 +142,19 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         sbits |= (unsigned)((wx >> 2) & 1) << k;
         woff[k] = ok ? (unsigned)((iy * p.IW + ix) * p.x_cs + p.x_co) * 2u + sfq * 16 : x_bytes;
     }
+    W4_TL(12);                                       // (diagnostic) window offsets computed
     auto stage_W = [&](int k, int c32, int wbuf) {
         glds16_buf(x_rsrc, woff[k], (unsigned)c32 * 64, smem + W4_WOFF + wbuf * W4_W + (wave + 4 * k) * 1024);
     };
 #pragma unroll
     for (int k = 0; k < MAXWB; ++k)
         if (k < nwb) stage_W(k, 0, 0);
+    W4_TL(13);                                       // (diagnostic) first window issued
     stage_A(1, 0, 1);
     stage_A(2, 0, 2);
     stage_A(3, 0, 3);
     __builtin_amdgcn_sched_barrier(0);
+    W4_TL(6);                                        // (diagnostic) every prologue DMA is issued
 
     // NORM: x is the raw tensor in front of a GroupNorm (+SiLU); a window block is normalised IN PLACE two or more taps
     // after its DMA was issued: the lane that moved a granule reads it back, applies v = silu(a[c] * x + b[c]) -- the
@@ -275,9 +280,12 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     } while (0)
     const int nc32 = p.Cin >> 5;                     // even: Cin is a multiple of 64
     __builtin_amdgcn_sched_barrier(0);
+    W4_TL(7);                                        // (diagnostic) set-up arithmetic done
     // window of chunk 0 and the weights of K-tile 0 (issued first) are in; weights 1 .. 3 (six instructions) may fly on
     W4_WAIT_VMCNT(6);
+    W4_TL(8);                                        // (diagnostic) own DMA landed
     __builtin_amdgcn_s_barrier();
+    W4_TL(9);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) W4_RD(fa[0][i], fao, i * 1024);
@@ -487,10 +495,10 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         if (lane == 0) {     // diagnostic build: p.stats is a debug buffer [blocks][4 waves][8] of int64
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
-            unsigned long long *dbg = (unsigned long long *)p.stats + ((int64_t)blockIdx.x * 4 + wave) * 8;
+            unsigned long long *dbg = (unsigned long long *)p.stats + ((int64_t)blockIdx.x * 4 + wave) * 16;
             dbg[0] = ((unsigned long long)xcc << 32) | hwid;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) dbg[1 + i] = tl[i];
+            for (int i = 0; i < 14; ++i) dbg[1 + i] = tl[i];
         }
         return;
 #endif

@@ -21,7 +21,7 @@ x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(K.a1
 w = pack.pack_matrix(torch.randn(Cout, 9 * Cin, generator=g, device=DEV) * (9 * Cin) ** -0.5, DEV)
 y = K.new_view(B, H, W, Cout, DEV)
 blocks = (Cout + 127) // 128 * (H // 16) * (W // 16) * B
-dbg = torch.zeros(blocks * 4 * 8, dtype=torch.int64, device=DEV)
+dbg = torch.zeros(blocks * 4 * 16, dtype=torch.int64, device=DEV)
 
 
 class FakeStats:
@@ -40,11 +40,15 @@ while time.time() < t_end:
         K.conv_gemm(x, w, None, y, KH=3, tile=131, stats=True)
     torch.cuda.synchronize()
     n += 20
-d = dbg.view(blocks, 4, 8).cpu().numpy().astype(np.int64)
+d = dbg.view(blocks, 4, 16).cpu().numpy().astype(np.int64)
 t0, t1, t2, t3 = d[:, :, 1].min(1), d[:, :, 2].max(1), d[:, :, 3].max(1), d[:, :, 4].max(1)
 clk = (d[:, :, 3] - d[:, :, 2]) / np.maximum(d[:, :, 6] - d[:, :, 5], 1) * 100.0      # MHz
 print(f"{blocks} workgroups, {n} launches; s_memtime ticks per workgroup (min start .. max end over its 4 waves):")
 print(f"  prologue (entry -> first fragments) {np.mean(t1 - t0):9.0f}")
+pa, pb, pc, pd = (np.mean(d[:, :, i] - d[:, :, 1]) for i in (7, 8, 9, 10))
+q0, q1, q2, q3 = (np.mean(d[:, :, i] - d[:, :, 1]) for i in (11, 12, 13, 14))
+print(f"    of it (per wave, from entry): tile decoded {q0:.0f}, first weights issued {q1:.0f}, window offsets {q2:.0f}, window issued {q3:.0f},")
+print(f"      every DMA issued {pa:.0f}, set-up arithmetic done {pb:.0f}, own DMA landed {pc:.0f}, barrier {pd:.0f}")
 print(f"  K loop                              {np.mean(t2 - t1):9.0f}   ({(Cin // 32) * 9} K-tiles: {np.mean(t2 - t1) / ((Cin // 32) * 9):.0f} per K-tile)")
 print(f"  epilogue                            {np.mean(t3 - t2):9.0f}")
 print(f"  whole workgroup                     {np.mean(t3 - t0):9.0f}")
