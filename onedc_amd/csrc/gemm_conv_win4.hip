@@ -19,6 +19,12 @@
 // Same arithmetic contract as the 8-wave kernel's fast path (16-bit output, bias / activation / residual / GroupNorm
 // statistics in the epilogue, line stores through LDS); k order (32-channel chunk, tap): sums round differently from the
 // other kernels, each kernel alone is deterministic and batch-invariant.
+// STATUS: the automatic choice (conv_choose in gemm_conv.hip) for every window layer with the linear epilogue on whole
+// 64-channel wave tiles, with or without GroupNorm on load, and for the upsample phases (MODE 2); tile 131 forces it, tile
+// 130 the 8-wave kernels.  tests/test_gpu_kernels.py::test_conv_win3x3_4wave_*, test_conv_upsample_phases*.  Measured
+// (DESIGN.md section 3 / 4): 3-19 % faster than the 8-wave kernel per layer; the chip holds 1.67 GHz in the K loop, where
+// the two resident workgroups keep the matrix pipe 91-96 % busy; a workgroup ALONE on its CU (its partner in prologue or
+// epilogue) reaches half of that, which is what the 128-channel layers at 768x768 still lose.
 #include <type_traits>
 
 #include "conv_common.h"
