@@ -1,0 +1,95 @@
+"""Host logic that needs no GPU: which kernel family onedc_conv_gemm picks (onedc_conv_gemm_kernel_id is the dispatcher's own
+answer, computed on the host from the parameters alone), and the head-dim layouts the attention kernels expect."""
+import ctypes as C
+
+import pytest
+import torch
+
+from onedc_amd import kernels as K
+from onedc_amd import pack
+
+
+def params(B=2, H=32, W=32, Cin=128, Cout=128, k=3, *, up=0, epi=K.EPI_LINEAR, tile=0, stats=0, gn=False, res=False,
+           y_co=0, y_cs=None, out_f32=0, stride=1, in_f32=0):
+    p = K.ConvParams()
+    dummy = C.cast(C.create_string_buffer(64), C.c_void_p)      # never dereferenced: no launch happens here
+    p.x = p.w = p.y = p.zeros = dummy
+    p.res = dummy if res else None
+    p.stats = dummy if stats else None
+    p.stats_gran = stats or 4
+    p.gn_ab = dummy if gn else None
+    p.B, p.IH, p.IW, p.Cin, p.x_cs, p.x_co = B, H, W, Cin, Cin, 0
+    p.OH, p.OW = (2 * H, 2 * W) if up else (H // stride, W // stride)
+    p.Cout, p.y_cs, p.y_co = Cout, (y_cs or Cout), y_co
+    p.r_cs, p.r_co = Cout, 0
+    p.KH = p.KW = k
+    p.stride, p.pad, p.up = stride, k // 2, up
+    p.epi, p.out_f32, p.in_f32 = epi, out_f32, in_f32
+    p.alpha, p.slope, p.batch, p.tile = 1.0, 0.01, 1, tile
+    return p
+
+
+def name(p, fmt="f16"):
+    lib = K.lib(fmt)
+    kid = lib.onedc_conv_gemm_kernel_id(C.byref(p))
+    return lib.onedc_conv_kernel_name(kid).decode() if kid >= 0 else kid
+
+
+@pytest.mark.parametrize("fmt", ["f16", "bf16"])
+def test_window_layers_go_to_the_4wave_kernel_where_its_epilogue_applies(fmt):
+    assert name(params(), fmt) == "win3x3_4w"
+    assert name(params(B=1), fmt) == name(params(B=16), fmt) == "win3x3_4w"          # by layer shape, never by batch size
+    assert name(params(Cin=192, Cout=320, stats=2, res=True), fmt) == "win3x3_4w"    # pair statistics, ragged last channel tile
+    assert name(params(gn=True, Cin=512), fmt) == "win3x3_4w"                        # GroupNorm on load: (a, b) fit behind the ring
+    # what it does not take stays on the 8-wave kernel: activations, fused upsample, f32 output, unaligned output slices
+    assert name(params(epi=K.EPI_SILU), fmt) == "win3x3"
+    assert name(params(up=1), fmt) == "win3x3"
+    assert name(params(out_f32=1), fmt) == "win3x3"
+    assert name(params(y_co=4, y_cs=256), fmt) == "win3x3"
+    # forcing: 130 = 8 waves, 131 = 4 waves (rejected where it cannot run)
+    assert name(params(tile=130), fmt) == "win3x3"
+    assert name(params(tile=131), fmt) == "win3x3_4w"
+    assert name(params(tile=131, epi=K.EPI_SILU), fmt) == -11
+
+
+def test_layers_no_window_kernel_takes():
+    assert name(params(H=24, W=24, Cin=1280, Cout=1280, B=16)) == "256x256"          # map is not whole 16x16 patches
+    assert name(params(H=12, W=12, Cin=1280, Cout=1280, B=16)) == "64x128"           # 2304 pixels: a small grid
+    assert name(params(k=1, H=96, W=96, Cin=320, Cout=2560, B=16)) == "128x128"      # short K: the 4-wave kernels
+    assert name(params(k=1, H=48, W=48, Cin=256, Cout=256, B=16, in_f32=1, out_f32=1)).startswith("f32_")
+    assert name(params(Cout=3)) == "16x256"                                           # conv_out-like
+
+
+def test_upsample_phases():
+    p = params(H=32, W=32, Cin=256, Cout=256, up=2)
+    assert name(p) == "ups2x2_4w"
+    p.tile = 130
+    assert name(p) == "ups2x2"
+    assert name(params(H=32, W=32, Cin=256, Cout=256, up=2, epi=K.EPI_SILU)) == "ups2x2"
+    assert name(params(H=24, W=24, Cin=256, Cout=256, up=2)) == -12                   # low-resolution map is not whole patches
+
+
+def test_groupnorm_on_load_question():
+    lib = K.lib()
+    assert lib.onedc_conv_win_takes(C.byref(params())) == 1
+    assert lib.onedc_conv_win_takes(C.byref(params(k=1))) == 0
+    assert lib.onedc_conv_win_takes(C.byref(params(Cin=1024, Cout=128))) == 1         # too many (a, b) pairs for two workgroups
+    assert name(params(Cin=1024, Cout=128, gn=True)) == "win3x3"                      # per CU: the 8-wave kernel has the room
+    assert lib.onedc_conv_win_takes(C.byref(params(up=1))) == 0                       # the fused-upsample variant cannot
+
+
+def test_head_layouts():
+    assert pack.HEAD_PAD[80] == (128, 96) and pack.HEAD_PAD[40] == (64, 48)
+    assert pack.head_positions(40, 64).tolist() == list(range(40))
+    assert pack.head_positions(80, 128).tolist() == list(range(40)) + list(range(64, 104))
+    assert pack.head_positions(80, 96).tolist() == list(range(40)) + list(range(48, 88))
+    w = torch.arange(2 * 80 * 3, dtype=torch.float32).view(160, 3)
+    rows = pack.pad_heads_rows(w, 2, 80, 128)
+    assert rows.shape == (256, 3)
+    assert torch.equal(rows[64:104], w[40:80]) and torch.equal(rows[128:168], w[80:120]) and float(rows[40:64].abs().max()) == 0
+    cols = pack.pad_heads_cols(w.t().contiguous(), 2, 80, 96)
+    assert cols.shape == (3, 192)
+    assert torch.equal(cols[:, 48:88], w.t()[:, 40:80]) and float(cols[:, 88:96].abs().max()) == 0
+    lib = K.lib()
+    assert lib.onedc_flash_attn_vt_is_bf16(128, 96, 144) == 1 and lib.onedc_flash_attn_vt_is_bf16(128, 96, 16) == 0
+    assert lib.onedc_flash_attn_vt_is_bf16(160, 160, 576) == 0
