@@ -22,6 +22,12 @@ data parallel, one process per GPU, weak scaling, every rank builds the same syn
 is read by rank 0 and broadcast once over RCCL: --broadcast-weights forces that path here too), no data-path
 collective.  Rank 0 prints ONE JSON line.
 
+Per SURVEY 8(d) the line also carries: `step_ms` (median / p10 / p90 of the per-batch completion intervals, HIP events
+on the decode streams), `device` (event-bracketed GPU time of one batch alone: entropy stage and stage S), `host_rans`
+(ns per symbol of the host coder, one thread, beside the reference coder's), `handoff` (the same K steps again with the
+pictures converted to 8-bit on the device and copied to page-locked host memory inside the timed region; --d2h makes
+THAT the headline region).
+
 Extra objects in the line:
   roofline      for the dominant kernel (the implicit-GEMM kernel family with the most device time, as reported by the
                 C dispatcher itself): achieved = algorithmic FLOPs of its launches / their summed duration, measured
@@ -49,8 +55,12 @@ MODE_DEFAULTS = {"decode": (768, 16), "z_only": (768, 16), "encode_decode": (512
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--d2h", action="store_true",
+                    help="the timed region also converts every picture to 8-bit samples on the device and copies it to "
+                         "page-locked host memory (what a service hands on, reference src/inference.py:106-107,119-120)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the hand-off pass, the device-time pass and the rANS timing")
     ap.add_argument("--mode", choices=sorted(MODE_DEFAULTS), default="decode")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: 16; encode_decode: 8)")
     ap.add_argument("--size", type=int, default=None, help="picture size (default: 768; encode_decode: 512)")
@@ -59,7 +69,9 @@ def parse():
     ap.add_argument("--s-streams", type=int, default=2, help="concurrent synthesis/UNet/VAE stages in the pipeline")
     ap.add_argument("--cpu-sample", type=int, default=None, help="picture size of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="torch threads of the CPU baseline (16 was the fastest of 16/32/64 on the 2x64-core host)")
+                    help="torch threads of the CPU baseline's main entry (16 was the fastest of 16/32/64 on the 2x64-core "
+                         "host); a 1-thread entry (the reference's own setting, src/inference.py:29) and an all-core entry "
+                         "are measured beside it on a 256x256 sample")
     ap.add_argument("--free-vae", action="store_true",
                     help="let the VAE stages of the pipeline's streams overlap each other (default: serialised on the device)")
     ap.add_argument("--broadcast-weights", action="store_true",
@@ -79,13 +91,10 @@ def _oracle_weights(sds):
     return codec_sd, R.fold_lora(unet_sd), vae_sd
 
 
-def cpu_baseline_decode(sample, threads, sds, z_only=False):
-    """Oracle decode (everything after the entropy decode) of one sample x sample picture on the host; scaled to
-    768^2-equivalent images/s by algorithmic FLOPs when sample != 768."""
+def _time_oracle_decode(sample, cores, weights, z_only):
     from oracle import torch_ref as R
-    cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
-    codec_cpu, unet_folded, vae_cpu = _oracle_weights(sds)
+    codec_cpu, unet_folded, vae_cpu = weights
     g = torch.Generator().manual_seed(0)
     z_sem = torch.randn(1, 128, sample // 64, sample // 64, generator=g)
     with torch.no_grad():
@@ -97,15 +106,102 @@ def cpu_baseline_decode(sample, threads, sds, z_only=False):
         else:
             y_hat = torch.randn(1, 128, sample // 16, sample // 16, generator=g)
         R.decode_from_latents(codec_cpu, unet_folded, vae_cpu, y_hat, z_sem)
-        dt = time.perf_counter() - t0
-    scale = GFLOP_PER_IMAGE[sample] / GFLOP_PER_IMAGE.get(768)
+        return time.perf_counter() - t0
+
+
+def cpu_baseline_decode(sample, threads, sds, z_only=False, extras=True):
+    """Oracle decode (everything after the entropy decode) of one sample x sample picture on the host; scaled to
+    768^2-equivalent images/s by algorithmic FLOPs when sample != 768.  Beside the main entry (`threads` torch threads):
+    ONE thread (the reference harness's own setting, src/inference.py:29) and ALL host threads, each on a 256x256 picture."""
+    weights = _oracle_weights(sds)
+    ncpu = os.cpu_count() or 1
     what = ("z indices -> hyper decoder + means-only four-part prior + decode_from_latents" if z_only
             else "decode_from_latents")
-    return {"value": round(scale / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_ref.py fp32 {what} of one {sample}x{sample} picture in "
-                      f"{dt:.2f} s on {cores} of {os.cpu_count()} host threads, scaled to 768x768 by algorithmic "
-                      f"GFLOP ({GFLOP_PER_IMAGE[sample]}/{GFLOP_PER_IMAGE[768]})"
-                      + ("" if z_only else "; host rANS not included")}
+
+    def entry(size, cores):
+        cores = max(1, min(cores, ncpu))
+        dt = _time_oracle_decode(size, cores, weights, z_only)
+        scale = GFLOP_PER_IMAGE[size] / GFLOP_PER_IMAGE[768]
+        return {"value": round(scale / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": f"oracle/torch_ref.py fp32 {what} of one {size}x{size} picture in "
+                          f"{dt:.2f} s on {cores} of {ncpu} host threads, scaled to 768x768 by algorithmic "
+                          f"GFLOP ({GFLOP_PER_IMAGE[size]}/{GFLOP_PER_IMAGE[768]})"
+                          + ("" if z_only else "; host rANS not included")}
+    out = entry(sample, threads)
+    if extras:
+        out["one_thread"] = entry(256, 1)              # torch.set_num_threads(1): src/inference.py:29
+        out["all_threads"] = entry(256, ncpu)
+    return out
+
+
+def host_rans_timing(model, blob):
+    """ns per symbol of the host coder on ONE picture's y stream (4 hops x 73 728 symbols at 768x768), one thread, through
+    the C ABI: decode (`onedc_rans_dec_decode_stream`) and encode (`encode_with_indexes` + `flush`).  The reference coder
+    (src/cpp/rans/rans.cpp, g++ -O2, one core of the build container): 25 ns decode, 10 ns encode (BASELINE.md section 2);
+    when oracle/_ref is present (the reference's own C++ built by oracle/Makefile) it is timed here on the same symbols."""
+    from onedc_amd.entropy import rans
+    from onedc_amd.entropy.utils import decode_i, unpack_indices
+    cm = model.codec_model
+    d = decode_i(blob, 14, 64)
+    n_idx = (d["pad_height"] // 64) * (d["pad_width"] // 64)
+    idx = torch.from_numpy(np.asarray(unpack_indices(d["bit_stream_z"], n_idx, 14)).astype(np.int32).reshape(
+        1, d["pad_height"] // 64, d["pad_width"] // 64)).to(model.device)
+    trace = []
+    cm.decompress([d["bit_stream_y"]], idx, trace=trace)
+    planes = [t[0].reshape(-1) for t in trace]
+    syms = [t[1].reshape(-1) for t in trace]
+    n = sum(p.size for p in planes)
+    best_dec = best_enc = 1e9
+    for _ in range(5):
+        dec = rans.RansDecoder(1)
+        dec.add_cdf(*cm._tables)
+        dec.set_stream(d["bit_stream_y"])
+        t0 = time.perf_counter()
+        for p in planes:
+            dec.decode_stream(p, 0)
+        best_dec = min(best_dec, time.perf_counter() - t0)
+        assert dec.finished()
+        enc = rans.RansEncoder(False, 1)
+        enc.add_cdf(*cm._tables)
+        t0 = time.perf_counter()
+        for sy, p in zip(syms, planes):
+            enc.encode_with_indexes(sy, p, 0)
+        enc.flush()
+        best_enc = min(best_enc, time.perf_counter() - t0)
+        assert enc.get_encoded_stream().tobytes() == d["bit_stream_y"]
+    out = {"symbols": n, "threads": 1, "decode_ns_per_symbol": round(best_dec / n * 1e9, 2),
+           "encode_ns_per_symbol": round(best_enc / n * 1e9, 2),
+           "reference_coder_ns_per_symbol": {"decode": 25.0, "encode": 10.0,
+                                             "where": "src/cpp/rans/rans.cpp, g++ -O2, one core of the build container (BASELINE.md section 2)"}}
+    try:                                                   # the reference's own coder, when its build travelled with the repo
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+        import MLCodec_rans as ref
+        cdf, sizes, offsets = (np.ascontiguousarray(a, dtype=np.int32) for a in cm._tables)
+        bd = be = 1e9
+        for _ in range(3):
+            e = ref.RansEncoder(False, 1)
+            e.add_cdf(cdf, sizes, offsets)
+            t0 = time.perf_counter()
+            for sy, p in zip(syms, planes):
+                e.encode_with_indexes(sy, p, 0)
+            e.flush()
+            stream = e.get_encoded_stream()
+            be = min(be, time.perf_counter() - t0)
+            r = ref.RansDecoder(1)
+            r.add_cdf(cdf, sizes, offsets)
+            r.set_stream(stream)
+            t0 = time.perf_counter()
+            for p in planes:
+                r.decode_stream(p, 0)
+            bd = min(bd, time.perf_counter() - t0)
+        out["reference_coder_here"] = {"decode_ns_per_symbol": round(bd / n * 1e9, 2), "encode_ns_per_symbol": round(be / n * 1e9, 2),
+                                       "what": "oracle/_ref/MLCodec_rans (the reference's C++ as built by oracle/Makefile), same symbols, this host"}
+    except Exception as ex:                                # noqa: BLE001 -- a missing / unloadable checker is not an error of the bench
+        out["reference_coder_here"] = f"not measured ({type(ex).__name__})"
+    finally:
+        if sys.path and sys.path[0].endswith("_ref"):
+            sys.path.pop(0)
+    return out
 
 
 def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, product_blob):
@@ -166,19 +262,32 @@ def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, produ
                        f"{S}x{S} picture in {dt:.2f} s on {cores} of {os.cpu_count()} host threads"}, parity)
 
 
+def step_stats(marks, pipelined):
+    """marks: completion times (ms from the start of the timed region) of the K batches -> interval statistics."""
+    if not marks:
+        return None
+    iv = np.diff(np.asarray([0.0] + list(marks)))
+    steady = iv[1:] if len(iv) > 2 else iv           # the first interval contains the pipeline fill (entropy stage of batch 0)
+    return {"median": round(float(np.median(steady)), 3), "p10": round(float(np.percentile(steady, 10)), 3),
+            "p90": round(float(np.percentile(steady, 90)), 3), "first": round(float(iv[0]), 3), "n": int(len(steady)),
+            "what": ("intervals between the end-of-batch HIP events of consecutive batches (device timestamps on the decode "
+                     "streams; the first interval, which contains the pipeline fill, is listed apart)" if pipelined else
+                     "host wall clock of each sequential step (each ends in its own synchronisation)")}
+
+
 def pin_host_threads(local_rank, world):
-    """Keep this rank's host threads (rANS pool, pipeline workers, torch) on its own share of the host cores, next to
-    its GPU: rank r of w gets the r-th contiguous slice of the cores this process may use.  On the 8-GPU node (2 sockets,
-    4 GPUs each) contiguous slices keep a rank's threads on the socket of its GPU."""
+    """Keep this rank's host threads (rANS pool, pipeline workers, torch) on its own share of the host cores, next to its
+    GPU: the ranks whose GPUs hang off one NUMA node split that node's cores (sysfs: the GPU's PCI numa_node, the node's
+    cpulist); without topology information rank r of w gets the r-th contiguous slice (onedc_amd.dataparallel.plan_core_sets)."""
     if world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
-    cores = sorted(os.sched_getaffinity(0))
-    per = len(cores) // world
-    if per < 2:
+    from onedc_amd.dataparallel import plan_core_sets, read_topology
+    gpu_nodes, node_cpus = read_topology(world)
+    plan = plan_core_sets(world, os.sched_getaffinity(0), gpu_nodes, node_cpus)
+    if plan is None:
         return None
-    mine = cores[local_rank * per:(local_rank + 1) * per]
-    os.sched_setaffinity(0, mine)
-    return mine
+    os.sched_setaffinity(0, plan[local_rank])
+    return plan[local_rank]
 
 
 def main():
@@ -251,36 +360,75 @@ def main():
     if not args.sequential and mode != "encode_decode":
         pipe = model.pipeline(s_streams=args.s_streams, z_only=(mode == "z_only"), serialise_vae=not args.free_vae)
 
-    def one_sequential():
-        if mode == "decode":
-            return model.decode(stream=blobs)
-        if mode == "z_only":
-            return model.decode_z_only_stream(stream=blobs)
-        bl, _ = model.encode(images, noise=noise)
-        return model.decode(stream=bl)
+    handoff = {"out": "u8", "to_host": True}        # 8-bit samples, page-locked host memory
 
-    def run(k):
+    def one_sequential(d2h=False):
+        if mode == "decode":
+            out = model.decode(stream=blobs, out="u8") if d2h else model.decode(stream=blobs)
+        elif mode == "z_only":
+            out = model.decode_z_only_stream(stream=blobs, out="u8") if d2h else model.decode_z_only_stream(stream=blobs)
+        else:
+            bl, _ = model.encode(images, noise=noise)
+            out = model.decode(stream=bl, out="u8") if d2h else model.decode(stream=bl)
+        if d2h:
+            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return host
+        return out
+
+    step_marks = []          # per-step completion times in ms from the start of the current timed region
+
+    def run(k, d2h=False, marks=None):
         if pipe is None:
-            return [one_sequential() for _ in range(k)][-1]
-        return pipe.map([blobs] * k)[-1]
+            t_start = time.perf_counter()
+            out = None
+            for _ in range(k):
+                out = one_sequential(d2h)                # returns after its own end-of-batch synchronisation (range guard)
+                if marks is not None:
+                    marks.append((time.perf_counter() - t_start) * 1e3)
+            return out
+        pipe.timing = marks is not None
+        e_start = torch.cuda.Event(enable_timing=True)
+        e_start.record()
+        out = pipe.map([blobs] * k, **(handoff if d2h else {}))[-1]
+        if marks is not None:
+            marks.extend(sorted(max(e_start.elapsed_time(ev) for ev in evs) for evs in pipe.last_done_events))
+        return out
+
+    def timed(k, d2h):
+        """Barrier + synchronize, K steps, synchronize + barrier (the contract's bracket) -> (seconds, last output, marks)."""
+        marks = []
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(k, d2h, marks)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0, out, marks
 
     if args.warmup:
-        run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+        run(args.warmup, args.d2h)
     K.PROFILE = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, out, step_marks = timed(args.steps, args.d2h)
     prof, K.PROFILE = K.PROFILE, None
-    assert out.shape == (B, 3, S, S) and bool(torch.isfinite(out).all())
+    if args.d2h:
+        assert out.shape == (B, S, S, 3) and out.dtype == torch.uint8 and out.device.type == "cpu"
+    else:
+        assert out.shape == (B, 3, S, S) and bool(torch.isfinite(out).all())
 
     elapsed = max_over_ranks(elapsed, device, world)
+
+    # the other hand-off, same K steps, same bracket (every rank runs it: the barriers are collective)
+    other_elapsed = None
+    if not args.no_extras:
+        run(1, not args.d2h)
+        other_elapsed, out2, _ = timed(args.steps, not args.d2h)
+        other_elapsed = max_over_ranks(other_elapsed, device, world)
+        del out2
 
     # The timed region runs several batches at once (the pipeline's streams): a kernel's event-bracketed duration
     # there includes the time it shares the GPU with kernels of other batches.  One more, untimed, sequential pass
@@ -291,6 +439,35 @@ def main():
         one_sequential()
         torch.cuda.synchronize()
         iso, K.PROFILE = K.PROFILE, None
+
+    # Device-only time of ONE batch with the GPU to itself: HIP events on the launch stream around the entropy
+    # stage (prior networks + the four host hops: the GPU idles while the host decodes) and around stage S (synthesis,
+    # UNet, VAE, crop: no host synchronisation inside, so the bracket is GPU time).
+    device = None
+    if rank == 0 and not args.no_extras and mode != "encode_decode":
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        best = None
+        with K.act_format(model.act), torch.no_grad():
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ev[0].record()
+                cm = model.codec_model
+                ent = cm.decode_entropy_z_only(stream=blobs) if mode == "z_only" else cm.decode_entropy(stream=blobs)
+                t_ent = time.perf_counter() - t0
+                ev[1].record()
+                model._decode_after_entropy(ent)
+                ev[2].record()
+                torch.cuda.synchronize()
+                cur = (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), t_ent * 1e3)
+                best = cur if best is None or sum(cur[:2]) < sum(best[:2]) else best
+        device = {"entropy_stage_ms": round(best[0], 3), "stage_s_ms": round(best[1], 3),
+                  "ms_per_step": round(best[0] + best[1], 3), "entropy_stage_host_wall_ms": round(best[2], 3),
+                  "how": "HIP events on the launch stream around one sequential batch, best of 3; the entropy stage's "
+                         "bracket contains the host rANS hops (GPU idle), stage S is GPU time only"}
+    rans_t = None
+    if rank == 0 and not args.no_extras and mode == "decode":
+        rans_t = host_rans_timing(model, blobs[0])
 
     if rank == 0:
         by_tile = {}
@@ -310,7 +487,7 @@ def main():
         # separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) and committed under
         # profiles/; PMC passes serialise every dispatch, so they cannot run inside the timed region.
         traffic = None
-        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if mode == "decode" and os.path.exists(tpath):
                 t = json.load(open(tpath)).get(kernel_symbol)
@@ -336,6 +513,7 @@ def main():
             "metric": metric, "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "step_ms": step_stats(step_marks, pipe is not None),
             "vs_baseline": None, "dtype": model.act, "data": "synthetic",
             "config": {"workload": workload, "mode": mode,
                        "images_per_gpu_per_step": B, "picture": f"{S}x{S}", "parallelism": f"dp{world}",
@@ -366,6 +544,19 @@ def main():
                          "all_conv_gemm_tflops": round(all_flops / all_secs / 1e12, 2),
                          "conv_gemm_share_of_step": round(all_secs / elapsed, 3)},
         }
+        out_desc = {False: "f32 [B,3,H,W] pictures left in HBM (what model.decode returns)",
+                    True: "8-bit samples converted on the device (save_image's quantisation) and copied to page-locked "
+                          "host memory inside the timed region"}
+        line["config"]["output"] = out_desc[args.d2h]
+        if other_elapsed is not None:
+            line["handoff"] = {"value": round(images_done / other_elapsed, 3), "unit": "images/s",
+                               "ms_per_step": round(other_elapsed / args.steps * 1e3, 3), "output": out_desc[not args.d2h],
+                               "bytes_per_image_over_pcie": 3 * S * S if not args.d2h else 0,
+                               "how": "the same K steps in the same barrier / synchronize bracket, the other output hand-off"}
+        if device:
+            line["device"] = device
+        if rans_t:
+            line["host_rans"] = rans_t
         if mode != "encode_decode":
             line["roofline"]["whole_path_tflops"] = round(value / world * GFLOP_PER_IMAGE.get(S, 0) / 1e3, 2)
         if iso:
@@ -381,7 +572,8 @@ def main():
                 line["cpu_baseline"], line["parity"] = cpu_baseline_encode_decode(
                     model, images[:1], noise[:1], args.cpu_threads, sds, enc_sds, model.encode(images[:1], noise=noise[:1])[0])
             else:
-                line["cpu_baseline"] = cpu_baseline_decode(args.cpu_sample, args.cpu_threads, sds, z_only=(mode == "z_only"))
+                line["cpu_baseline"] = cpu_baseline_decode(args.cpu_sample, args.cpu_threads, sds, z_only=(mode == "z_only"),
+                                                           extras=not args.no_extras)
         print(json.dumps(line), flush=True)
     if pipe is not None:
         pipe.close()

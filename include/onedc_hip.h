@@ -207,9 +207,16 @@ int onedc_x0_from_noise(const float *reduced, const float *eps, float *x0, int64
                         double alpha_bar, void *stream);
 
 /* NHWC (bf16/f32) padded picture -> NCHW f32 [B][3][H][W] crop (model...stage1.py:327-329),
- * optional clamp(-1,1)*0.5+0.5 (inference.py:106). */
+ * optional clamp(-1,1)*0.5+0.5 (inference.py:106).
+ * nonfinite: NULL, or int32 [B] zero-filled by the caller; word b is set to 1 when picture b holds a NaN / Inf BEFORE the
+ * clamp (which would turn it into a valid-looking pixel): the range guard of the IEEE-half build. */
 int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
-                    int unit_range, void *stream);
+                    int unit_range, int32_t *nonfinite, void *stream);
+/* The same crop as 8-bit samples, converted on the device: clamp(-1,1)*0.5+0.5 (inference.py:106), then x255 + 0.5,
+ * clamp(0,255), truncation (torchvision save_image, inference.py:107,120).  nhwc = 1: [B][H][W][3] (what an image
+ * writer takes), 0: [B][3][H][W].  A batch then crosses PCIe as 1 byte per sample. */
+int onedc_image_out_u8(const void *x, int x_f32, int x_cs, uint8_t *out, int B, int PH, int PW, int H, int W,
+                       int nhwc, int32_t *nonfinite, void *stream);
 
 /* generic strided copy / cast between NHWC views (channel concat, padding layouts) */
 int onedc_copy_channels(const void *x, int x_f32, int x_cs, int x_co, void *y, int y_f32, int y_cs,
@@ -237,6 +244,8 @@ int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *s
 int onedc_add(const void *a, const void *b, void *y, int64_t n, void *stream);
 
 const char *onedc_hip_version(void);
+/* "bf16" or "f16": the 16-bit activation format this build of the library computes in (exact token) */
+const char *onedc_hip_act_format(void);
 
 #ifdef __cplusplus
 }

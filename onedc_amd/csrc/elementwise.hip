@@ -130,9 +130,12 @@ __global__ void x0_kernel(const float *reduced, const float *eps, float *x0, int
         x0[i] = (float)(((double)reduced[i] - sb * (double)eps[i]) / sa);
 }
 
+// nonfinite: NULL, or int32 [B] zero-filled by the caller: picture b's word becomes 1 when one of its values is NaN / Inf
+// BEFORE the clamp (every writer stores the same constant: no atomic needed).  The clamp itself would hide it
+// (fmaxf(NaN, -1) = -1): an activation that left the IEEE-half range upstream must not come out as a black pixel.
 template <bool F32>
 __global__ void image_out_kernel(const void *x, int x_cs, float *out, int B, int PH, int PW, int H, int W,
-                                 int unit) {
+                                 int unit, int32_t *nonfinite) {
     const int64_t total = (int64_t)B * 3 * H * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -143,8 +146,39 @@ __global__ void image_out_kernel(const void *x, int x_cs, float *out, int B, int
         const int c = (int)(r % 3);
         const int b = (int)(r / 3);
         float v = ldp<F32>(x, (((int64_t)b * PH + yy) * PW + xx) * x_cs + c);
+        if (nonfinite && !(fabsf(v) <= 3.0e38f)) nonfinite[b] = 1;
         if (unit) v = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
         out[i] = v;
+    }
+}
+
+// The picture as the 8-bit samples a file or a display takes: clamp(-1,1)*0.5+0.5 (inference.py:106), then
+// torchvision.utils.save_image's x255 + 0.5, clamp(0,255), truncation (inference.py:107,120) -- on the device, so that a
+// batch leaves over PCIe as 1 byte per sample instead of 4.  One thread per output PIXEL (three samples); nhwc = 1: HWC
+// order (what an image writer takes), 0: the reference's CHW planes.
+template <bool F32>
+__global__ void image_out_u8_kernel(const void *x, int x_cs, uint8_t *out, int B, int PH, int PW, int H, int W,
+                                    int nhwc, int32_t *nonfinite) {
+    const int64_t total = (int64_t)B * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        int64_t r = i / W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int64_t src = (((int64_t)b * PH + yy) * PW + xx) * x_cs;
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = ldp<F32>(x, src + c);
+            bad |= !(fabsf(v) <= 3.0e38f);
+            v = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
+            v = fminf(fmaxf(__fadd_rn(__fmul_rn(v, 255.f), 0.5f), 0.f), 255.f);   // mul, then add: two roundings like torch's mul(255).add_(0.5)
+            const uint8_t q = (uint8_t)(int)v;
+            if (nhwc) out[i * 3 + c] = q;
+            else out[(((int64_t)b * 3 + c) * H + yy) * W + xx] = q;
+        }
+        if (bad && nonfinite) nonfinite[b] = 1;
     }
 }
 
@@ -384,7 +418,9 @@ inline int grid_for(int64_t n, int per = 256) { return (int)min((int64_t)16384, 
 
 extern "C" {
 
-const char *onedc_hip_version(void) { return "onedc-hip 0.2 (gfx950, " ONEDC_ACT_NAME " activations)"; }
+const char *onedc_hip_version(void) { return "onedc-hip 0.3 (gfx950, " ONEDC_ACT_NAME " activations)"; }
+// the 16-bit activation format this library was built for: "bf16" or "f16" (exactly; the loader compares it)
+const char *onedc_hip_act_format(void) { return ONEDC_ACT_NAME; }
 
 int onedc_fsq_codes(const int32_t *idx, float *codes, int64_t n, void *stream) {
     if (!idx || !codes) return -1;
@@ -444,11 +480,20 @@ int onedc_x0_from_noise(const float *reduced, const float *eps, float *x0, int64
 }
 
 int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
-                    int unit_range, void *stream) {
+                    int unit_range, int32_t *nonfinite, void *stream) {
     if (!x || !out || H > PH || W > PW) return -1;
     const int64_t n = (int64_t)B * 3 * H * W;
-    if (x_f32) LAUNCH(image_out_kernel<true>, n, x, x_cs, out, B, PH, PW, H, W, unit_range);
-    else LAUNCH(image_out_kernel<false>, n, x, x_cs, out, B, PH, PW, H, W, unit_range);
+    if (x_f32) LAUNCH(image_out_kernel<true>, n, x, x_cs, out, B, PH, PW, H, W, unit_range, nonfinite);
+    else LAUNCH(image_out_kernel<false>, n, x, x_cs, out, B, PH, PW, H, W, unit_range, nonfinite);
+    return 0;
+}
+
+int onedc_image_out_u8(const void *x, int x_f32, int x_cs, uint8_t *out, int B, int PH, int PW, int H, int W,
+                       int nhwc, int32_t *nonfinite, void *stream) {
+    if (!x || !out || H > PH || W > PW) return -1;
+    const int64_t n = (int64_t)B * H * W;
+    if (x_f32) LAUNCH(image_out_u8_kernel<true>, n, x, x_cs, out, B, PH, PW, H, W, nhwc, nonfinite);
+    else LAUNCH(image_out_u8_kernel<false>, n, x, x_cs, out, B, PH, PW, H, W, nhwc, nonfinite);
     return 0;
 }
 

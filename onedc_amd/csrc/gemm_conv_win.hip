@@ -546,7 +546,11 @@ bool onedc_conv_win_ok(const onedc_conv_params &p) {
     return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && !p.pixel_shuffle && p.batch <= 1 && !p.in_f32 &&
            (p.OH & 15) == 0 && (p.OW & 15) == 0 && (p.Cin & 63) == 0 &&
            (p.up ? (p.OH == 2 * p.IH && p.OW == 2 * p.IW) : (p.OH == p.IH && p.OW == p.IW)) &&
-           (int64_t)p.B * p.IH * p.IW * p.x_cs < (int64_t)1 << 40;
+           (int64_t)p.B * p.IH * p.IW * p.x_cs < (int64_t)1 << 40 &&
+           // window offsets inside one image are 32-bit byte offsets against a descriptor of at most 0xfffff000 bytes (both
+           // window kernels, gemm_conv_win4.hip too): a bigger image (128 channels at 4096x4096) goes to the generic GEMM,
+           // whose addressing is 64-bit, instead of wrapping or reading the out-of-range zeros
+           (int64_t)p.IH * p.IW * p.x_cs * 2 < 0xfffff000ll;
 }
 
 // With gn_ab set the launch needs the plain (not upsampled) variant and room for the image's (a, b) pairs behind the

@@ -34,6 +34,46 @@ def save_image(img, path):
     Image.fromarray(arr).save(path)
 
 
+def save_image_u8(arr, path):
+    """One [H,W,3] uint8 picture as the device's output kernel quantised it (model.decode(out="u8"): the same
+    x255 + 0.5, clamp, truncation as `save_image`, without moving f32 samples over PCIe)."""
+    from PIL import Image
+    Image.fromarray(arr.cpu().numpy()).save(path)
+
+
+def prepare_output_dir(out):
+    """The reference removes an existing --output_path before writing (inference.py:41-45).  Same here, but only for a
+    directory that looks like a previous run of this harness (it has recon/) or is empty: a mistyped path must not cost
+    somebody a directory tree."""
+    import shutil
+    if os.path.exists(out):
+        if not os.path.isdir(out):
+            raise SystemExit(f"--output_path {out!r} exists and is not a directory")
+        if os.listdir(out) and not os.path.isdir(os.path.join(out, "recon")):
+            raise SystemExit(f"--output_path {out!r} exists, is not empty and has no recon/ of an earlier run: "
+                             "refusing to delete it")
+        shutil.rmtree(out)
+    recon_path, stream_path = os.path.join(out, "recon"), os.path.join(out, "stream")
+    os.makedirs(recon_path)
+    os.makedirs(stream_path)
+    return recon_path, stream_path
+
+
+def check_mode_args(parser, cli):
+    """argparse leaves every path optional like the reference does (inference.py:138-147); what each mode needs is
+    checked here instead of failing later inside os.path.join(None, ...)."""
+    if cli["decoder_only"]:
+        for k in ("decoder_bin_path", "decoder_out_path"):
+            if not cli[k]:
+                parser.error(f"--decoder_only needs --{k}")
+    else:
+        for k in ("output_path", "eval_image_path"):
+            if not cli[k]:
+                parser.error(f"--{k} is required unless --decoder_only is given")
+        if not os.path.isdir(cli["eval_image_path"]):
+            parser.error(f"--eval_image_path {cli['eval_image_path']!r} is not a directory")
+
+
 def load_image(path):
     """data/evalset.py:15-20: RGB, ToTensor() * 2 - 1 -> f32 [3,H,W] in [-1,1]."""
     from PIL import Image
@@ -53,6 +93,7 @@ def parse_args(argv=None):
     parser.add_argument("--vae_path", type=str, default=None, required=False)
     parser.add_argument("--batch_size", type=int, default=16, required=False)
     cli = vars(parser.parse_args(argv))
+    check_mode_args(parser, cli)
     with open(cli["config_path"]) as f:
         config = yaml.safe_load(f) or {}
     config.update(cli)                                   # CLI over file, like OmegaConf.merge(config, args)
@@ -93,27 +134,23 @@ class Evaluator:
             for group in by_size.values():
                 for i in range(0, len(group), args["batch_size"]):
                     chunk = group[i:i + args["batch_size"]]
-                    recon = self.model.decode(fp=chunk, unit_range=True)
+                    recon = self.model.decode(fp=chunk, out="u8")
                     for f, img in zip(chunk, recon):
-                        save_image(img, os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png"))
+                        save_image_u8(img, os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png"))
             return
-        recon = self.model.decode(fp=src, unit_range=True)      # clamp(-1,1)*0.5+0.5, inference.py:106
-        save_image(recon[0], dst)
+        # clamp(-1,1)*0.5+0.5 and save_image's 8-bit quantisation (inference.py:106-107) happen in the output kernel;
+        # a picture with NaN / Inf raises kernels.HalfRangeError there instead of being written
+        recon = self.model.decode(fp=src, out="u8")
+        save_image_u8(recon[0], dst)
 
 
     @torch.no_grad()
     def evaluate_folder(self):
         """The encode + decode loop of the reference (inference.py:109-134), one picture at a time."""
-        import shutil
-
         import pandas as pd
         args = self.args
         out = args["output_path"]
-        recon_path, stream_path = os.path.join(out, "recon"), os.path.join(out, "stream")
-        if os.path.exists(out):
-            shutil.rmtree(out)
-        os.makedirs(recon_path)
-        os.makedirs(stream_path)
+        recon_path, stream_path = prepare_output_dir(out)
         src = args["eval_image_path"]
         names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
         torch.manual_seed(0)                                   # inference.py:28: the draw of latent_dist.sample()
@@ -126,8 +163,8 @@ class Evaluator:
             noise = torch.randn(1, Hp // 8, Wp // 8, 4, device=self.model.device)
             stream_file = os.path.join(stream_path, f"{name}.bin")
             _, bpp = self.model.encode(image, fp=stream_file, noise=noise)
-            recon = self.model.decode(fp=stream_file, unit_range=True)
-            save_image(recon[0], os.path.join(recon_path, f"{name}.png"))
+            recon = self.model.decode(fp=stream_file, out="u8")
+            save_image_u8(recon[0], os.path.join(recon_path, f"{name}.png"))
             bpp = dict(bpp)
             bpp["image_name"] = name
             rows.append(pd.DataFrame(bpp, index=[idx]))

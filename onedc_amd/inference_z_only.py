@@ -19,12 +19,10 @@ empty y part, 16 B header + ceil(14 n / 8) B of indices = 268 B for a 768x768 pi
 import argparse
 import glob
 import os
-import shutil
-
 import torch
 import yaml
 
-from .inference import load_image, save_image
+from .inference import check_mode_args, load_image, prepare_output_dir, save_image, save_image_u8
 
 
 def parse_args(argv=None):
@@ -39,6 +37,7 @@ def parse_args(argv=None):
     parser.add_argument("--decoder_out_path", type=str, default="", required=False)
     parser.add_argument("--batch_size", type=int, default=16, required=False)
     cli = vars(parser.parse_args(argv))
+    check_mode_args(parser, cli)
     with open(cli["config_path"]) as f:
         config = yaml.safe_load(f) or {}
     config.update(cli)
@@ -80,11 +79,7 @@ class Evaluator:
         if getattr(self.model, "vae_encoder", None) is None:
             raise RuntimeError("the checkpoint carries no encoder weights (enc.*, hyper_enc.*, VAE encoder)")
         out = args["output_path"]
-        recon_path, stream_path = os.path.join(out, "recon"), os.path.join(out, "stream")
-        if os.path.exists(out):
-            shutil.rmtree(out)
-        os.makedirs(recon_path)
-        os.makedirs(stream_path)
+        recon_path, stream_path = prepare_output_dir(out)
         src = args["eval_image_path"]
         names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
         torch.manual_seed(0)                                   # :30, the draw of latent_dist.sample()
@@ -112,8 +107,8 @@ class Evaluator:
         args = self.args
         src, dst = args["decoder_bin_path"], args["decoder_out_path"]
         if not os.path.isdir(src):
-            recon = self.model.decode_z_only_stream(fp=src, unit_range=True)
-            save_image(recon[0], dst)
+            recon = self.model.decode_z_only_stream(fp=src, out="u8")
+            save_image_u8(recon[0], dst)
             return
         from .entropy.utils import decode_i, read_from_file
         os.makedirs(dst, exist_ok=True)
@@ -124,9 +119,9 @@ class Evaluator:
         for group in by_size.values():
             for i in range(0, len(group), args["batch_size"]):
                 chunk = group[i:i + args["batch_size"]]
-                recon = self.model.decode_z_only_stream(fp=chunk, unit_range=True)
+                recon = self.model.decode_z_only_stream(fp=chunk, out="u8")
                 for f, img in zip(chunk, recon):
-                    save_image(img, os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png"))
+                    save_image_u8(img, os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png"))
 
 
 def main(argv=None):

@@ -116,12 +116,14 @@ SIGNATURES = {
     "onedc_prior_update_enc": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_prior_update_zonly": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_x0_from_noise": (_I, [_P, _P, _P, _L, _D, _P]),
-    "onedc_image_out": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_image_out": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "onedc_image_out_u8": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "onedc_copy_channels": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
     "onedc_window_partition": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
     "onedc_hip_version": (C.c_char_p, []),
+    "onedc_hip_act_format": (C.c_char_p, []),
 }
 HIP_SYMBOLS = list(SIGNATURES)
 
@@ -137,14 +139,32 @@ def lib(fmt=None):
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if fmt.encode() not in l.onedc_hip_version():
-            raise _native.NativeLibraryError(f"{fmt} kernel library reports {l.onedc_hip_version()!r}")
+        check_library_format(fmt, l.onedc_hip_act_format(), l.onedc_hip_version())
         _libs[fmt] = l
     return l
 
 
+def check_library_format(fmt, reported, version=b""):
+    """The library loaded for activation format `fmt` must have been BUILT for it: an f16 tensor read as bf16 is silent
+    garbage.  Exact token comparison (b"f16" is a substring of b"bf16")."""
+    if reported != fmt.encode():
+        raise _native.NativeLibraryError(f"the kernel library loaded for {fmt!r} activations was built for "
+                                         f"{reported.decode()!r} ({version.decode()})")
+
+
 class KernelError(RuntimeError):
     pass
+
+
+class HalfRangeError(FloatingPointError):
+    """A decoded picture holds NaN / Inf: an activation left the IEEE-half range (act_dtype "f16", +-65504; the VAE stream
+    is stored x 2^-6) somewhere upstream.  Raised by model.decode() / DecodePipeline.map() instead of returning the
+    clamped garbage; `.images` lists the batch positions.  The fix is in the message: act_dtype: bf16."""
+
+    def __init__(self, images, act):
+        self.images = list(images)
+        super().__init__(f"decoded picture(s) {self.images} of the batch hold non-finite values "
+                         f"({act} activations: half-precision range exceeded); set act_dtype: bf16 in the config")
 
 
 def _ok(rc, name):
@@ -490,9 +510,17 @@ def x0_from_noise(reduced, eps, x0, alpha_bar):
     return x0
 
 
-def image_out(x, out, H, W, unit_range=False):
+def image_out(x, out, H, W, unit_range=False, nonfinite=None):
+    """nonfinite: int32 device tensor [B], zero-filled: word b becomes 1 when picture b holds a NaN / Inf (before the clamp)."""
     _ok(lib().onedc_image_out(x.ptr, int(x.f32), x.cs, out.data_ptr(), x.B, x.H, x.W, H, W, int(unit_range),
-                              stream()), "onedc_image_out")
+                              _ptr(nonfinite), stream()), "onedc_image_out")
+    return out
+
+
+def image_out_u8(x, out, H, W, nhwc=True, nonfinite=None):
+    """8-bit samples of the cropped picture (save_image's quantisation on the device): out uint8 [B,H,W,3] or [B,3,H,W]."""
+    _ok(lib().onedc_image_out_u8(x.ptr, int(x.f32), x.cs, out.data_ptr(), x.B, x.H, x.W, H, W, int(nhwc),
+                                 _ptr(nonfinite), stream()), "onedc_image_out_u8")
     return out
 
 

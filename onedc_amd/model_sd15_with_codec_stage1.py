@@ -97,10 +97,12 @@ class SD15_1step_codec_stage1:
             self.load_encoder_state_dicts(codec, codec, vae)
         return self
 
-    def load_synthetic(self, seed=0):
-        """Deterministic random-init weights of the real architecture (no checkpoints offline)."""
-        return self.load_state_dicts(synth.unet_state_dict(seed), synth.codec_state_dict(seed),
-                                     synth.vae_state_dict(seed))
+    def load_synthetic(self, seed=0, preset=None):
+        """Deterministic synthetic weights of the real architecture (no checkpoints offline).  preset: "random_init"
+        (default) or "trained_like" (residual branches damped so that x0 rms ~1 and the prior stays inside its table:
+        the operating point of a trained checkpoint, onedc_amd/synth.py)."""
+        return self.load_state_dicts(synth.unet_state_dict(seed, preset=preset), synth.codec_state_dict(seed, preset=preset),
+                                     synth.vae_state_dict(seed, preset=preset))
 
     def load_encoder_state_dicts(self, codec_enc_sd, hyper_enc_sd, vae_enc_sd):
         with K.act_format(self.act):
@@ -208,42 +210,69 @@ class SD15_1step_codec_stage1:
                 image = self.vae_large.decode(x0)
         return {"eps": eps, "reduced": reduced, "x0": x0, "image": image}
 
-    def decode(self, fp=None, stream=None, unit_range=False):
+    def decode(self, fp=None, stream=None, unit_range=False, out="f32"):
         with K.act_format(self.act):
-            return self._decode(fp=fp, stream=stream, unit_range=unit_range)
+            return self._decode(fp=fp, stream=stream, unit_range=unit_range, out=out)
 
     @torch.no_grad()
-    def _decode(self, fp=None, stream=None, unit_range=False):
-        """-> f32 tensor [B,3,H,W] (B = 1 for a single path/bytes, as in the reference)."""
+    def _decode(self, fp=None, stream=None, unit_range=False, out="f32"):
+        """-> f32 tensor [B,3,H,W] (B = 1 for a single path/bytes, as in the reference); out="u8": the 8-bit samples
+        [B,H,W,3] that `save_image` would write (inference.py:106-107), converted on the device.
+        Raises kernels.HalfRangeError when a picture holds NaN / Inf (f16 range exceeded) unless `check_finite` is off."""
         assert fp or stream
         with torch.cuda.device(self.device):
             entropy_out = self.codec_model.decode_entropy(fp=fp, stream=stream)
-            return self._decode_after_entropy(entropy_out, unit_range)
+            res, flags = self._decode_after_entropy(entropy_out, unit_range, out=out)
+            self._raise_if_nonfinite(flags)
+            return res
+
+    check_finite = True      # model.decode() / DecodePipeline.map() raise HalfRangeError on NaN / Inf pictures
+
+    def _raise_if_nonfinite(self, flags):
+        """flags: int32 [B] written by the output kernel (device, or already on the host)."""
+        if flags is None or not self.check_finite:
+            return
+        bad = torch.nonzero(flags.cpu()).flatten().tolist()         # (a device tensor synchronises its stream here)
+        if bad:
+            raise K.HalfRangeError(bad, self.act)
 
     @torch.no_grad()
-    def _decode_after_entropy(self, entropy_out, unit_range=False, vae_gate=None):
-        """Synthesis transform, UNet step, x0, VAE decoder, crop: everything after the rANS hops."""
+    def _decode_after_entropy(self, entropy_out, unit_range=False, vae_gate=None, out="f32"):
+        """Synthesis transform, UNet step, x0, VAE decoder, crop: everything after the rANS hops.
+        -> (pictures, non-finite flags int32 [B] on the device)."""
         y_hat, z_semantic, orig_hw, pad_hw, pad_size = entropy_out
         h_detail_hat, y_semantic = self.codec_model.synthesis(y_hat, z_semantic)
-        out = self.decode_latents(h_detail_hat, y_semantic, vae_gate)
-        image = out["image"]
+        image = self.decode_latents(h_detail_hat, y_semantic, vae_gate)["image"]
         H, W = orig_hw[0]
         if any(hw != (H, W) for hw in orig_hw):
             H, W = pad_hw                                            # mixed crops: return the padded frame
-        res = torch.empty(image.B, 3, H, W, dtype=torch.float32, device=self.device)
-        K.image_out(image, res, H, W, unit_range)
-        return res
+        return self._image_out(image, H, W, unit_range, out)
+
+    def _image_out(self, image, H, W, unit_range, out="f32"):
+        flags = torch.zeros(image.B, dtype=torch.int32, device=self.device)
+        if out == "u8":
+            res = torch.empty(image.B, H, W, 3, dtype=torch.uint8, device=self.device)
+            K.image_out_u8(image, res, H, W, True, flags)
+        elif out == "f32":
+            res = torch.empty(image.B, 3, H, W, dtype=torch.float32, device=self.device)
+            K.image_out(image, res, H, W, unit_range, flags)
+        else:
+            raise ValueError(f"out must be 'f32' or 'u8', not {out!r}")
+        return res, flags
 
     def pipeline(self, depth=2, s_streams=2, z_only=False, serialise_vae=True):
         """z_only: the batches are indices-only containers of the ex-low-rate model (`decode_z_only_stream`)."""
         return DecodePipeline(self, depth, s_streams, z_only, serialise_vae)
 
-    def decode_z_only_stream(self, fp=None, stream=None, unit_range=False):
+    def decode_z_only_stream(self, fp=None, stream=None, unit_range=False, out="f32"):
         """Decoder of the ex-low-rate model from files / byte strings: the 16 B + ceil(14 n / 8) B containers written by
         `forward_z_only` / `python -m onedc_amd.inference_z_only` (the reference has no such entry: its z-only harness
         runs `forward()` and never writes a stream, models/sd15_onedc_codec_z_only/inference.py:125)."""
         with K.act_format(self.act), torch.no_grad(), torch.cuda.device(self.device):
-            return self._decode_after_entropy(self.codec_model.decode_entropy_z_only(fp=fp, stream=stream), unit_range)
+            res, flags = self._decode_after_entropy(self.codec_model.decode_entropy_z_only(fp=fp, stream=stream),
+                                                    unit_range, out=out)
+            self._raise_if_nonfinite(flags)
+            return res
 
     def decode_z_only(self, indices):
         with K.act_format(self.act):
@@ -256,10 +285,9 @@ class SD15_1step_codec_stage1:
         with torch.cuda.device(self.device):
             y_hat, z_semantic = self.codec_model.recon_with_z(indices.to(self.device, torch.int32))
             h_detail_hat, y_semantic = self.codec_model.synthesis(y_hat, z_semantic)
-            out = self.decode_latents(h_detail_hat, y_semantic)
-            image = out["image"]
-            res = torch.empty(image.B, 3, image.H, image.W, dtype=torch.float32, device=self.device)
-            K.image_out(image, res, image.H, image.W, False)
+            image = self.decode_latents(h_detail_hat, y_semantic)["image"]
+            res, flags = self._image_out(image, image.H, image.W, False)
+            self._raise_if_nonfinite(flags)
         return res
 
 
@@ -290,6 +318,8 @@ class DecodePipeline:
         # fills the chip on its own -- whereas a VAE next to the other batch's synthesis / UNet (hundreds of kernels of
         # 72..720 workgroups) fills the CUs those leave idle.  No host thread blocks on it.
         self.serialise_vae = serialise_vae and len(self.streams_s) > 1
+        self.timing = False          # True: the end-of-batch events carry timestamps; map() leaves them in `last_done_events`
+        self.last_done_events = []
         self._vae_lock = threading.Lock()
         self._vae_done = None
         self._in = queue.Queue()
@@ -322,10 +352,10 @@ class DecodePipeline:
                     # to the two streams instead (every kernel is batch-invariant: same bits as the whole batch)
                     y_hat, z_sem, orig_hw, pad_hw, pad_size = out
                     h = y_hat.B // 2
-                    slot, results, unit_range, done = job
+                    slot, results, opts, done = job
                     for part, (b0, b1) in enumerate(((0, h), (h, y_hat.B))):
                         sub = (y_hat.batch_slice(b0, b1), z_sem.batch_slice(b0, b1), orig_hw[b0:b1], pad_hw, pad_size)
-                        self._mid.put((sub, ev, None, ((slot, part), results, unit_range, done)))
+                        self._mid.put((sub, ev, None, ((slot, part), results, opts, done)))
                 else:
                     self._mid.put((out, ev, None, job))
             except BaseException as e:      # surfaced on the caller's thread
@@ -340,7 +370,8 @@ class DecodePipeline:
             item = self._mid.get()
             if item is None:
                 return
-            out, ev, err, (slot, results, unit_range, done) = item
+            out, ev, err, (slot, results, opts, done) = item
+            unit_range, fmt, to_host = opts
             try:
                 if err is not None:
                     raise err
@@ -348,44 +379,66 @@ class DecodePipeline:
                     stream.wait_event(ev)
                     for v in (out[0], out[1]):      # y_hat / z_semantic were allocated on the entropy stream
                         v.t.record_stream(stream)
-                    res = self.model._decode_after_entropy(out, unit_range, _VaeGate(self, stream) if self.serialise_vae else None)
-                    ev_done = torch.cuda.Event()
+                    res, flags = self.model._decode_after_entropy(
+                        out, unit_range, _VaeGate(self, stream) if self.serialise_vae else None, out=fmt)
+                    # the non-finite flags ride to the host behind the pictures (pinned: the copy is asynchronous); with
+                    # to_host the pictures themselves do too -- the hand-off a service does (inference.py:106-107,119-120)
+                    flags_host = torch.empty(flags.shape, dtype=flags.dtype, pin_memory=True)
+                    flags_host.copy_(flags, non_blocking=True)
+                    if to_host:
+                        host = torch.empty(res.shape, dtype=res.dtype, pin_memory=True)
+                        host.copy_(res, non_blocking=True)
+                        res = host
+                    ev_done = torch.cuda.Event(enable_timing=self.timing)
                     ev_done.record(stream)
-                entry = (res, ev_done, stream, None)
+                entry = (res, ev_done, stream, None, flags_host)
             except BaseException as e:
-                entry = (None, None, None, e)
+                entry = (None, None, None, e, None)
             if isinstance(slot, tuple):                  # half of a split batch
                 results[slot[0]][slot[1]] = entry
             else:
                 results[slot] = entry
             done.release()
 
-    def map(self, batches, unit_range=False):
-        """Decode a list of batches (each a list of container byte strings) -> list of [B,3,H,W] tensors."""
+    def map(self, batches, unit_range=False, out="f32", to_host=False):
+        """Decode a list of batches (each a list of container byte strings) -> list of [B,3,H,W] f32 tensors, or with
+        out="u8" of [B,H,W,3] uint8 tensors (save_image's samples, converted on the device); to_host=True returns them in
+        page-locked host memory (the copies run on the decode streams, overlapped with the next batches).
+        Raises kernels.HalfRangeError for a batch with NaN / Inf pictures (model.check_finite)."""
         import threading
         results = [None] * len(batches)
         done = threading.Semaphore(0)
         n_jobs = 0
+        opts = (unit_range, out, to_host)
         for i, b in enumerate(batches):
             split = (i == len(batches) - 1 and len(batches) % 2 == 1 and len(self.streams_s) == 2 and len(b) >= 2 and
                      len(b) % 2 == 0)
             if split:
                 results[i] = [None, None]
-            self._in.put((b, (i, results, unit_range, done), split))
+            self._in.put((b, (i, results, opts, done), split))
             n_jobs += 2 if split else 1
         for _ in range(n_jobs):
             done.acquire()
         cur = torch.cuda.current_stream(self.dev)
         outs = []
+        self.last_done_events = [[p[1] for p in (e if isinstance(e, list) else [e])] for e in results]
         for entry in results:
             parts = entry if isinstance(entry, list) else [entry]
-            tensors = []
-            for res, ev_done, stream, err in parts:
+            tensors, first = [], 0
+            for res, ev_done, stream, err, flags_host in parts:
                 if err is not None:
                     raise err
-                cur.wait_event(ev_done)
-                res.record_stream(cur)
+                if self.model.check_finite or to_host:
+                    ev_done.synchronize()                    # the flags (and host pictures) have landed
+                    if self.model.check_finite:
+                        bad = [first + b for b in torch.nonzero(flags_host).flatten().tolist()]
+                        if bad:
+                            raise K.HalfRangeError(bad, self.model.act)
+                if not to_host:
+                    cur.wait_event(ev_done)
+                    res.record_stream(cur)
                 tensors.append(res)
+                first += res.shape[0]
             outs.append(tensors[0] if len(tensors) == 1 else torch.cat(tensors, 0))
         return outs
 

@@ -316,6 +316,53 @@ def main():
              y_hat=sample_points(y_hat8, 16384),
              y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat8.numpy().tobytes()).digest(), dtype=np.uint8))
 
+    # ---------------------------------------------------------------- G9 the same, "trained_like" synthetic weights
+    # The random-init prior nets of G8 grow (scales, means) ~4x per hop until most scales leave the table; the damped preset of
+    # onedc_amd.synth keeps them inside it and passes a perturbation on with gain < 1 per hop, like a trained context model.
+    # Same capture as G8: what a drop-in decoder must reproduce, written by the reference's own compress path.
+    print("G9 reference-made streams, trained-like weights (256x256, 768x768)")
+    sd_t = synth.codec_state_dict(seed=0, preset="trained_like")
+
+    def load_t(mod, prefix):
+        mod.load_state_dict(sub_sd(sd_t, prefix), strict=True)
+        return mod.eval()
+
+    with torch.no_grad():
+        hyper_dec_t = load_t(rcm.HyperDecoder(N, [4] * 7), "hyper_dec.")
+        fusion_t = load_t(torch.nn.Sequential(DepthConvBlock4(N, 2 * N), DepthConvBlock4(2 * N, 2 * N)), "y_prior_fusion.")
+        reduction_t = load_t(torch.nn.Conv2d(2 * N, N, 1), "y_spatial_prior_reduction.")
+        adaptors_t = [load_t(DepthConvBlock4(2 * N, 2 * N), f"y_spatial_prior_adaptor_{i}.") for i in (1, 2, 3)]
+        spatial_t = load_t(torch.nn.Sequential(*[DepthConvBlock4(2 * N, 2 * N) for _ in range(3)]), "y_spatial_prior.")
+    rng9 = np.random.default_rng(9)
+    for tag, zn in (("256", 4), ("768", 12)):
+        with torch.no_grad():
+            indices9 = torch.from_numpy(rng9.integers(0, 16384, (1, zn, zn)))
+            z_hat9 = torch.stack([((indices9 // 4 ** d) % 4 - 2).float() / 2 for d in range(7)], dim=1)
+            params9, _ = hyper_dec_t(z_hat9)
+            fused9 = fusion_t(params9)
+            scales9, means9 = fused9.chunk(2, 1)
+            y9 = means9 + 1.5 * torch.randn(means9.shape, generator=torch.Generator().manual_seed(90 + zn))
+            out9 = cm.compress_four_part_prior(y9, fused9, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t,
+                                               y_spatial_prior_reduction=reduction_t)
+            yq9, s9, y_hat9 = out9[0:4], out9[4:8], out9[8]
+            ec.reset()
+            planes9 = []
+            for yq, sc in zip(yq9, s9):
+                planes9.append(cm.gaussian_encoder.build_indexes(sc))
+                cm.gaussian_encoder.encode(yq, sc)
+            ec.flush()
+            stream9 = ec.get_encoded_stream()
+            ec.set_stream(stream9)
+            back9 = cm.decompress_four_part_prior(fused9, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t, reduction_t)
+            assert torch.equal(back9, y_hat9)
+            inside = float(torch.stack([((p > 0) & (p < 255)).float().mean() for p in planes9]).mean())
+            print(f"    {tag}: {len(stream9)} B, {len(stream9) * 8 / (4 * planes9[0].numel()):.2f} bit/symbol, "
+                  f"{inside:.3f} of the table indexes strictly inside the table")
+        save(f"g9_ref_stream_{tag}_trained.npz", indices=indices9.int(), stream=np.frombuffer(stream9, np.uint8),
+             symbols=torch.stack(list(yq9)).to(torch.int16), index_planes=torch.stack(planes9).to(torch.int16),
+             y_hat=sample_points(y_hat9, 16384),
+             y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat9.numpy().tobytes()).digest(), dtype=np.uint8))
+
     # ---------------------------------------------------------------- G7 hyper encoder (encode side)
     print("G7 hyper encoder")
     with torch.no_grad():

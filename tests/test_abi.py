@@ -39,10 +39,28 @@ def test_hip_library_exports_header_symbols():
         lib = ctypes.CDLL(path)
         for n in names:
             assert hasattr(lib, n), f"{n} declared in onedc_hip.h but not exported by {path}"
-        lib.onedc_hip_version.restype = ctypes.c_char_p
+        lib.onedc_hip_version.restype = lib.onedc_hip_act_format.restype = ctypes.c_char_p
         assert fmt + b" activations" in lib.onedc_hip_version()
+        assert lib.onedc_hip_act_format() == fmt
     assert set(names) == set(kernels.HIP_SYMBOLS)
     assert kernels.lib("bf16") is not kernels.lib("f16")
+
+
+def test_library_of_the_other_format_is_refused(monkeypatch):
+    """b"f16" is a substring of b"bf16": the loader compares the exact token the library reports, so a bf16 build handed in
+    as the f16 library (ONEDC_HIP_F16_SO pointing at an experiment build without -DONEDC_ACT_F16) cannot be used."""
+    with pytest.raises(_native.NativeLibraryError):
+        kernels.check_library_format("f16", b"bf16", b"onedc-hip 0.3 (gfx950, bf16 activations)")
+    with pytest.raises(_native.NativeLibraryError):
+        kernels.check_library_format("bf16", b"f16")
+    kernels.check_library_format("f16", b"f16")
+    build.build_hip()
+    monkeypatch.setattr(kernels, "_libs", {})
+    monkeypatch.setattr(_native, "_hip_f16", None)
+    monkeypatch.setattr(_native, "HIP_F16_SO", _native.HIP_SO)            # the bf16 build under the f16 name
+    with pytest.raises(_native.NativeLibraryError, match="built for 'bf16'"):
+        kernels.lib("f16")
+    monkeypatch.setattr(_native, "_hip_f16", None)
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -11,7 +11,7 @@ import torch
 import torch.multiprocessing as mp
 
 from onedc_amd import arch, synth
-from onedc_amd.dataparallel import broadcast_state_dicts, max_over_ranks, shard
+from onedc_amd.dataparallel import broadcast_state_dicts, max_over_ranks, parse_cpulist, plan_core_sets, shard
 
 
 def _free_port():
@@ -87,6 +87,50 @@ def test_shard_is_a_partition():
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
 
 
+def _check_plan(plan, world, allowed):
+    assert plan is not None and len(plan) == world
+    seen = set()
+    for cores in plan:
+        assert len(cores) >= 2 and set(cores) <= set(allowed)
+        assert not (seen & set(cores))                      # pairwise disjoint
+        seen |= set(cores)
+
+
+def test_host_core_plan_follows_the_numa_topology():
+    """WORLD_SIZE = 8 on a faked 2-socket node (128 cores, SMT siblings numbered +128; GPUs 0-3 on node 0, 4-7 on node 1):
+    every rank gets a non-empty core set on ITS GPU's node, all sets disjoint; degraded inputs fall back sanely."""
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    node_cpus = {0: parse_cpulist("0-63,128-191"), 1: parse_cpulist("64-127,192-255")}
+    allowed = list(range(256))
+    gpu_nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    plan = plan_core_sets(8, allowed, gpu_nodes, node_cpus)
+    _check_plan(plan, 8, allowed)
+    for r in range(8):
+        assert set(plan[r]) <= set(node_cpus[gpu_nodes[r]]) and len(plan[r]) == 32
+    # GPUs enumerated in an interleaved order: contiguous slices would put ranks on the wrong socket, the plan does not
+    inter = [0, 1, 0, 1, 0, 1, 0, 1]
+    plan = plan_core_sets(8, allowed, inter, node_cpus)
+    _check_plan(plan, 8, allowed)
+    assert all(set(plan[r]) <= set(node_cpus[inter[r]]) for r in range(8))
+    # a cgroup that only allows part of the machine
+    sub = list(range(16, 48)) + list(range(64, 96))
+    plan = plan_core_sets(8, sub, gpu_nodes, node_cpus)
+    _check_plan(plan, 8, sub)
+    assert all(set(plan[r]) <= set(node_cpus[gpu_nodes[r]]) for r in range(8))
+    # no topology (containers): contiguous slices
+    plan = plan_core_sets(8, allowed, None, None)
+    _check_plan(plan, 8, allowed)
+    assert plan[3] == list(range(96, 128))
+    # one GPU with an unknown node (numa_node = -1) shares what the node groups left over
+    plan = plan_core_sets(4, list(range(64)), [0, 0, -1, 1], {0: list(range(32)), 1: list(range(32, 64))})
+    _check_plan(plan, 4, list(range(64)))
+    # all allowed cores on one node although the GPUs sit on two: nobody may end up empty
+    plan = plan_core_sets(8, list(range(64)), gpu_nodes, node_cpus)
+    _check_plan(plan, 8, list(range(64)))
+    # too few cores for the ranks: no pinning at all
+    assert plan_core_sets(8, list(range(8)), gpu_nodes, node_cpus) is None
+
+
 @pytest.mark.gpu
 def test_bench_under_torchrun_with_rccl_broadcast_on_one_gpu(tmp_path):
     """The launch line the driver uses for N > 1, with N = 1 (the only size a 1-GPU box allows):
@@ -111,4 +155,6 @@ def test_bench_under_torchrun_with_rccl_broadcast_on_one_gpu(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["config"]["weights"].startswith("rank 0 builds") and line["config"]["images_per_gpu_per_step"] == 4
+    assert line["step_ms"]["n"] >= 1 and line["handoff"]["value"] > 0 and line["device"]["stage_s_ms"] > 0
+    assert line["host_rans"]["decode_ns_per_symbol"] > 0
     assert not torch.cuda.is_initialized()

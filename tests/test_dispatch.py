@@ -60,6 +60,15 @@ def test_layers_no_window_kernel_takes():
     assert name(params(Cout=3)) == "16x256"                                           # conv_out-like
 
 
+def test_window_kernels_refuse_images_beyond_their_32bit_window_offsets():
+    """A window kernel addresses one image through a buffer descriptor of at most 0xfffff000 bytes with 32-bit offsets:
+    128 channels at 4096x4096 (4 GiB per image) must go to a 64-bit-addressed GEMM, not wrap."""
+    assert name(params(B=1, H=2048, W=2048, Cin=128, Cout=128)) == "win3x3_4w"          # 1 GiB per image: fine
+    assert name(params(B=1, H=4096, W=4096, Cin=128, Cout=128)) not in ("win3x3_4w", "win3x3")
+    assert name(params(B=1, H=4096, W=4096, Cin=128, Cout=128, tile=131)) == -11        # forcing it is refused
+    assert K.lib().onedc_conv_win_takes(C.byref(params(B=1, H=4096, W=4096, Cin=128, Cout=128))) == 0
+
+
 def test_upsample_phases():
     p = params(H=32, W=32, Cin=256, Cout=256, up=2)
     assert name(p) == "ups2x2_4w"

@@ -2,10 +2,11 @@
 itself pinned to the reference by tests/test_oracle_codec.py), stage by stage and end to end, with
 the deterministic synthetic weights of onedc_amd.synth.
 
-Floating-point tolerances are written at each check.  The product computes in bf16 with fp32
-accumulation (BASELINE config "bf16"); the oracle is fp32, so per-stage relative RMS errors of a
-few 1e-3 per layer are the expected bf16 rounding noise, not bugs.  Integer/byte results (symbols,
-bitstreams, round trips) are checked bit-exactly.
+Floating-point tolerances are written at each check and KEYED BY THE 16-BIT FORMAT (`tol(f16, bf16)`): the product
+computes in IEEE half (default) or bf16 (ONEDC_ACT=bf16, BASELINE config "bf16") with fp32 accumulation, the oracle is
+fp32.  bf16 rounds 8x coarser than f16, so one number for both would let a 5-10x regression of the f16 kernels pass: the
+f16 bounds are ~2x the values measured on MI355X (printed by every check), the bf16 bounds the round-1 ones.
+Integer/byte results (symbols, bitstreams, round trips) are checked bit-exactly.
 """
 import numpy as np
 import pytest
@@ -31,6 +32,11 @@ DEV = "cuda:0"
 def rel_rms(got, ref):
     got, ref = got.double().cpu(), ref.double().cpu()
     return float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
+
+
+def tol(f16, bf16):
+    """Tolerance for the library under test (`K.act()`)."""
+    return f16 if K.act() == "f16" else bf16
 
 
 def check(got, ref, tol, what):
@@ -76,15 +82,15 @@ def test_codec_blocks(codec_sd):
     x768 = torch.from_numpy(g["x768"]).to(torch.bfloat16).float()
     with torch.no_grad():
         y = DepthConvBlock4(codec_sd, "hyper_dec.to_entropy.0", DEV)(from_nchw(x128.to(DEV)))
-        check(y.torch_nchw(), R.depth_conv_block4(codec_sd, "hyper_dec.to_entropy.0", x128), 1e-2, "DCB4 128->128")
+        check(y.torch_nchw(), R.depth_conv_block4(codec_sd, "hyper_dec.to_entropy.0", x128), tol(2e-3, 1e-2), "DCB4 128->128")
         y = DepthConvBlock4(codec_sd, "y_prior_fusion.0", DEV)(from_nchw(x128.to(DEV)))
-        check(y.torch_nchw(), R.depth_conv_block4(codec_sd, "y_prior_fusion.0", x128), 1e-2, "DCB4 128->256")
+        check(y.torch_nchw(), R.depth_conv_block4(codec_sd, "y_prior_fusion.0", x128), tol(2e-3, 1e-2), "DCB4 128->256")
         y = ResidualBlockUpsample(codec_sd, "hyper_dec.to_entropy.1", DEV)(from_nchw(x128.to(DEV)))
-        check(y.torch_nchw(), R.residual_block_upsample(codec_sd, "hyper_dec.to_entropy.1", x128), 1e-2, "RBU")
+        check(y.torch_nchw(), R.residual_block_upsample(codec_sd, "hyper_dec.to_entropy.1", x128), tol(2e-3, 1e-2), "RBU")
         y = VQResnetBlock(codec_sd, "semantic_adaptor.to_semantic.1", DEV)(from_nchw(x768.to(DEV)), ws)
-        check(y.torch_nchw(), R.vq_resnet_block(codec_sd, "semantic_adaptor.to_semantic.1", x768), 1e-2, "ResnetBlock")
+        check(y.torch_nchw(), R.vq_resnet_block(codec_sd, "semantic_adaptor.to_semantic.1", x768), tol(2e-3, 1e-2), "ResnetBlock")
         y = VQAttnBlock(codec_sd, "semantic_adaptor.to_semantic.2", DEV, 768)(from_nchw(x768.to(DEV)), ws)
-        check(y.torch_nchw(), R.vq_attn_block(codec_sd, "semantic_adaptor.to_semantic.2", x768), 1e-2, "AttnBlock")
+        check(y.torch_nchw(), R.vq_attn_block(codec_sd, "semantic_adaptor.to_semantic.2", x768), tol(2e-3, 1e-2), "AttnBlock")
 
 
 def test_hyper_decoder_and_prior_params(codec, codec_sd):
@@ -92,7 +98,7 @@ def test_hyper_decoder_and_prior_params(codec, codec_sd):
     g = golden("g5_codec_path.npz")
     idx = torch.from_numpy(g["indices"]).to(DEV)
     fused, z_sem = codec._params_from_indices(idx)
-    check(z_sem.torch_nchw(), torch.from_numpy(g["z_semantic"]), 4e-3, "z_semantic vs reference golden")
+    check(z_sem.torch_nchw(), torch.from_numpy(g["z_semantic"]), tol(1e-3, 4e-3), "z_semantic vs reference golden")
     # the prior networks run in exact f32 (f32 MFMA): tol 1e-5 rel. RMS against the reference's fp32 CPU result
     check(fused.torch_nchw(), torch.from_numpy(g["fused"]), 1e-5, "prior params (f32 path) vs reference golden")
     with torch.no_grad():
@@ -228,11 +234,11 @@ def test_semantic_adaptor_and_synthesis(codec, codec_sd):
     with torch.no_grad():
         ys_ref = R.semantic_adaptor(codec_sd, z_sem)
         xh_ref = R.codec_decoder(codec_sd, y_hat, ys_ref)
-    check(y_sem.torch_nchw(), ys_ref, 2e-2, "semantic adaptor")
-    check(x_hat.torch_nchw(), xh_ref, 3e-2, "codec synthesis (h_detail_hat)")
+    check(y_sem.torch_nchw(), ys_ref, tol(4e-3, 2e-2), "semantic adaptor")
+    check(x_hat.torch_nchw(), xh_ref, tol(6e-3, 3e-2), "codec synthesis (h_detail_hat)")
     flat = x_hat.torch_nchw().reshape(-1).cpu()
     gi = torch.from_numpy(g["x_hat.idx"])
-    assert rel_rms(flat[gi], torch.from_numpy(g["x_hat.val"])) <= 3e-2       # vs the reference-made golden
+    assert rel_rms(flat[gi], torch.from_numpy(g["x_hat.val"])) <= tol(6e-3, 3e-2)       # vs the reference-made golden
 
 
 @pytest.fixture(scope="module")
@@ -251,8 +257,8 @@ def test_unet_step(unet_pair):
     eps, reduced = unet(from_nchw(sample.to(DEV)), 999, from_nchw(ctx.to(DEV)))
     with torch.no_grad():
         eps_ref, red_ref = R.unet_forward(sd, sample, torch.tensor([999, 999]), ctx.permute(0, 2, 3, 1).reshape(2, 6, 768))
-    check(reduced.torch_nchw(), red_ref, 1e-2, "vae_reduction")
-    check(eps.torch_nchw(), eps_ref, 3e-2, "UNet eps")
+    check(reduced.torch_nchw(), red_ref, tol(2e-3, 1e-2), "vae_reduction")
+    check(eps.torch_nchw(), eps_ref, tol(6e-3, 3e-2), "UNet eps")
 
 
 @pytest.mark.parametrize("h,w", [(32, 48), (24, 40)])
@@ -267,13 +273,14 @@ def test_vae_decoder_windowed(h, w):
     img = vae.decode(lv)
     with torch.no_grad():
         ref = R.vae_decode(sd, lat, 16)
-    check(img.torch_nchw(), ref, 3e-2, f"VAE decoder {h}x{w}")
+    check(img.torch_nchw(), ref, tol(6e-3, 3e-2), f"VAE decoder {h}x{w}")
 
 
 def test_end_to_end_decode_psnr(full_model, gaussian_tables):
     """Whole decode of two 128x192 streams (made by the product's own encoder side) against the
     oracle run from the same decoded latents.  Reported: PSNR(product, oracle) on [0,1] pictures
-    (reference metric, test_quality.py:234-235).  tol: >= 30 dB (bf16 UNet + x14.65 eps->x0 gain)."""
+    (reference metric, test_quality.py:234-235).  tol: >= 60 dB with f16 activations (measured 67), >= 45 dB with bf16
+    (measured 49-50; bf16 UNet + x14.65 eps->x0 gain)."""
     model = full_model
     rng = np.random.default_rng(9)
     idx = torch.from_numpy(rng.integers(0, 16384, (2, 2, 3)).astype(np.int32)).to(DEV)
@@ -288,7 +295,7 @@ def test_end_to_end_decode_psnr(full_model, gaussian_tables):
     ref = R.to_unit_range(out["image"])
     p = R.psnr(img.cpu(), ref)
     print(f"[parity] end-to-end PSNR(product, oracle) = {p:.2f} dB")
-    assert p >= 30.0
+    assert p >= tol(60.0, 45.0)
 
 
 def test_decode_pipeline_matches_sequential_decode(full_model):
@@ -339,8 +346,8 @@ def test_hyper_encoder_fsq_and_compress_round_trip(codec, codec_sd):
     z = codec.hyper_enc(yv, sv, codec.ws)
     with torch.no_grad():
         z_ref = R.hyper_encoder(henc_sd, y.to(torch.bfloat16).float(), sem.to(torch.bfloat16).float())
-    check(z.slice(0, 7).torch_nchw(), z_ref, 3e-2, "hyper encoder z vs oracle")
-    check(z.slice(0, 7).torch_nchw(), torch.from_numpy(g["z"]), 3e-2, "hyper encoder z vs reference golden")
+    check(z.slice(0, 7).torch_nchw(), z_ref, tol(6e-3, 3e-2), "hyper encoder z vs oracle")
+    check(z.slice(0, 7).torch_nchw(), torch.from_numpy(g["z"]), tol(6e-3, 3e-2), "hyper encoder z vs reference golden")
     # FSQ kernel on a dense sweep of z values
     zz = (torch.rand(4, 7, 16, 16, generator=torch.Generator().manual_seed(31)) * 6 - 3)
     zzv = from_nchw(zz.to(DEV), torch.float32, pad_to=8)
@@ -376,7 +383,7 @@ def test_vae_encoder_vs_oracle():
     z = enc.encode(iv, noise.permute(0, 2, 3, 1).contiguous().to(DEV))
     with torch.no_grad():
         ref = R.vae_encode(sd, img, 16, noise)
-    check(z.torch_nchw(), ref, 3e-2, "VAE encoder latents")
+    check(z.torch_nchw(), ref, tol(6e-3, 3e-2), "VAE encoder latents")
 
 
 def test_flash_attention_head_dim_8():
@@ -400,7 +407,7 @@ def test_flash_attention_head_dim_8():
                  o, B, Hh, N, N, n_pad, DQ, DV, d ** -0.5)
     ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v
     got = o.float().cpu().view(B, N, Hh, DV)[..., :d].permute(0, 2, 1, 3)
-    check(got, ref, 8e-3, "flash attention d=8")
+    check(got, ref, tol(2e-3, 8e-3), "flash attention d=8")
 
 
 def test_analysis_transform_vs_oracle():
@@ -418,8 +425,8 @@ def test_analysis_transform_vs_oracle():
     y, sem = enc(iv, cv)
     with torch.no_grad():
         y_ref, sem_ref = R.codec_encoder(sd, img, cond)
-    check(sem.torch_nchw(), sem_ref, 5e-2, "analysis transform: sem (UNet mid output)")
-    check(y.torch_nchw(), y_ref, 5e-2, "analysis transform: y")
+    check(sem.torch_nchw(), sem_ref, tol(1e-2, 5e-2), "analysis transform: sem (UNet mid output)")
+    check(y.torch_nchw(), y_ref, tol(1e-2, 5e-2), "analysis transform: y")
 
 
 def test_model_encode_then_decode_round_trip(full_model, tmp_path):
@@ -581,6 +588,6 @@ def test_softmax_rows_long_rows_match_torch():
     got = p.view(rows, n_pad).float().cpu()
     assert float(got[:, n:].abs().max()) == 0.0
     ref = torch.softmax(s.double(), -1)
-    tol = 2e-3 if K.act() == "f16" else 1e-2                  # output rounding: 11 / 8 significant bits
-    assert float((got[:, :n].double() - ref).abs().max()) <= tol * float(ref.max())
-    assert float((got[:, :n].double().sum(-1) - 1).abs().max()) <= tol
+    t = tol(2e-3, 1e-2)                                        # output rounding: 11 / 8 significant bits
+    assert float((got[:, :n].double() - ref).abs().max()) <= t * float(ref.max())
+    assert float((got[:, :n].double().sum(-1) - 1).abs().max()) <= t
