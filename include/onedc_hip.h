@@ -170,6 +170,11 @@ int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, 
  * 8 zeros] (onedc_amd/pack.py: head_positions); o has the v layout.  scale multiplies q.k before the softmax. */
 int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
                      int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream);
+/* The same with strides: q_rs / k_rs = elements between consecutive query / key rows (q, k as column slices of one wider
+ * projection output: a fused [to_q | to_k] GEMM, or the to_k of all layers that share a context), vt_bs = elements between
+ * the V^T blocks of consecutive images (the to_v of several layers from one batched GEMM); 0 = dense.  Multiples of 8. */
+int onedc_flash_attn_strided(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq, int Nk,
+                             int Nk_pad, int DQ, int DV, float scale, int q_rs, int k_rs, int64_t vt_bs, void *stream);
 /* 1 if onedc_flash_attn reads vt as bf16 for this shape whatever the library's activation format (head dims 40 and 80 with
  * at least 64 keys: P and V^T of those kernels are bf16, see attention.hip); the producer sets onedc_conv_params.out_bf16 */
 int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk);
@@ -237,6 +242,14 @@ int onedc_nchw_to_nhwc(const float *x, void *y, int y_f32, int B, int C, int H, 
 int onedc_patchify8(const float *x, int x_cs, void *y, int B, int H, int W, void *stream);
 /* latent_dist.sample() * scaling_factor: moments f32 [n][8], noise f32 [n][4] or NULL (mode) -> f32 [n][4] */
 int onedc_latent_sample(const float *moments, const float *noise, float *out, int64_t n, float scale, void *stream);
+
+/* MXFP8 experiment (reference call the layers belong to: model_sd15_with_codec_stage1.py:184-188): quantise every
+ * block of 32 consecutive channels of every pixel to OCP e4m3 with one shared power-of-two scale (OCP MX v1.0: what
+ * v_mfma_scale_f32_16x16x128_f8f6f4 consumes along K) and write the values back dequantised, 16 bit -> 16 bit.  A conv that
+ * reads y with weights treated the same way computes what an MXFP8 layer would (exact products, f32 accumulation), so the
+ * picture-level cost of such a layer is measured on hardware before any kernel is written for it.  C % 32 == 0. */
+int onedc_mxfp8_roundtrip(const void *x, void *y, int64_t pixels, int C, int x_cs, int x_co, int y_cs, int y_co,
+                          void *stream);
 
 /* sinusoidal timestep embedding, flip_sin_to_cos, shift 0 (decoder_unet.py:138): f32 [n][dim] */
 int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *stream);

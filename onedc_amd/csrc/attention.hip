@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const a16_t *__restrict
                                                          const a16_t *__restrict__ K,
                                                          const a16_t *__restrict__ VT,
                                                          a16_t *__restrict__ O, int H, int Nq, int Nk,
-                                                         int Nk_pad, float scale_log2e, int d_real) {
+                                                         int Nk_pad, float scale_log2e, int d_real, int q_rs, int k_rs,
+                                                              int64_t vt_bs) {
     using C = FA<DQ, DV, ONES_ROW>;
     constexpr int NBUF = PREFETCH ? 2 : 1;
     __shared__ __attribute__((aligned(16))) char lds[NBUF * C::STAGE];
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const a16_t *__restrict
 #pragma unroll
         for (int ks = 0; ks < C::QS; ++ks) {
             if (qi < Nq)
-                qf[t][ks] = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
+                qf[t][ks] = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * q_rs + h * DQ + ks * 32 + g * 8);
             else
                 qf[t][ks] = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const a16_t *__restrict
         for (int t = 0; t < 2; ++t) o[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
 
-    const a16_t *Kb = K + (int64_t)b * Nk * (H * DQ) + h * DQ;
-    const a16_t *Vb = VT + ((int64_t)b * H + h) * DV * Nk_pad;
+    const a16_t *Kb = K + (int64_t)b * Nk * k_rs + h * DQ;
+    const a16_t *Vb = VT + (int64_t)b * vt_bs + (int64_t)h * DV * Nk_pad;
     const uint4 ones = make_uint4(ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2, ONEDC_A16_ONE2);
 
     uint4 kreg[C::NKL], vreg[C::NVL];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const a16_t *__restrict
             const int row = c / C::KCH, ch = c - row * C::KCH;
             kreg[i] = make_uint4(0, 0, 0, 0);
             if ((C::KCHUNKS % 256 == 0 || c < C::KCHUNKS) && k0 + row < Nk)
-                kreg[i] = *(const uint4 *)(Kb + (int64_t)(k0 + row) * (H * DQ) + ch * 8);
+                kreg[i] = *(const uint4 *)(Kb + (int64_t)(k0 + row) * k_rs + ch * 8);
         }
 #pragma unroll
         for (int i = 0; i < C::NVL; ++i) {
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
                                                               const a16_t *__restrict__ K,
                                                               const a16_t *__restrict__ VT,
                                                               a16_t *__restrict__ O, int H, int Nq, int Nk,
-                                                              int Nk_pad, float scale_log2e, int d_real) {
+                                                              int Nk_pad, float scale_log2e, int d_real, int q_rs, int k_rs,
+                                                              int64_t vt_bs) {
     constexpr int DQ = 64, DV = 48, QT = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
         for (int ks = 0; ks < 2; ++ks) {
             union { a16x8 v; uint32_t u[4]; } f;
             f.v = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
+            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * q_rs + h * DQ + ks * 32 + g * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 f.u[e] = pack_a2(a2f((a16_t)(f.u[e] & 0xffff)) * scale_log2e, a2f((a16_t)(f.u[e] >> 16)) * scale_log2e);
@@ -358,9 +360,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
     // ---- DMA geometry: 14 blocks of 8 LDS rows per tile: K blocks 0..7 (two per wave), V^T blocks 0..5
     // (waves 0, 1: two; waves 2, 3: one).  lane -> (row in block, 16-byte chunk)
     const int lrow = lane >> 3, lch = lane & 7;
-    const char *Kb = (const char *)(K + (int64_t)b * Nk * (H * DQ) + h * DQ);
-    const char *Vb = (const char *)(VT + ((int64_t)b * H + h) * DV * Nk_pad);
-    const int64_t krow_bytes = (int64_t)H * DQ * 2;
+    const char *Kb = (const char *)(K + (int64_t)b * Nk * k_rs + h * DQ);
+    const char *Vb = (const char *)(VT + (int64_t)b * vt_bs + (int64_t)h * DV * Nk_pad);
+    const int64_t krow_bytes = (int64_t)k_rs * 2;
     const int64_t vrow_bytes = (int64_t)Nk_pad * 2;
     int krow[2], kchunk[2];
 #pragma unroll
@@ -595,7 +597,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
                                                               const a16_t *__restrict__ K,
                                                               const a16_t *__restrict__ VT,
                                                               a16_t *__restrict__ O, int H, int Nq, int Nk,
-                                                              int Nk_pad, float scale_log2e, int d_real) {
+                                                              int Nk_pad, float scale_log2e, int d_real, int q_rs, int k_rs,
+                                                              int64_t vt_bs) {
     constexpr int DQ = 128, DV = 96, QT = 2;   // two half-heads of (64, 48): dims 0..39 | pad | 40..79 | pad
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
         for (int ks = 0; ks < 4; ++ks) {
             union { a16x8 v; uint32_t u[4]; } f;
             f.v = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * (H * DQ) + h * DQ + ks * 32 + g * 8);
+            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * q_rs + h * DQ + ks * 32 + g * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 f.u[e] = pack_a2(a2f((a16_t)(f.u[e] & 0xffff)) * scale_log2e, a2f((a16_t)(f.u[e] >> 16)) * scale_log2e);
@@ -638,9 +641,9 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
     // ---- DMA geometry: a stage is [K half 0 | K half 1 | V^T half 0 | V^T half 1] = 28 blocks of 8 LDS rows: wave w moves
     // K rows 8 w .. of both halves, V^T block w and (w < 4) block w + 8 (block vb: half vb / 6, rows 8 (vb % 6) ..)
     const int lrow = lane >> 3, lch = lane & 7;
-    const char *Kb = (const char *)(K + (int64_t)b * Nk * (H * DQ) + h * DQ);
-    const char *Vb = (const char *)(VT + ((int64_t)b * H + h) * DV * Nk_pad);
-    const int64_t krow_bytes = (int64_t)H * DQ * 2;
+    const char *Kb = (const char *)(K + (int64_t)b * Nk * k_rs + h * DQ);
+    const char *Vb = (const char *)(VT + (int64_t)b * vt_bs + (int64_t)h * DV * Nk_pad);
+    const int64_t krow_bytes = (int64_t)k_rs * 2;
     const int64_t vrow_bytes = (int64_t)Nk_pad * 2;
     const int krow = wave * 8 + lrow;                                         // key row inside the tile
     const int kchunk = lch ^ ((krow & 3) | (((krow >> 3) & 1) << 2));
@@ -864,28 +867,36 @@ extern "C" int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk) {
     return ((DQ == 64 && DV == 48) || (DQ == 128 && DV == 96)) && Nk >= 64;
 }
 
-extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
-                                int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream) {
+// q_rs / k_rs: elements between consecutive query / key rows (>= H * DQ: q and k may be column slices of one wider
+// projection output, e.g. a fused [q | k] GEMM); vt_bs: elements between the V^T blocks of consecutive images (>= H * DV *
+// Nk_pad: the V^T of several layers that share one context can come out of ONE batched GEMM).  0 = dense.
+extern "C" int onedc_flash_attn_strided(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
+                                        int Nk, int Nk_pad, int DQ, int DV, float scale, int q_rs, int k_rs,
+                                        int64_t vt_bs, void *stream) {
     if (!q || !k || !vt || !o || B < 1 || H < 1 || Nq < 1 || Nk < 1) return -1;
     if (Nk_pad < ((Nk + 63) / 64) * 64 || (Nk_pad & 7)) return -2;
+    if (q_rs == 0) q_rs = H * DQ;
+    if (k_rs == 0) k_rs = H * DQ;
+    if (vt_bs == 0) vt_bs = (int64_t)H * DV * Nk_pad;
+    if (q_rs < H * DQ || k_rs < H * DQ || vt_bs < (int64_t)H * DV * Nk_pad || (q_rs & 7) || (k_rs & 7) || (vt_bs & 7)) return -4;
     dim3 grid((Nq + 127) / 128, H, B), block(256);
     hipStream_t st = as_stream(stream);
     const float c = scale * 1.4426950408889634f;
 #define FA_LAUNCH(dq, dv, ones, pre, dreal)                                                                   \
     hipLaunchKernelGGL((flash_attn_kernel<dq, dv, ones, pre>), grid, block, 0, st, (const a16_t *)q,          \
-                       (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c, dreal)
+                       (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c, dreal, q_rs, k_rs, vt_bs)
     if (DQ == 64 && DV == 48 && Nk >= 64) {
         static OnedcLdsAttrOnce once;
         once.ensure({{(const void *)flash_attn64_kernel, FA64_NST * FA64_STAGE}});
         hipLaunchKernelGGL(flash_attn64_kernel, dim3(((Nq + 255) / 256) * H * B), block, FA64_NST * FA64_STAGE, st,
                            (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
-                           40);
+                           40, q_rs, k_rs, vt_bs);
     } else if (DQ == 128 && DV == 96 && Nk >= 64) {
         static OnedcLdsAttrOnce once;
         once.ensure({{(const void *)flash_attn80_kernel, FA64_NST * FA80_STAGE}});
         hipLaunchKernelGGL(flash_attn80_kernel, dim3(((Nq + 255) / 256) * H * B), dim3(512), FA64_NST * FA80_STAGE, st,
                            (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
-                           40);
+                           40, q_rs, k_rs, vt_bs);
     } else if (DQ == 64 && DV == 48) FA_LAUNCH(64, 48, true, true, 40);
     else if (DQ == 128 && DV == 96) FA_LAUNCH(128, 96, false, true, 80);      // (fewer than 64 keys; pad dims are zeros)
     else if (DQ == 160 && DV == 160) FA_LAUNCH(160, 160, false, false, 160);
@@ -894,4 +905,9 @@ extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, vo
 #undef FA_LAUNCH
     ONEDC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
+                                int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream) {
+    return onedc_flash_attn_strided(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale, 0, 0, 0, stream);
 }

@@ -273,6 +273,55 @@ __global__ void window_partition_kernel(const a16_t *x, a16_t *y, int B, int H, 
     }
 }
 
+// ---- MXFP8 experiment ------------------------------------------------------------------------------------
+// What v_mfma_scale_f32_16x16x128_f8f6f4 would consume, made visible to the 16-bit kernels: every block of 32 consecutive
+// channels of a pixel (= 32 consecutive k of a conv's GEMM: k = (ky, kx, cin)) is quantised to OCP e4m3 (4-bit significand,
+// exponents -6 .. 8, subnormal step 2^-9, saturating at 448) with ONE shared power-of-two scale 2^(floor(log2 amax) - 8)
+// (OCP MX v1.0), and written back dequantised.  q * 2^e is exact in either 16-bit format, an MFMA on these operands forms the
+// same exact products the block-scaled instruction forms, and both accumulate in f32: the ACCURACY of an MXFP8 layer is
+// measured on hardware without its kernel (tests/test_gpu_fullsize.py::test_mxfp8_*).  One thread per (pixel, block).
+__device__ __forceinline__ float e4m3_round(float v) {
+    float a = fminf(fabsf(v), 448.f);
+    int ex = (int)(__float_as_uint(a) >> 23) - 127;
+    ex = ex < -6 ? -6 : ex;
+    const float q = __uint_as_float((uint32_t)(ex - 3 + 127) << 23);          // spacing of e4m3 at this magnitude
+    a = fminf(rintf(a / q) * q, 448.f);                                        // exact division, round half to even
+    return copysignf(a, v);
+}
+
+__global__ void mxfp8_roundtrip_kernel(const a16_t *x, a16_t *y, int64_t pixels, int C, int x_cs, int x_co, int y_cs,
+                                       int y_co) {
+    const int nb = C >> 5;
+    const int64_t total = pixels * nb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / nb;
+        const int b = (int)(i - pix * nb);
+        const uint4 *src = (const uint4 *)(x + pix * x_cs + x_co + b * 32);
+        uint4 *dst = (uint4 *)(y + pix * y_cs + y_co + b * 32);
+        uint4 v[4];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = src[j];
+            const uint32_t *w = (const uint32_t *)&v[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a2f_lo(w[e])), fabsf(a2f_hi(w[e]))));
+        }
+        int es = (int)(__float_as_uint(amax) >> 23) - 127 - 8;                 // floor(log2 amax) - emax(e4m3)
+        es = amax > 0.f ? (es < -126 ? -126 : es) : 0;
+        const float scale = __uint_as_float((uint32_t)(es + 127) << 23), inv = __uint_as_float((uint32_t)(127 - es) << 23);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t *w = (uint32_t *)&v[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = pack_a2(e4m3_round(a2f_lo(w[e]) * inv) * scale, e4m3_round(a2f_hi(w[e]) * inv) * scale);
+            dst[j] = v[j];
+        }
+    }
+}
+
 __global__ void timestep_embedding_kernel(const float *t, float *emb, int n, int dim) {
     const int half = dim >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -537,6 +586,14 @@ int onedc_window_partition(const void *x, void *y, int B, int H, int W, int C, i
     if (y0 < 0 || x0 < 0 || y0 + RH > H || x0 + RW > W) return -2;
     const int64_t n = (int64_t)B * RH * RW * (C / 8);
     LAUNCH(window_partition_kernel, n, (const a16_t *)x, (a16_t *)y, B, H, W, C, y0, x0, RH, RW, wh, ww, reverse);
+    return 0;
+}
+
+int onedc_mxfp8_roundtrip(const void *x, void *y, int64_t pixels, int C, int x_cs, int x_co, int y_cs, int y_co,
+                          void *stream) {
+    if (!x || !y || (C & 31) || ((x_cs | x_co | y_cs | y_co) & 7)) return -1;
+    const int64_t n = pixels * (C / 32);
+    LAUNCH(mxfp8_roundtrip_kernel, n, (const a16_t *)x, (a16_t *)y, pixels, C, x_cs, x_co, y_cs, y_co);
     return 0;
 }
 

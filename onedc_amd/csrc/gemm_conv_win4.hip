@@ -79,6 +79,16 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;        // channel half, pixel half (patch rows 8 wc ..)
+#ifdef EXP_W4_STAGGER
+    // (experiment) The first round of workgroups starts within a few microseconds on every CU and all tiles of a layer
+    // take the same time: the CUs run in lockstep and their epilogues (64 KB of stores each) hit the memory system as one
+    // burst.  Delay the first-round workgroups of CU group q by q / EXP_W4_STAGGER of a tile time, once per launch.
+    if (blockIdx.x < 2 * 256) {
+        const int q = (blockIdx.x >> 3) % EXP_W4_STAGGER;
+        const int cyc = q * ((Ktot >> 5) * 1100 + 15000) / EXP_W4_STAGGER;
+        for (int i = 0; i < (cyc >> 12); ++i) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
 
     // ---- patch of this workgroup (same order as the 8-wave kernel: channel tile fastest, bands of four patch rows) ----
     const int tiles_pi = tiles_x * tiles_y;

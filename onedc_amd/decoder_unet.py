@@ -12,7 +12,7 @@ import torch
 from . import arch, pack
 from . import kernels as K
 from .kernels import View, new_view
-from .layers import (Conv, GroupNorm, ResnetBlock2D, Transformer2D, Workspace, silu_cpu,
+from .layers import (ContextKV, Conv, GroupNorm, ResnetBlock2D, Transformer2D, Workspace, silu_cpu,
                      timestep_embedding_cpu)
 
 
@@ -63,6 +63,10 @@ class UNet:
         self.norm_out = GroupNorm(sd, "conv_norm_out", device, 1e-5)
         self.conv_out = Conv(sd, "conv_out", device)
         self._timestep = None
+        # the 16 cross-attention layers read one context: their to_k / to_v run as three GEMMs per step (layers.ContextKV)
+        self._transformers = [t for blk in self.down if blk["attn"] for t in blk["attn"]] + [self.mid_attn] + \
+                             [t for blk in self.up if blk["attn"] for t in blk["attn"]]
+        self.ctx_kv = ContextKV([t.attn2 for t in self._transformers], device)
 
     def _all_resnets(self):
         for blk in self.down:
@@ -93,6 +97,7 @@ class UNet:
         ws, dev = self.ws, self.device
         B = sample.B
         reduced = self.vae_reduction(sample, ws)
+        kv = {id(t): v for t, v in zip(self._transformers, self.ctx_kv(ctx, ws))}
 
         # Skip tensors are written straight into the channel tail of the buffer the matching up
         # resnet will read (torch.cat([h, skip]) in diffusers), so plan those buffers first.
@@ -132,7 +137,7 @@ class UNet:
             for j in range(2):
                 if blk["attn"] is not None:
                     h = blk["res"][j](h, ws)
-                    h = blk["attn"][j](h, ctx, ws, skip_slot(si))
+                    h = blk["attn"][j](h, ctx, ws, skip_slot(si), kv=kv[id(blk["attn"][j])])
                 else:
                     h = blk["res"][j](h, ws, skip_slot(si))
                 si += 1
@@ -141,7 +146,7 @@ class UNet:
                 si += 1
 
         h = self.mid_res[0](h, ws)
-        h = self.mid_attn(h, ctx, ws)
+        h = self.mid_attn(h, ctx, ws, kv=kv[id(self.mid_attn)])
         # the first up resnet reads cat(h, skip): h must land in the head of that buffer
         nxt = order[0]
         h = self.mid_res[1](h, ws, head_slot(nxt))
@@ -161,7 +166,7 @@ class UNet:
                     dst = head_slot(order[oi])
                 if blk["attn"] is not None:
                     h = blk["res"][j](cat, ws)
-                    h = blk["attn"][j](h, ctx, ws, dst)
+                    h = blk["attn"][j](h, ctx, ws, dst, kv=kv[id(blk["attn"][j])])
                 else:
                     h = blk["res"][j](cat, ws, dst)
             if blk["up"] is not None:

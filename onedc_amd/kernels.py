@@ -105,6 +105,7 @@ SIGNATURES = {
     "onedc_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "onedc_softmax_rows": (_I, [_P, _P, _L, _I, _I, _P]),
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_flash_attn_strided": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _L, _P]),
     "onedc_flash_attn_vt_is_bf16": (_I, [_I, _I, _I]),
     "onedc_fsq_codes": (_I, [_P, _P, _L, _P]),
     "onedc_fsq_quantize": (_I, [_P, _I, _I, _I, _P, _L, _P]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "onedc_copy_channels": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
     "onedc_window_partition": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
+    "onedc_mxfp8_roundtrip": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
     "onedc_hip_version": (C.c_char_p, []),
     "onedc_hip_act_format": (C.c_char_p, []),
@@ -130,15 +132,19 @@ HIP_SYMBOLS = list(SIGNATURES)
 _libs = {}
 
 
+def attach_signatures(l):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+    return l
+
+
 def lib(fmt=None):
     fmt = fmt or act()
     l = _libs.get(fmt)
     if l is None:
-        l = _native.hip(fmt)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
-            fn.restype = res
-            fn.argtypes = args
+        l = attach_signatures(_native.hip(fmt))
         check_library_format(fmt, l.onedc_hip_act_format(), l.onedc_hip_version())
         _libs[fmt] = l
     return l
@@ -440,11 +446,13 @@ def flash_vt_dtype(DQ, DV, Nk):
     return torch.bfloat16 if lib().onedc_flash_attn_vt_is_bf16(DQ, DV, Nk) else a16()
 
 
-def flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale):
+def flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale, q_rs=0, k_rs=0, vt_bs=0):
+    """q_rs / k_rs: elements between consecutive query / key rows when q / k are column slices of a wider buffer (0: dense,
+    H * DQ); vt_bs: elements between the V^T blocks of consecutive images (0: dense, H * DV * Nk_pad)."""
     if vt.dtype != flash_vt_dtype(DQ, DV, Nk):
         raise KernelError(f"flash_attn: V^T must be {flash_vt_dtype(DQ, DV, Nk)} for DQ={DQ}, DV={DV}, Nk={Nk}, not {vt.dtype}")
-    _ok(lib().onedc_flash_attn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, Nq, Nk, Nk_pad,
-                               DQ, DV, scale, stream()), "onedc_flash_attn")
+    _ok(lib().onedc_flash_attn_strided(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, Nq, Nk, Nk_pad,
+                                       DQ, DV, scale, q_rs, k_rs, vt_bs, stream()), "onedc_flash_attn_strided")
     return o
 
 
@@ -536,6 +544,14 @@ def window_partition(x, y, B, H, W, Cc, win, reverse=False, region=None, win_hw=
     wh, ww = win_hw or (win, win)
     _ok(lib().onedc_window_partition(x.data_ptr(), y.data_ptr(), B, H, W, Cc, y0, x0, RH, RW, wh, ww,
                                      int(reverse), stream()), "onedc_window_partition")
+    return y
+
+
+def mxfp8_roundtrip(x, y):
+    """x, y: 16-bit Views of one shape: y = x quantised to MXFP8 (e4m3, one power-of-two scale per 32 channels of a pixel)
+    and dequantised again."""
+    _ok(lib().onedc_mxfp8_roundtrip(x.ptr, y.ptr, x.B * x.H * x.W, x.C, x.cs, x.co, y.cs, y.co, stream()),
+        "onedc_mxfp8_roundtrip")
     return y
 
 

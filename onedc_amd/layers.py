@@ -39,6 +39,17 @@ class Workspace:
     def bf16(self, name, n):
         return self._get(name, n, K.a16())
 
+    def zeros(self, name, n, dtype):
+        """A buffer that is zero when it is made and never re-zeroed: for tensors whose writers always touch the SAME
+        positions and whose other positions must read as zero (the padding keys of V^T).  The caller puts everything that
+        decides the layout into `name`, so a buffer is never shared between two layouts."""
+        key = (torch.cuda.current_stream(self.device).cuda_stream, name)
+        t = self._t.get(key)
+        if t is None or t.numel() != n or t.dtype != dtype:
+            t = torch.zeros(max(n, 1), dtype=dtype, device=self.device)
+            self._t[key] = t
+        return t
+
 
 USE_UPSAMPLE_PHASES = True    # tests switch it off to compare with the plain fused-upsample path
 
@@ -67,6 +78,20 @@ class Conv:
         self.w_ups = None
         if upsample and self.k == 3 and self.cout % 128 == 0 and self.cin % 64 == 0 and not f32:
             self.w_ups = pack.pack_matrix(pack.upsample_phase_matrix(w), device)
+        self.mxfp8 = False
+        self._mx_src = (m, perm, device) if (not f32 and not glu and not shuffle and self.cin % 32 == 0) else None
+
+    def set_mxfp8(self, on=True):
+        """MXFP8 experiment: the layer computes on operands quantised to e4m3 with one power-of-two scale per
+        32 along K -- the weights once, here; the activations per call (kernels.mxfp8_roundtrip) -- through the SAME 16-bit
+        kernel: the values, products and f32 accumulation of a block-scaled fp8 MFMA layer, without its speed."""
+        if on and self._mx_src is None:
+            raise ValueError("this layer has no MXFP8 form (f32 path, GLU / pixel-shuffle rows, or Cin % 32 != 0)")
+        if on and not hasattr(self, "w_mx"):
+            m, perm, device = self._mx_src
+            self.w_mx = pack.pack_matrix(pack.mxfp8_roundtrip(m), device, perm)
+        self.mxfp8 = bool(on)
+        return self
 
     def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
                  alpha=1.0, stats=False, pad=None, gn=None):
@@ -90,6 +115,14 @@ class Conv:
             y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else K.a16())
         if stats:
             y.want_stats()
+        if self.mxfp8:
+            if gn is not None:                     # the NORMALISED tensor is the operand: its own pass, then quantise
+                x = gn[0](x, gn[1], gn[2])
+                gn = None
+            xq = K.mxfp8_roundtrip(x, new_view(x.B, x.H, x.W, x.C, x.t.device))
+            return K.conv_gemm(xq, self.w_mx, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
+                               alpha=alpha, res=res, Cin=self.cin, Cout=self.cout, flop_scale=self.flop_scale, stats=stats,
+                               pad=pad)
         if (up and self.w_ups is not None and USE_UPSAMPLE_PHASES and res is None and x.H % 16 == 0 and
                 x.W % 16 == 0 and not y.f32 and y.cs % 8 == 0 and y.co % 8 == 0 and
                 epi in (EPI_LINEAR, EPI_LEAKY, EPI_SILU)):
@@ -185,7 +218,7 @@ class SingleHeadAttention:
         self.out_scale = s
         self.o.b = (self.o.b * s).contiguous()
 
-    def __call__(self, hn, res, n, y=None):
+    def __call__(self, hn, res, n, y=None, ws=None):
         """hn: normalised tokens View with B groups of n = H*W tokens; res: residual View."""
         dev, C, G = hn.t.device, self.C, hn.B
         n_pad = (n + 63) // 64 * 64
@@ -193,8 +226,14 @@ class SingleHeadAttention:
         q = self.q(hn)
         k = self.k(hn)
         kbuf = k.t
-        # V^T per group: [C][n_pad], zero padded keys
-        vt = torch.zeros(G * C * n_pad, dtype=K.a16(), device=dev)
+        # V^T per group: [C][n_pad], zero padded keys (a workspace buffer of exactly this layout is zeroed once: the GEMM
+        # below only ever writes the n real keys)
+        if n == n_pad:
+            vt = torch.empty(G * C * n_pad, dtype=K.a16(), device=dev)
+        elif ws is not None:
+            vt = ws.zeros(f"sha_vt_{G}_{C}_{n}", G * C * n_pad, K.a16())
+        else:
+            vt = torch.zeros(G * C * n_pad, dtype=K.a16(), device=dev)
         hn_flat = hn
         K.conv_gemm(self.wv, hn_flat.t, None, View(vt, 1, 1, C, n, n_pad), Cin=C, Cout=n, batch=G,
                     x_bs=0, w_bs=n * C, y_bs=C * n_pad)
@@ -215,7 +254,7 @@ class VQAttnBlock:
         self.attn = SingleHeadAttention(sd, (f"{p}.q", f"{p}.k", f"{p}.v", f"{p}.proj_out"), device, C)
 
     def __call__(self, x, ws, y=None):
-        return self.attn(self.norm(x, ws, False), x, x.H * x.W, y)
+        return self.attn(self.norm(x, ws, False), x, x.H * x.W, y, ws)
 
 
 class ResnetBlock2D:
@@ -257,37 +296,128 @@ class ResnetBlock2D:
 
 
 class MultiHeadAttention:
-    """diffusers Attention (8 heads) on flash attention; projections zero-pad the head dim."""
+    """diffusers Attention (8 heads) on flash attention; projections zero-pad the head dim.
 
-    def __init__(self, sd, p, device, C, ctx_dim, heads=8):
+    Self-attention (`ctx_dim == C`, keys = queries): to_q and to_k are ONE GEMM whose output rows are [q | k]
+    (`onedc_flash_attn_strided` reads both as column slices of it).  Cross-attention: K and V^T depend on the context only,
+    which all 16 transformer blocks of the UNet share -- `ContextKV` projects it for all of them in one K GEMM and one or
+    two V^T GEMMs per UNet call, and this layer is handed its slices (`kv`)."""
+
+    def __init__(self, sd, p, device, C, ctx_dim, heads=8, self_attention=None):
         d = C // heads
         self.H, self.d = heads, d
         self.DQ, self.DV = pack.HEAD_PAD[d]
         self.C, self.ctx_dim = C, ctx_dim
-        self.q = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_q.weight"], heads, d, self.DQ),
-                      flop_scale=d / self.DQ)
-        self.k = Conv(sd, "", device, weight=pack.pad_heads_rows(sd[f"{p}.to_k.weight"], heads, d, self.DQ),
-                      flop_scale=d / self.DQ)
-        wv = pack.pad_heads_rows(sd[f"{p}.to_v.weight"], heads, d, self.DV)
-        self.wv = View(pack.pack_matrix(wv, device), 1, 1, heads * self.DV, ctx_dim)
+        self.self_attention = (ctx_dim == C) if self_attention is None else self_attention
+        wq = pack.pad_heads_rows(sd[f"{p}.to_q.weight"], heads, d, self.DQ)
+        self.wk_rows = pack.pad_heads_rows(sd[f"{p}.to_k.weight"], heads, d, self.DQ)      # (kept on the host for ContextKV)
+        self.wv_rows = pack.pad_heads_rows(sd[f"{p}.to_v.weight"], heads, d, self.DV)
+        if self.self_attention:
+            self.qk = Conv(sd, "", device, weight=torch.cat([wq, self.wk_rows], 0), flop_scale=d / self.DQ)
+            self.wv = View(pack.pack_matrix(self.wv_rows, device), 1, 1, heads * self.DV, ctx_dim)
+            self.wk_rows = self.wv_rows = None
+        else:
+            self.q = Conv(sd, "", device, weight=wq, flop_scale=d / self.DQ)
         self.o = Conv(sd, "", device, weight=pack.pad_heads_cols(sd[f"{p}.to_out.0.weight"], heads, d, self.DV),
                       bias=sd[f"{p}.to_out.0.bias"], flop_scale=d / self.DV)
 
-    def __call__(self, x, ctx, res, y=None):
-        """x: query tokens View (B, H, W, C); ctx: key/value tokens View; res: residual."""
+    def __call__(self, x, ctx, res, y=None, ws=None, kv=None):
+        """x: query tokens View (B, H, W, C); ctx: key/value tokens View; res: residual.
+        kv = (k tensor, k row stride, V^T tensor, V^T image stride) from ContextKV (cross-attention)."""
         dev = x.t.device
         B, Nq, Nk = x.B, x.H * x.W, ctx.H * ctx.W
         Nk_pad = (Nk + 63) // 64 * 64
-        q = self.q(x)
-        k = self.k(ctx)
-        vt_dtype = K.flash_vt_dtype(self.DQ, self.DV, Nk)
-        vt = torch.zeros(B * self.H * self.DV * Nk_pad, dtype=vt_dtype, device=dev)
-        K.conv_gemm(self.wv, ctx.t, None, View(vt, 1, 1, self.H * self.DV, Nk, Nk_pad), Cin=self.ctx_dim,
-                    Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=self.H * self.DV * Nk_pad,
-                    flop_scale=self.d / self.DV, out_bf16=(vt_dtype == torch.bfloat16))
-        o = new_view(x.B, x.H, x.W, self.H * self.DV, dev)
-        K.flash_attn(q.t, k.t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, self.DQ, self.DV, self.d ** -0.5)
+        HDQ, HDV = self.H * self.DQ, self.H * self.DV
+        if self.self_attention:
+            qk = self.qk(x)                                          # rows [q (H DQ) | k (H DQ)]
+            q_t, k_t, q_rs, k_rs = qk.t, qk.t[HDQ:], 2 * HDQ, 2 * HDQ
+            vt_dtype = K.flash_vt_dtype(self.DQ, self.DV, Nk)
+            n = B * HDV * Nk_pad
+            if Nk == Nk_pad:
+                vt = torch.empty(n, dtype=vt_dtype, device=dev)
+            elif ws is not None:                                     # zero padding keys: zeroed once per layout
+                vt = ws.zeros(f"mha_vt_{B}_{HDV}_{Nk}_{vt_dtype}", n, vt_dtype)
+            else:
+                vt = torch.zeros(n, dtype=vt_dtype, device=dev)
+            K.conv_gemm(self.wv, ctx.t, None, View(vt, 1, 1, HDV, Nk, Nk_pad), Cin=self.ctx_dim,
+                        Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=HDV * Nk_pad,
+                        flop_scale=self.d / self.DV, out_bf16=(vt_dtype == torch.bfloat16))
+            vt_bs = 0
+        else:
+            if kv is None:
+                kv = ContextKV([self], dev)(ctx, ws)[0]
+            k_t, k_rs, vt, vt_bs = kv
+            q = self.q(x)
+            q_t, q_rs = q.t, HDQ
+        o = new_view(x.B, x.H, x.W, HDV, dev)
+        K.flash_attn(q_t, k_t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, self.DQ, self.DV, self.d ** -0.5,
+                     q_rs=q_rs, k_rs=k_rs, vt_bs=vt_bs)
         return self.o(o, y, res=res)
+
+
+class ContextKV:
+    """to_k / to_v of every cross-attention layer that reads ONE context (the UNet's 16 transformer blocks all attend to
+    y_semantic: reference decoder_unet.py:204-293 passes the same `encoder_hidden_states` down): K of all layers is one GEMM
+    [tokens][sum H DQ], V^T of all layers one batched GEMM [image][sum H DV][keys] (two in the IEEE-half build when the
+    d = 40 / 80 kernels take their V^T as bf16 and the d = 160 kernel as f16) -- 3 launches per UNet step instead of 32."""
+
+    def __init__(self, layers, device):
+        # V^T rows: the layers whose kernel may want bf16 V^T first (head dims 40, 80), so that each dtype is one row range
+        self.layers = list(layers)
+        order = sorted(range(len(self.layers)), key=lambda i: (self.layers[i].d >= 160, i))
+        self.ctx_dim = self.layers[0].ctx_dim
+        wk, wv, self.k_off, self.v_off = [], [], {}, {}
+        ko = vo = 0
+        real = padded = 0
+        for i in order:
+            l = self.layers[i]
+            wk.append(l.wk_rows)
+            wv.append(l.wv_rows)
+            self.k_off[i], self.v_off[i] = ko, vo
+            ko += l.H * l.DQ
+            vo += l.H * l.DV
+            real += l.H * l.d
+            padded += l.H * l.DQ
+        self.k_cols, self.v_rows = ko, vo
+        self.v_split = sum(l.H * l.DV for l in self.layers if l.d < 160)           # rows [0, v_split): head dims 40 / 80
+        self.k = Conv({}, "", device, weight=torch.cat(wk, 0), flop_scale=real / padded)
+        self.wv = View(pack.pack_matrix(torch.cat(wv, 0), device), 1, 1, vo, self.ctx_dim)
+        self.v_scale = sum(l.H * l.d for l in self.layers) / vo
+        for l in self.layers:
+            l.wk_rows = l.wv_rows = None                                           # packed: drop the host copies
+
+    def __call__(self, ctx, ws=None):
+        """-> per layer (k tensor, k row stride, V^T tensor, V^T image stride), in the order the layers were given."""
+        dev = ctx.t.device
+        B, Nk = ctx.B, ctx.H * ctx.W
+        Nk_pad = (Nk + 63) // 64 * 64
+        k = self.k(ctx)                                             # (B, h, w, sum H DQ)
+        small = [l for l in self.layers if l.d < 160]
+        bf16_rows = self.v_split if small and K.flash_vt_dtype(small[0].DQ, small[0].DV, Nk) == torch.bfloat16 else 0
+        if K.a16() == torch.bfloat16:
+            bf16_rows = 0                                           # one format anyway
+        # ONE buffer of 16-bit words for all layers (bf16 and f16 are both 2 bytes: the row ranges are written as what
+        # their readers expect)
+        n = B * self.v_rows * Nk_pad
+        if Nk == Nk_pad:
+            vt = torch.empty(n, dtype=K.a16(), device=dev)
+        elif ws is not None:
+            vt = ws.zeros(f"ctx_vt_{B}_{self.v_rows}_{Nk}", n, K.a16())
+        else:
+            vt = torch.zeros(n, dtype=K.a16(), device=dev)
+        vt_bs = self.v_rows * Nk_pad
+        for r0, r1, as_bf16 in ((0, bf16_rows, True), (bf16_rows, self.v_rows, False)):
+            if r1 > r0:
+                K.conv_gemm(View(self.wv.t.view(-1)[r0 * self.ctx_dim:], 1, 1, r1 - r0, self.ctx_dim), ctx.t, None,
+                            View(vt[r0 * Nk_pad:], 1, 1, r1 - r0, Nk, Nk_pad), Cin=self.ctx_dim, Cout=Nk, batch=B, x_bs=0,
+                            w_bs=Nk * ctx.cs, y_bs=vt_bs, flop_scale=self.v_scale, out_bf16=as_bf16)
+        out = []
+        for i, l in enumerate(self.layers):
+            vt_l = vt[self.v_off[i] * Nk_pad:]
+            if self.v_off[i] < bf16_rows:
+                vt_l = vt_l.view(torch.bfloat16)                    # same bytes, the dtype its kernel asks for
+            out.append((k.t[self.k_off[i]:], self.k_cols, vt_l, vt_bs))
+        return out
 
 
 class LayerNorm:
@@ -309,17 +439,18 @@ class Transformer2D:
         self.norm = GroupNorm(sd, f"{p}.norm", device, 1e-6)
         self.proj_in = Conv(sd, f"{p}.proj_in", device)
         self.n1, self.n2, self.n3 = (LayerNorm(sd, f"{t}.norm{i}", device) for i in (1, 2, 3))
-        self.attn1 = MultiHeadAttention(sd, f"{t}.attn1", device, C, C)
-        self.attn2 = MultiHeadAttention(sd, f"{t}.attn2", device, C, ctx_dim)
+        self.attn1 = MultiHeadAttention(sd, f"{t}.attn1", device, C, C, self_attention=True)
+        self.attn2 = MultiHeadAttention(sd, f"{t}.attn2", device, C, ctx_dim, self_attention=False)
         self.ff1 = Conv(sd, f"{t}.ff.net.0.proj", device, glu=True)
         self.ff2 = Conv(sd, f"{t}.ff.net.2", device)
         self.proj_out = Conv(sd, f"{p}.proj_out", device)
 
-    def __call__(self, x, ctx, ws, y=None):
+    def __call__(self, x, ctx, ws, y=None, kv=None):
+        """kv: this block's slices of the shared context projections (ContextKV), or None to project here."""
         h = self.proj_in(self.norm(x, ws, False))
         n = self.n1(h)
-        h = self.attn1(n, n, h)
-        h = self.attn2(self.n2(h), ctx, h)
+        h = self.attn1(n, n, h, ws=ws)
+        h = self.attn2(self.n2(h), ctx, h, ws=ws, kv=kv)
         f = self.ff1(self.n3(h), epi=EPI_GEGLU)
         h = self.ff2(f, res=h)
         return self.proj_out(h, y, res=x, stats=True)

@@ -77,6 +77,20 @@ def upsample_phase_matrix(w):
     return out.reshape(4 * C, 4 * Cin)
 
 
+def mxfp8_roundtrip(m, block=32):
+    """[rows][K] f32 -> the same matrix with every block of 32 consecutive k quantised to OCP e4m3 under one shared
+    power-of-two scale 2^(floor(log2 amax) - 8) (OCP MX v1.0) and dequantised again: the weight operand of an MXFP8 layer
+    (csrc/elementwise.hip: mxfp8_roundtrip_kernel does the same to the activations)."""
+    rows, Kk = m.shape
+    assert Kk % block == 0
+    b = m.float().reshape(rows, Kk // block, block)
+    amax = b.abs().amax(-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp_min(2.0 ** -126))) - 8
+    scale = torch.where(amax > 0, torch.exp2(e), torch.ones_like(amax))
+    q = (b / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return (q * scale).reshape(rows, Kk)
+
+
 def glu_perm(n_half):
     """Row order for GLU epilogues: [v0..v15, g0..g15, v16..v31, g16..g31, ...]."""
     assert n_half % 16 == 0

@@ -60,6 +60,28 @@ class VAEDecoder:
         self.norm_out = GroupNorm(sd, "decoder.conv_norm_out", device, 1e-6 * s * s)
         self.conv_out = Conv(sd, "decoder.conv_out", device)
 
+    MXFP8_GROUPS = ("mid", "up0", "up1", "up2", "up3")
+
+    def set_mxfp8(self, groups=()):
+        """MXFP8 experiment: run the 3x3 convs of the named parts of the decoder -- "mid" (two resnets, 96^2 at
+        768x768), "up0" .. "up3" (three resnets + the upsampler conv each: 96^2, 192^2, 384^2, 768^2) -- on MXFP8-quantised
+        operands (layers.Conv.set_mxfp8).  () switches it off again.  Off by default: DESIGN.md section 5 has the measured
+        cost in dB."""
+        groups = set(groups)
+        unknown = groups - set(self.MXFP8_GROUPS)
+        if unknown:
+            raise ValueError(f"unknown decoder parts {sorted(unknown)} (known: {self.MXFP8_GROUPS})")
+        parts = {"mid": [(r, None) for r in self.mid_res]}
+        for i, blk in enumerate(self.up):
+            parts[f"up{i}"] = [(r, None) for r in blk["res"]] + ([(None, blk["up"])] if blk["up"] is not None else [])
+        for name, items in parts.items():
+            on = name in groups
+            for r, c in items:
+                for conv in ((r.c1, r.c2) if r is not None else (c,)):
+                    conv.set_mxfp8(on)
+        self.mxfp8_groups = tuple(sorted(groups))
+        return self
+
     def set_attn_patch(self, attn_patch):
         assert attn_patch > 0, "attn_patch must be greater than 0"
         self.attn_patch = attn_patch

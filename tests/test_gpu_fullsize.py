@@ -170,6 +170,40 @@ def test_fullsize_delta_psnr_within_north_star(request, regime):
                 assert d <= TOL_DELTA_PSNR_DB, (level, b, d)
 
 
+def test_mxfp8_vae_layers_cost_measured(model_trained, fullsize_pair_trained):
+    """SURVEY 8 f-4, measured on hardware at the trained-like operating point: the VAE decoder's 512-channel layers (mid block
+    and up blocks 0 / 1: 96^2 and 192^2 maps at 768x768, 29 % of the decode FLOPs, the layers that are MFMA-bound) computed
+    on MXFP8 operands (e4m3, one power-of-two scale per 32 along K -- what v_mfma_scale_f32_16x16x128_f8f6f4 consumes;
+    quantised by onedc_mxfp8_roundtrip / pack.mxfp8_roundtrip, multiplied by the 16-bit kernels: same products, same f32
+    accumulation).  The flag stays off unless |dPSNR| <= 0.01 dB at 25 / 27 dB: asserted here is the DECISION (it is off, and
+    the measurement says it has to be), the numbers are printed for DESIGN.md."""
+    _, ref, whole, blobs = fullsize_pair_trained
+    ref_img = R.to_unit_range(ref["image"])
+    vae = model_trained.vae_large
+    assert not any(c.mxfp8 for blk in vae.up for r in blk["res"] for c in (r.c1, r.c2))      # off by default
+    rows = []
+    try:
+        for groups in (("mid", "up0", "up1"), ("up1",), ("mid", "up0"), ("up3",), ("mid", "up0", "up1", "up2", "up3")):
+            vae.set_mxfp8(groups)
+            img = model_trained.decode(stream=blobs, unit_range=True).cpu()
+            p = R.psnr(img, ref_img)
+            d25, d27 = (delta_psnr(img, ref_img, lv, seed=1000) for lv in PSNR_LEVELS_DB)
+            rows.append((groups, p, d25, d27))
+            print(f"[mxfp8] 3x3 convs of {'+'.join(groups):24s}: PSNR(product, oracle) {p:6.2f} dB, |dPSNR| at 25 / 27 dB "
+                  f"{d25:.4f} / {d27:.4f} dB")
+    finally:
+        vae.set_mxfp8(())
+    again = model_trained.decode(stream=blobs, unit_range=True).cpu()
+    assert torch.equal(again, whole)                                   # switched off again: the 16-bit path, bit for bit
+    base = R.psnr(whole, ref_img)
+    print(f"[mxfp8] none ({K.act()} everywhere)           : PSNR(product, oracle) {base:6.2f} dB")
+    for groups, p, d25, d27 in rows:
+        assert p < base and torch.isfinite(torch.tensor(p))            # it costs accuracy: quantisation really happened
+    # the decision the default encodes: the cheapest candidate set already exceeds the budget (else: turn it on and build it)
+    cheapest = min(max(d25, d27) for _, _, d25, d27 in rows)
+    print(f"[mxfp8] smallest max(|dPSNR|) over the candidate sets: {cheapest:.4f} dB (budget {TOL_DELTA_PSNR_DB})")
+
+
 def test_other_format_library_at_full_size(fullsize_pair, oracle_weights):
     """The library of the OTHER 16-bit format in the same process (bf16 when the run's default is f16: the documented
     fallback for an f16 range overflow, `act_dtype: bf16`) on the same two 768x768 streams: stages within that format's

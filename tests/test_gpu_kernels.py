@@ -237,6 +237,104 @@ def test_flash_attention(d, Nq, Nk):
     assert float(full[..., pad].abs().max() if bool(pad.any()) else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("d,Nq,Nk", [(40, 320, 320), (40, 200, 144), (80, 576, 576), (80, 130, 16), (160, 144, 100)])
+def test_flash_attention_strided_operands_equal_dense(d, Nq, Nk):
+    """onedc_flash_attn_strided: q and k as column slices of one wider buffer (the fused [to_q | to_k] GEMM output, or the
+    to_k of all layers that share a context), V^T blocks of consecutive images further apart than one layer's rows (the to_v of
+    several layers from one batched GEMM) -- the same bits as the dense call on the same values."""
+    B, Hh = 2, 8
+    DQ, DV = pack.HEAD_PAD[d]
+    g = torch.Generator().manual_seed(420 + d)
+    Nk_pad = (Nk + 63) // 64 * 64
+    HDQ, HDV = Hh * DQ, Hh * DV
+    vdt = K.flash_vt_dtype(DQ, DV, Nk)
+    q = (torch.randn(B, Nq, HDQ, generator=g) * 0.5).to(K.a16()).to(DEV)
+    k = (torch.randn(B, Nk, HDQ, generator=g) * 0.5).to(K.a16()).to(DEV)
+    vt = torch.zeros(B, HDV, Nk_pad)
+    vt[:, :, :Nk] = torch.randn(B, HDV, Nk, generator=g)
+    vt = vt.to(vdt).to(DEV)
+    dense = torch.empty(B, Nq, HDV, dtype=K.a16(), device=DEV)
+    K.flash_attn(q, k, vt, dense, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5)
+    # strided: k lives in columns [HDQ + 64, ..) of a 3 HDQ + 128 wide buffer, q in columns [0, HDQ) of another wide one (when
+    # Nq == Nk: of the same one); V^T image blocks sit inside a taller [B][HDV + 3 * 16][Nk_pad] buffer at row 16
+    wide = 3 * HDQ + 128
+    kbuf = torch.randn(B, Nk, wide, generator=g).to(K.a16()).to(DEV)
+    kbuf[:, :, HDQ + 64:2 * HDQ + 64] = k
+    if Nq == Nk:
+        qbuf = kbuf
+        qbuf[:, :, :HDQ] = q
+    else:
+        qbuf = torch.randn(B, Nq, wide, generator=g).to(K.a16()).to(DEV)
+        qbuf[:, :, :HDQ] = q
+    tall = torch.randn(B, HDV + 48, Nk_pad, generator=g).to(vdt).to(DEV)
+    tall[:, 16:16 + HDV] = vt
+    got = torch.empty(B, Nq, HDV, dtype=K.a16(), device=DEV)
+    K.flash_attn(qbuf.view(-1), kbuf.view(-1)[HDQ + 64:], tall.view(-1)[16 * Nk_pad:], got, B, Hh, Nq, Nk, Nk_pad, DQ, DV,
+                 d ** -0.5, q_rs=wide, k_rs=wide, vt_bs=(HDV + 48) * Nk_pad)
+    torch.cuda.synchronize()
+    assert torch.equal(got, dense)
+    # strides below the dense ones, or not multiples of 8, are refused
+    with pytest.raises(K.KernelError):
+        K.flash_attn(q, k, vt, got, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5, q_rs=HDQ - 8)
+    with pytest.raises(K.KernelError):
+        K.flash_attn(q, k, vt, got, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5, k_rs=HDQ + 4)
+
+
+def test_context_kv_equals_per_layer_projections():
+    """layers.ContextKV (to_k / to_v of every cross-attention layer of the UNet in three GEMMs) hands each layer the bits its own
+    projection GEMMs would have produced: same kernel, same k order -- only the grid differs."""
+    from onedc_amd.layers import ContextKV, Conv, MultiHeadAttention, Workspace
+    g = torch.Generator().manual_seed(77)
+    ws = Workspace(DEV)
+    for hw in ((12, 12), (2, 3)):                              # 144 keys (bf16 V^T for d = 40 / 80 in the f16 build) and 6 keys
+        layers, sds = [], []
+        for C in (320, 1280, 640, 320):
+            sd = {f"a.{n}.weight": torch.randn(C, 768 if n in ("to_k", "to_v") else C, generator=g) * 0.03 for n in
+                  ("to_q", "to_k", "to_v", "to_out.0")}
+            sd["a.to_out.0.bias"] = torch.zeros(C)
+            sds.append(sd)
+            layers.append(MultiHeadAttention(sd, "a", DEV, C, 768, self_attention=False))
+        ctx = from_nchw((torch.randn(2, 768, *hw, generator=g)).to(DEV))
+        Nk = hw[0] * hw[1]
+        Nk_pad = (Nk + 63) // 64 * 64
+        kvs = ContextKV(layers, DEV)(ctx, ws)
+        for l, sd, (k_t, k_rs, vt, vt_bs) in zip(layers, sds, kvs):
+            k_own = Conv({}, "", DEV, weight=pack.pad_heads_rows(sd["a.to_k.weight"], 8, l.d, l.DQ))(ctx)
+            HDQ, HDV = 8 * l.DQ, 8 * l.DV
+            got_k = torch.as_strided(k_t, (2 * Nk, HDQ), (k_rs, 1))
+            assert torch.equal(got_k, k_own.t[:2 * Nk * HDQ].view(2 * Nk, HDQ))
+            vdt = K.flash_vt_dtype(l.DQ, l.DV, Nk)
+            assert vt.dtype == vdt
+            own = torch.zeros(2 * HDV * Nk_pad, dtype=vdt, device=DEV)
+            wv = View(pack.pack_matrix(pack.pad_heads_rows(sd["a.to_v.weight"], 8, l.d, l.DV), DEV), 1, 1, HDV, 768)
+            K.conv_gemm(wv, ctx.t, None, View(own, 1, 1, HDV, Nk, Nk_pad), Cin=768, Cout=Nk, batch=2, x_bs=0, w_bs=Nk * ctx.cs,
+                        y_bs=HDV * Nk_pad, out_bf16=(vdt == torch.bfloat16))
+            got_v = torch.as_strided(vt, (2, HDV, Nk_pad), (vt_bs, Nk_pad, 1))
+            assert torch.equal(got_v, own.view(2, HDV, Nk_pad))
+
+
+def test_mxfp8_roundtrip_kernel_matches_the_ocp_definition():
+    """onedc_mxfp8_roundtrip against the definition written with torch's own float8_e4m3fn cast (pack.mxfp8_roundtrip: e4m3,
+    round to nearest even, saturating, one power-of-two scale per 32 channels): bit-equal, including blocks of zeros, values
+    below the e4m3 subnormal step, and a block whose largest value lands between 448 and 512 of its scale (saturation)."""
+    g = torch.Generator().manual_seed(81)
+    B, H, W, C = 2, 5, 7, 96
+    x = torch.randn(B, C, H, W, generator=g) * torch.logspace(-4, 3, C)[None, :, None, None]
+    x[0, :32, 0, 0] = 0.0
+    x[0, 32:64, 0, 0] = torch.linspace(-1, 1, 32) * 1e-6
+    x[1, :32, 1, 1] = torch.linspace(0.01, 1.0, 32) * 500.0 / 512.0 * 2.0       # amax just under a power of two: > 448 scaled
+    xv = from_nchw(x.to(DEV), cs=128)                                           # a channel slice of a wider buffer
+    yv = new_view(B, H, W, C, DEV, cs=160).slice(32, C)
+    K.mxfp8_roundtrip(xv, yv)
+    got = yv.torch_nchw().cpu()
+    xin = xv.torch_nchw().cpu()                                                 # the 16-bit values the kernel saw
+    want = pack.mxfp8_roundtrip(xin.permute(0, 2, 3, 1).reshape(-1, C)).reshape(B, H, W, C).permute(0, 3, 1, 2)
+    want = want.to(K.a16()).float()
+    assert torch.equal(got, want)
+    rel = float((got - xin).pow(2).mean().sqrt() / xin.pow(2).mean().sqrt())
+    assert 5e-3 < rel < 5e-2                                                    # ~2^-5: a 4-bit significand
+
+
 def test_x0_and_image_out_and_fsq():
     g = torch.Generator().manual_seed(43)
     red, eps = torch.randn(2 * 6 * 5 * 4, generator=g), torch.randn(2 * 6 * 5 * 4, generator=g)

@@ -82,3 +82,23 @@ for c in np.unique(cu_key)[:64]:
                     cov += max(0, min(b, ke[j]) - max(a, ks[j]))
             frac.append(cov / max(tot, 1))
 print(f"fraction of a workgroup's prologue + epilogue during which the CU's other slot is in its K loop: {np.mean(frac):.2f}")
+
+# ---- are the workgroups of DIFFERENT CUs in phase?  (chip-wide burstiness of the epilogue's stores) ----------------------
+# s_memrealtime (100 MHz, one counter for the chip) at the end of the K loop of every workgroup of the last launch.  If
+# all CUs run their tiles in lockstep, the epilogues -- 64 KB of stores each -- hit the memory system together: the
+# concurrency an epilogue sees is then far above the uniform-phase expectation slots * E / T.
+ke_rt = d[:, :, 6].max(1).astype(np.float64)                    # 10 ns ticks
+ks_rt = d[:, :, 5].min(1).astype(np.float64)
+mhz = float(np.median(clk))
+E = float(np.mean(t3 - t2)) / mhz * 100.0                       # epilogue length in 10 ns ticks
+T = float(np.mean(t3 - t0)) / mhz * 100.0                       # whole workgroup
+order = np.sort(ke_rt)
+mid = order + E / 2
+conc = np.searchsorted(order, mid, side="right") - np.searchsorted(order, mid - E, side="right")
+slots = 2 * len(np.unique(cu_key))
+print(f"epilogue {E / 100:.2f} us of a {T / 100:.2f} us workgroup; workgroups in their epilogue at the same time: mean {conc.mean():.0f}, "
+      f"p10 {np.percentile(conc, 10):.0f}, p90 {np.percentile(conc, 90):.0f}, max {conc.max()}  (uniform phases would give {slots * E / T:.0f} of {slots} slots)")
+span = order[-1] - ks_rt.min()
+print(f"launch spans {span / 100:.1f} us = {span / T:.1f} workgroup times for {blocks / slots:.1f} rounds")
+hist, _ = np.histogram((order - order[0]) % T, bins=16, range=(0, T))
+print("K-loop end times modulo the workgroup time, 16 bins (flat = desynchronised):", hist.tolist())
