@@ -287,6 +287,9 @@ def pin_host_threads(local_rank, world):
     if plan is None:
         return None
     os.sched_setaffinity(0, plan[local_rank])
+    # torch sized its intra-op pool for the whole machine when it was imported: on this rank's share of the cores that many
+    # threads only contend (the synthetic weights and the CPU baseline are the torch-CPU work of this process)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(plan[local_rank]))))
     return plan[local_rank]
 
 

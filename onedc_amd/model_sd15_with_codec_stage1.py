@@ -66,6 +66,12 @@ class SD15_1step_codec_stage1:
         self.feedforward_model = None
         self.codec_model = None
         self.vae_large = None
+        # f16_range_fallback: a batch whose f16 decode trips the range guard (kernels.HalfRangeError) is decoded again by a
+        # bf16 twin of this model (same weights, bf16 storage: f32's exponent range, 8x coarser rounding) instead of raising.
+        # The twin is built on first use from where the weights came from (checkpoint files / the synthetic generator).
+        self.range_fallback = bool(_get(args, "f16_range_fallback", False))
+        self._weight_source = None
+        self._twin = None
 
     # -- weights -------------------------------------------------------------------------------
     def load_state_dicts(self, feedforward_sd, codec_sd, vae_sd):
@@ -92,6 +98,9 @@ class SD15_1step_codec_stage1:
         vae = load_safetensor(vae_path)
         check_state_dicts(ff, codec, vae)
         self.load_state_dicts(ff, codec, vae)
+        self._weight_source = lambda: (load_safetensor(os.path.join(checkpoint_path, "model.safetensors")),
+                                       load_safetensor(os.path.join(checkpoint_path, "model_1.safetensors")),
+                                       load_safetensor(vae_path))
         # encode side, when the files carry it (model_1.safetensors always does: enc.*, hyper_enc.*)
         if "enc.pix_emb.weight" in codec and "encoder.conv_in.weight" in vae:
             self.load_encoder_state_dicts(codec, codec, vae)
@@ -101,8 +110,23 @@ class SD15_1step_codec_stage1:
         """Deterministic synthetic weights of the real architecture (no checkpoints offline).  preset: "random_init"
         (default) or "trained_like" (residual branches damped so that x0 rms ~1 and the prior stays inside its table:
         the operating point of a trained checkpoint, onedc_amd/synth.py)."""
-        return self.load_state_dicts(synth.unet_state_dict(seed, preset=preset), synth.codec_state_dict(seed, preset=preset),
-                                     synth.vae_state_dict(seed, preset=preset))
+        self._weight_source = lambda: (synth.unet_state_dict(seed, preset=preset), synth.codec_state_dict(seed, preset=preset),
+                                       synth.vae_state_dict(seed, preset=preset))
+        return self.load_state_dicts(*self._weight_source())
+
+    def bf16_twin(self):
+        """This model with bf16 activations (built once, on first use): the decoder a batch goes to when its f16 decode left
+        the half-precision range and `f16_range_fallback` is set."""
+        if self._twin is None:
+            if self._weight_source is None:
+                raise RuntimeError("no weight source to build the bf16 twin from (load() / load_synthetic() record one)")
+            args = dict(self.args) if isinstance(self.args, dict) else dict(vars(self.args))
+            args["act_dtype"] = "bf16"
+            args["f16_range_fallback"] = False
+            twin = SD15_1step_codec_stage1(args, device=self.device).load_state_dicts(*self._weight_source())
+            twin.codec_model.update(force=True)
+            self._twin = twin
+        return self._twin
 
     def load_encoder_state_dicts(self, codec_enc_sd, hyper_enc_sd, vae_enc_sd):
         with K.act_format(self.act):
@@ -223,7 +247,12 @@ class SD15_1step_codec_stage1:
         with torch.cuda.device(self.device):
             entropy_out = self.codec_model.decode_entropy(fp=fp, stream=stream)
             res, flags = self._decode_after_entropy(entropy_out, unit_range, out=out)
-            self._raise_if_nonfinite(flags)
+            try:
+                self._raise_if_nonfinite(flags)
+            except K.HalfRangeError:
+                if not (self.range_fallback and self.act == "f16"):
+                    raise
+                return self.bf16_twin().decode(fp=fp, stream=stream, unit_range=unit_range, out=out)
             return res
 
     check_finite = True      # model.decode() / DecodePipeline.map() raise HalfRangeError on NaN / Inf pictures

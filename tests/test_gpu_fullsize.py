@@ -45,11 +45,11 @@ TOL_STAGE_BY_ACT = {
 # trained_like: x0 = (reduced - 0.998 eps) / 0.068 is a DIFFERENCE of two O(0.05) tensors there (in the random-init
 # regime `reduced` dominates it), so the x14.65 gain acts on the absolute error of both: x0 and the picture get a wider bound
 TOL_STAGE_TRAINED_BY_ACT = {
-    "f16": {"y_semantic": 2e-3, "h_detail": 2e-3, "reduced": 2e-3, "eps": 4e-3, "x0": 6e-3, "image": 1e-2},
-    "bf16": {"y_semantic": 1.2e-2, "h_detail": 1.2e-2, "reduced": 1.2e-2, "eps": 3e-2, "x0": 5e-2, "image": 8e-2},
-}
-MIN_PSNR_DB_BY_ACT = {"f16": 62.0, "bf16": 47.0}      # random_init: measured 67.4 / 49.7
-MIN_PSNR_TRAINED_DB_BY_ACT = {"f16": 52.0, "bf16": 36.0}
+    "f16": {"y_semantic": 2e-3, "h_detail": 2.5e-3, "reduced": 2.5e-3, "eps": 3.5e-3, "x0": 3e-3, "image": 4e-3},
+    "bf16": {"y_semantic": 1.2e-2, "h_detail": 1.5e-2, "reduced": 1.5e-2, "eps": 3e-2, "x0": 3e-2, "image": 4e-2},
+}   # measured, f16: 7.7e-4, 9.9e-4, 1.0e-3, 1.3e-3, 1.1e-3, 1.7e-3
+MIN_PSNR_DB_BY_ACT = {"f16": 62.0, "bf16": 47.0}      # random_init: measured 67.3 / 49.6
+MIN_PSNR_TRAINED_DB_BY_ACT = {"f16": 61.0, "bf16": 42.0}   # trained_like: measured 66.3 (f16)
 TOL_STAGE = TOL_STAGE_BY_ACT[K.act()]
 MIN_PSNR_DB = MIN_PSNR_DB_BY_ACT[K.act()]
 TOL_DELTA_PSNR_DB = 0.01           # BASELINE.json north_star
@@ -183,7 +183,8 @@ def test_mxfp8_vae_layers_cost_measured(model_trained, fullsize_pair_trained):
     assert not any(c.mxfp8 for blk in vae.up for r in blk["res"] for c in (r.c1, r.c2))      # off by default
     rows = []
     try:
-        for groups in (("mid", "up0", "up1"), ("up1",), ("mid", "up0"), ("up3",), ("mid", "up0", "up1", "up2", "up3")):
+        for groups in (("mid", "up0", "up1"), ("up1",), ("mid", "up0"), ("up2",), ("up3",), ("up2", "up3"),
+                       ("mid", "up0", "up1", "up2", "up3")):
             vae.set_mxfp8(groups)
             img = model_trained.decode(stream=blobs, unit_range=True).cpu()
             p = R.psnr(img, ref_img)

@@ -127,6 +127,17 @@ def test_half_range_overflow_raises_with_the_fix_named(model, tmp_path):
             with pytest.raises(K.HalfRangeError):
                 ev.evaluate()
             assert not (tmp_path / "a.png").exists()
+            # f16_range_fallback: the batch is decoded again by a bf16 twin of the model instead of raising
+            model.range_fallback = True
+            try:
+                fb = model.decode(stream=blobs, unit_range=True)
+            finally:
+                model.range_fallback = False
+            assert model._twin is not None and model._twin.act == "bf16" and bool(torch.isfinite(fb).all())
+            from oracle import torch_ref as R
+            assert R.psnr(fb.cpu(), good.cpu()) >= 44.0            # the bf16 picture of the same streams (measured 49.5 dB)
+            model._twin = None
+            torch.cuda.empty_cache()
             model.check_finite = False                     # opting out restores the old behaviour: a finite, wrong picture
             try:
                 out = model.decode(stream=blobs, unit_range=True)
@@ -139,3 +150,24 @@ def test_half_range_overflow_raises_with_the_fix_named(model, tmp_path):
     finally:
         w.copy_(saved)
     assert torch.equal(model.decode(stream=blobs, unit_range=True), good)
+
+
+def test_quality_metrics_on_device_tensors(model):
+    """onedc_amd.quality (PSNR of reference src/test_quality.py:234-235, MS-SSIM restated) on pictures that stay on the GPU --
+    what an evaluation loop behind model.decode() calls -- against the same functions on the CPU."""
+    import math
+    from onedc_amd import quality as Q
+    g = torch.Generator().manual_seed(5)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 192), torch.linspace(0, 1, 256), indexing="ij")
+    ref = (0.5 + 0.3 * torch.sin(12 * xx) * torch.cos(9 * yy))[None, None].repeat(2, 3, 1, 1)
+    rec = (ref + 0.03 * torch.randn(ref.shape, generator=g)).clamp(0, 1)
+    p_cpu, s_cpu = Q.psnr(ref, rec), Q.ms_ssim(ref, rec)
+    p_gpu, s_gpu = Q.psnr(ref.to(DEV), rec.to(DEV)), Q.ms_ssim(ref.to(DEV), rec.to(DEV))
+    assert abs(p_cpu - p_gpu) < 1e-6 and abs(s_cpu - s_gpu) < 1e-5 and 0.5 < s_gpu < 1.0
+    assert abs(Q.psnr(ref.to(DEV), ref.to(DEV) + 0.1) - 20.0) < 1e-4
+    # straight from the decoder: the 8-bit hand-off costs what 8-bit quantisation costs (uniform error of 1/255: 58.9 dB)
+    blobs = _streams(model, 2, 51)
+    f = model.decode(stream=blobs, unit_range=True)
+    u = model.decode(stream=blobs, out="u8").permute(0, 3, 1, 2).float() / 255.0
+    p = Q.psnr(f, u)
+    assert p > 10 * math.log10(12 * 255 ** 2) - 1.5, p

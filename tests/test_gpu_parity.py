@@ -5,7 +5,9 @@ the deterministic synthetic weights of onedc_amd.synth.
 Floating-point tolerances are written at each check and KEYED BY THE 16-BIT FORMAT (`tol(f16, bf16)`): the product
 computes in IEEE half (default) or bf16 (ONEDC_ACT=bf16, BASELINE config "bf16") with fp32 accumulation, the oracle is
 fp32.  bf16 rounds 8x coarser than f16, so one number for both would let a 5-10x regression of the f16 kernels pass: the
-f16 bounds are ~2x the values measured on MI355X (printed by every check), the bf16 bounds the round-1 ones.
+f16 bounds are 2-3x the values measured on MI355X (printed by every check; round 3: semantic adaptor 9.5e-4,
+synthesis 1.0e-3, vae_reduction 3.5e-4, UNet eps 1.5e-3, VAE decoder 1.5e-3, VAE encoder 7.5e-4, analysis transform 1.3e-3 / 1.4e-3,
+end-to-end 67.8 dB), the bf16 bounds the round-1 ones.
 Integer/byte results (symbols, bitstreams, round trips) are checked bit-exactly.
 """
 import numpy as np
@@ -234,11 +236,11 @@ def test_semantic_adaptor_and_synthesis(codec, codec_sd):
     with torch.no_grad():
         ys_ref = R.semantic_adaptor(codec_sd, z_sem)
         xh_ref = R.codec_decoder(codec_sd, y_hat, ys_ref)
-    check(y_sem.torch_nchw(), ys_ref, tol(4e-3, 2e-2), "semantic adaptor")
-    check(x_hat.torch_nchw(), xh_ref, tol(6e-3, 3e-2), "codec synthesis (h_detail_hat)")
+    check(y_sem.torch_nchw(), ys_ref, tol(2.5e-3, 2e-2), "semantic adaptor")
+    check(x_hat.torch_nchw(), xh_ref, tol(2.5e-3, 3e-2), "codec synthesis (h_detail_hat)")
     flat = x_hat.torch_nchw().reshape(-1).cpu()
     gi = torch.from_numpy(g["x_hat.idx"])
-    assert rel_rms(flat[gi], torch.from_numpy(g["x_hat.val"])) <= tol(6e-3, 3e-2)       # vs the reference-made golden
+    assert rel_rms(flat[gi], torch.from_numpy(g["x_hat.val"])) <= tol(2.5e-3, 3e-2)       # vs the reference-made golden
 
 
 @pytest.fixture(scope="module")
@@ -257,8 +259,8 @@ def test_unet_step(unet_pair):
     eps, reduced = unet(from_nchw(sample.to(DEV)), 999, from_nchw(ctx.to(DEV)))
     with torch.no_grad():
         eps_ref, red_ref = R.unet_forward(sd, sample, torch.tensor([999, 999]), ctx.permute(0, 2, 3, 1).reshape(2, 6, 768))
-    check(reduced.torch_nchw(), red_ref, tol(2e-3, 1e-2), "vae_reduction")
-    check(eps.torch_nchw(), eps_ref, tol(6e-3, 3e-2), "UNet eps")
+    check(reduced.torch_nchw(), red_ref, tol(1e-3, 1e-2), "vae_reduction")
+    check(eps.torch_nchw(), eps_ref, tol(4e-3, 3e-2), "UNet eps")
 
 
 @pytest.mark.parametrize("h,w", [(32, 48), (24, 40)])
@@ -273,7 +275,7 @@ def test_vae_decoder_windowed(h, w):
     img = vae.decode(lv)
     with torch.no_grad():
         ref = R.vae_decode(sd, lat, 16)
-    check(img.torch_nchw(), ref, tol(6e-3, 3e-2), f"VAE decoder {h}x{w}")
+    check(img.torch_nchw(), ref, tol(4e-3, 3e-2), f"VAE decoder {h}x{w}")
 
 
 def test_end_to_end_decode_psnr(full_model, gaussian_tables):
@@ -295,7 +297,7 @@ def test_end_to_end_decode_psnr(full_model, gaussian_tables):
     ref = R.to_unit_range(out["image"])
     p = R.psnr(img.cpu(), ref)
     print(f"[parity] end-to-end PSNR(product, oracle) = {p:.2f} dB")
-    assert p >= tol(60.0, 45.0)
+    assert p >= tol(62.0, 45.0)
 
 
 def test_decode_pipeline_matches_sequential_decode(full_model):
@@ -346,8 +348,8 @@ def test_hyper_encoder_fsq_and_compress_round_trip(codec, codec_sd):
     z = codec.hyper_enc(yv, sv, codec.ws)
     with torch.no_grad():
         z_ref = R.hyper_encoder(henc_sd, y.to(torch.bfloat16).float(), sem.to(torch.bfloat16).float())
-    check(z.slice(0, 7).torch_nchw(), z_ref, tol(6e-3, 3e-2), "hyper encoder z vs oracle")
-    check(z.slice(0, 7).torch_nchw(), torch.from_numpy(g["z"]), tol(6e-3, 3e-2), "hyper encoder z vs reference golden")
+    check(z.slice(0, 7).torch_nchw(), z_ref, tol(4e-3, 3e-2), "hyper encoder z vs oracle")
+    check(z.slice(0, 7).torch_nchw(), torch.from_numpy(g["z"]), tol(3e-3, 3e-2), "hyper encoder z vs reference golden")
     # FSQ kernel on a dense sweep of z values
     zz = (torch.rand(4, 7, 16, 16, generator=torch.Generator().manual_seed(31)) * 6 - 3)
     zzv = from_nchw(zz.to(DEV), torch.float32, pad_to=8)
@@ -383,7 +385,7 @@ def test_vae_encoder_vs_oracle():
     z = enc.encode(iv, noise.permute(0, 2, 3, 1).contiguous().to(DEV))
     with torch.no_grad():
         ref = R.vae_encode(sd, img, 16, noise)
-    check(z.torch_nchw(), ref, tol(6e-3, 3e-2), "VAE encoder latents")
+    check(z.torch_nchw(), ref, tol(2e-3, 3e-2), "VAE encoder latents")
 
 
 def test_flash_attention_head_dim_8():
@@ -407,7 +409,7 @@ def test_flash_attention_head_dim_8():
                  o, B, Hh, N, N, n_pad, DQ, DV, d ** -0.5)
     ref = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v
     got = o.float().cpu().view(B, N, Hh, DV)[..., :d].permute(0, 2, 1, 3)
-    check(got, ref, tol(2e-3, 8e-3), "flash attention d=8")
+    check(got, ref, tol(1e-3, 8e-3), "flash attention d=8")
 
 
 def test_analysis_transform_vs_oracle():
@@ -425,8 +427,8 @@ def test_analysis_transform_vs_oracle():
     y, sem = enc(iv, cv)
     with torch.no_grad():
         y_ref, sem_ref = R.codec_encoder(sd, img, cond)
-    check(sem.torch_nchw(), sem_ref, tol(1e-2, 5e-2), "analysis transform: sem (UNet mid output)")
-    check(y.torch_nchw(), y_ref, tol(1e-2, 5e-2), "analysis transform: y")
+    check(sem.torch_nchw(), sem_ref, tol(4e-3, 5e-2), "analysis transform: sem (UNet mid output)")
+    check(y.torch_nchw(), y_ref, tol(4e-3, 5e-2), "analysis transform: y")
 
 
 def test_model_encode_then_decode_round_trip(full_model, tmp_path):
