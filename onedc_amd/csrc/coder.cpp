@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -38,6 +39,26 @@ struct TableGroup {
     std::vector<int32_t> size;     // entries used per table (symbols = size - 1, escape = size - 2)
     std::vector<int32_t> offset;   // value of symbol 0
     std::vector<uint8_t> lut;      // decoder only: [n_tables][kLutSize] first candidate symbol
+    // encoder only: [n_tables][row_len] (start, frequency, reciprocal) of every symbol, so that coding a symbol is one
+    // 12-byte copy when it is pushed and a multiply-high instead of a 32-bit division when the stream is written
+    struct EncSym {
+        uint16_t start;
+        uint16_t range;   // frequency; 0 marks a raw bypass digit held in `start`
+        uint32_t rcp;     // ceil(2^(31 + shift) / range), shift = ceil(log2 range)   (range >= 2)
+        uint32_t shift;   // x / range == mulhi(x, rcp) >> (shift - 1) for every x < 2^31 (Alverson; rans_byte.h uses the same)
+    };
+    std::vector<EncSym> enc_sym;
+
+    static EncSym make_enc_sym(uint32_t start, uint32_t range) {
+        EncSym e{(uint16_t)start, (uint16_t)range, 0u, 0u};
+        if (range >= 2) {
+            uint32_t sh = 0;
+            while (range > (1u << sh)) ++sh;
+            e.rcp = (uint32_t)(((1ull << (sh + 31)) + range - 1) / range);
+            e.shift = sh - 1;
+        }
+        return e;
+    }
 
     int load(const int32_t *cdfs, int n, int len, const int32_t *sizes, const int32_t *offsets,
              bool with_lut) {
@@ -57,6 +78,14 @@ struct TableGroup {
         cdf.assign(cdfs, cdfs + (size_t)n * len);
         size.assign(sizes, sizes + n);
         offset.assign(offsets, offsets + n);
+        if (!with_lut) {
+            enc_sym.assign((size_t)n * len, EncSym{0, 0, 0, 0});
+            for (int t = 0; t < n; ++t) {
+                const int32_t *c = &cdf[(size_t)t * len];
+                for (int k = 0; k + 1 < size[t]; ++k)
+                    enc_sym[(size_t)t * len + k] = make_enc_sym((uint32_t)c[k], (uint32_t)(c[k + 1] - c[k]));
+            }
+        }
         if (with_lut) {
             if (len > 257) return ONEDC_ERR_ARG;  // lut entries are uint8
             lut.resize((size_t)n * kLutSize);
@@ -75,46 +104,82 @@ struct TableGroup {
     }
 };
 
-struct PendingSym {
-    uint16_t start;
-    uint16_t range;  // 0 marks a raw bypass digit held in `start`
-};
+typedef TableGroup::EncSym PendingSym;
 
 // ---- single-stream encoder --------------------------------------------------
+// The pending symbols of a stream: a plain growable array that is never value-initialised (std::vector::resize would
+// zero 12 bytes per symbol before the loop below overwrites them)
+struct PendingBuf {
+    PendingSym *d = nullptr;
+    size_t n = 0, cap = 0;
+    PendingBuf() = default;
+    PendingBuf(const PendingBuf &) = delete;
+    PendingBuf &operator=(const PendingBuf &) = delete;
+    PendingBuf(PendingBuf &&o) noexcept : d(o.d), n(o.n), cap(o.cap) { o.d = nullptr; o.n = o.cap = 0; }
+    ~PendingBuf() { free(d); }
+    bool room(size_t total) {                      // capacity for `total` entries, contents kept
+        if (total <= cap) return true;
+        size_t c = std::max(total, cap + cap / 2 + 1024);
+        auto *nd = (PendingSym *)realloc(d, c * sizeof(PendingSym));
+        if (!nd) return false;
+        d = nd;
+        cap = c;
+        return true;
+    }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+};
+
 struct EncPart {
-    std::vector<PendingSym> pending;
+    PendingBuf pending;
     std::vector<uint8_t> stream;
+    bool oom = false;
 
     void push(const TableGroup &g, const int16_t *symbols, const int16_t *indexes, int64_t n) {
-        pending.reserve(pending.size() + (size_t)n + (size_t)n / 2);
+        // one slot per symbol up front (the common case writes through a raw pointer); an escape appends its bypass
+        // digits through the slow path, which makes room first
+        size_t w = pending.size();
+        if (!pending.room(w + (size_t)n)) {
+            oom = true;
+            return;
+        }
+        PendingSym *out = pending.d;
+        const PendingSym *table = g.enc_sym.data();
+        const int row = g.row_len;
         for (int64_t i = 0; i < n; ++i) {
             const int t = indexes[i];
             if (t < 0) continue;
-            const int32_t *c = &g.cdf[(size_t)t * g.row_len];
             const int32_t escape = g.size[t] - 2;
             int32_t v = (int32_t)symbols[i] - g.offset[t];
-            uint32_t raw = 0;
-            if (v < 0) {
-                raw = (uint32_t)(-2 * v - 1);
-                v = escape;
-            } else if (v >= escape) {
-                raw = (uint32_t)(2 * (v - escape));
-                v = escape;
+            if ((uint32_t)v < (uint32_t)escape) {               // 0 <= v < escape
+                out[w++] = table[(size_t)t * row + v];
+                continue;
             }
-            pending.push_back({(uint16_t)c[v], (uint16_t)(c[v + 1] - c[v])});
-            if (v == escape) {
-                int digits = 0;
-                while ((raw >> (digits * kBypassBits)) != 0) ++digits;
-                int rem = digits;  // unary-ish count: runs of kBypassMax then the remainder
-                while (rem >= (int)kBypassMax) {
-                    pending.push_back({(uint16_t)kBypassMax, 0});
-                    rem -= kBypassMax;
+            uint32_t raw;
+            if (v < 0) raw = (uint32_t)(-2 * v - 1);
+            else raw = (uint32_t)(2 * (v - escape));
+            int digits = 0;
+            while ((raw >> (digits * kBypassBits)) != 0) ++digits;
+            const size_t need = 2 + (size_t)digits / kBypassMax + (size_t)digits;          // escape + count run + digits
+            if (w + need + (size_t)(n - i) > pending.cap) {
+                pending.n = w;
+                if (!pending.room(w + need + (size_t)(n - i) + 64)) {
+                    oom = true;
+                    return;
                 }
-                pending.push_back({(uint16_t)rem, 0});
-                for (int d = 0; d < digits; ++d)
-                    pending.push_back({(uint16_t)((raw >> (d * kBypassBits)) & kBypassMax), 0});
+                out = pending.d;
             }
+            out[w++] = table[(size_t)t * row + escape];
+            int rem = digits;  // unary-ish count: runs of kBypassMax then the remainder
+            while (rem >= (int)kBypassMax) {
+                out[w++] = PendingSym{(uint16_t)kBypassMax, 0, 0, 0};
+                rem -= kBypassMax;
+            }
+            out[w++] = PendingSym{(uint16_t)rem, 0, 0, 0};
+            for (int d = 0; d < digits; ++d)
+                out[w++] = PendingSym{(uint16_t)((raw >> (d * kBypassBits)) & kBypassMax), 0, 0, 0};
         }
+        pending.n = w;
     }
 
     void flush() {
@@ -123,16 +188,24 @@ struct EncPart {
         uint8_t *end = buf.data() + buf.size();
         uint8_t *p = end;
         uint32_t x = kStateLow;
+        const PendingSym *sym = pending.d;
         for (size_t k = pending.size(); k-- > 0;) {
-            const PendingSym s = pending[k];
-            if (s.range != 0) {
+            const PendingSym s = sym[k];
+            if (s.range >= 2) {
                 const uint32_t freq = s.range;
                 const uint32_t x_max = freq << 15;  // ((L >> 16) << 8) * freq
                 while (x >= x_max) {
                     *--p = (uint8_t)(x & 0xff);
                     x >>= 8;
                 }
-                x = ((x / freq) << kProbBits) + (x % freq) + s.start;
+                const uint32_t q = (uint32_t)(((uint64_t)x * s.rcp) >> 32) >> s.shift;      // x / freq, exact for x < 2^31
+                x = (q << kProbBits) + (x - q * freq) + s.start;
+            } else if (s.range == 1) {
+                while (x >= (1u << 15)) {
+                    *--p = (uint8_t)(x & 0xff);
+                    x >>= 8;
+                }
+                x = (x << kProbBits) + s.start;
             } else {
                 const uint32_t x_max = (1u << (kProbBits - kBypassBits)) << 15;
                 while (x >= x_max) {
@@ -261,7 +334,7 @@ struct onedc_rans_dec {
 
 extern "C" {
 
-const char *onedc_coder_version(void) { return "onedc-coder 0.1"; }
+const char *onedc_coder_version(void) { return "onedc-coder 0.2"; }
 
 onedc_rans_enc *onedc_rans_enc_create(int /*multi_thread*/, int stream_part) {
     if (stream_part < 1 || stream_part > 16) return nullptr;
@@ -304,6 +377,7 @@ int onedc_rans_enc_encode_with_indexes(onedc_rans_enc *enc, const int16_t *symbo
     for (int p = 0; p < np; ++p) {
         const int64_t cnt = p < np - 1 ? each : n - each * (np - 1);
         enc->parts[p].push(g, symbols + p * each, indexes + p * each, cnt);
+        if (enc->parts[p].oom) return ONEDC_ERR_CAPACITY;       // out of memory for the pending symbols
     }
     return ONEDC_OK;
 }

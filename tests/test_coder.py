@@ -136,6 +136,37 @@ def test_round_trip_random_tables():
     assert rans_port.encode(sym, idx, t) == stream.tobytes()
 
 
+def test_encoder_reciprocal_division_is_exact_for_extreme_frequencies():
+    """The encoder replaces x / freq by a multiply-high with a precomputed reciprocal (coder.cpp: EncSym).  Tables whose
+    frequencies are 1, 2, 3, powers of two and their neighbours, and 65 000+ (two-symbol rows) must still give the bytes of
+    the C restatement, which divides (oracle/rans_port.c), for long random symbol runs that walk the state through its range."""
+    rng = np.random.default_rng(11)
+    rows = []
+    for f in (1, 2, 3, 4, 5, 7, 8, 9, 255, 256, 257, 4095, 4096, 4097, 32767, 32768, 32769, 65533, 65534):
+        rows.append([0, f, 65535, 65536] if f < 65535 else None)
+    rows = [r for r in rows if r is not None]
+    rows += [[0, 1, 2, 3, 65536], [0, 21845, 43690, 65535, 65536], [0, 65533, 65534, 65535, 65536]]
+    n_tab, L = len(rows), max(len(r) for r in rows)
+    cdf = np.zeros((n_tab, L), np.int32)
+    sizes = np.zeros(n_tab, np.int32)
+    for t, r in enumerate(rows):
+        cdf[t, :len(r)] = r
+        sizes[t] = len(r)
+    offsets = np.zeros(n_tab, np.int32)
+    enc, dec = rans.RansEncoder(False, 1), rans.RansDecoder(1)
+    assert enc.add_cdf(cdf, sizes, offsets) == 0 and dec.add_cdf(cdf, sizes, offsets) == 0
+    n = 200000
+    idx = rng.integers(0, n_tab, n).astype(np.int16)
+    sym = (rng.integers(0, 4, n) % (sizes[idx] - 2)).astype(np.int16)             # in-table symbols only (no escape)
+    sym[::1001] = 7                                                               # ... and a few escapes
+    enc.encode_with_indexes(sym, idx, 0)
+    enc.flush()
+    stream = enc.get_encoded_stream()
+    assert rans_port.encode(sym, idx, rans_port.Tables(cdf, sizes, offsets)) == stream.tobytes()
+    dec.set_stream(stream)
+    assert np.array_equal(dec.decode_stream(idx, 0), sym) and dec.finished()
+
+
 def test_batch_decode_matches_serial(gaussian_tables):
     rng = np.random.default_rng(3)
     B, n = 6, 3000
