@@ -13,11 +13,16 @@ run bench_line_bf16 env ONEDC_ACT=bf16 python3 bench.py --no-cpu-baseline
 run bench_line_sequential python3 bench.py --sequential --no-cpu-baseline
 run bench_line_zonly python3 bench.py --mode z_only --no-cpu-baseline
 run bench_line_encdec python3 bench.py --mode encode_decode
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r2 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r3 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$root/$out/pmc_$c" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --sequential > /dev/null 2> "$root/$out/pmc_$c.err" < /dev/null; echo "pmc $c rc=$?" )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$root/$out/pmc_$c" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_$c.err" < /dev/null; echo "pmc $c rc=$?" )
 done
 find "$out" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \; < /dev/null
+# the same decode with the GPU to itself: kernel time per batch without the pipeline's sharing (tools/seqprof.sh)
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$root/$out/seqprof" -o seq --output-format csv -- python3 "$root/bench.py" --sequential --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$root/$out/bench_line_seqprof.json" 2> "$root/$out/seqprof.err" < /dev/null; echo "seqprof rc=$?" )
+find "$out/seqprof" -name "*kernel_stats.csv" -exec cp {} "$out/sequential_kernel_stats.csv" \; < /dev/null
+rm -rf "$out/seqprof"
+[ -x tools/micro/mfma_rate ] && timeout 120 tools/micro/mfma_rate > "$out/mfma_rate.txt" 2>&1 < /dev/null
 f=$(find "$out/pmc_FETCH_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
 w=$(find "$out/pmc_WRITE_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 tools/pmc_traffic.py "$f" "$w" "$out/pmc_traffic.json" "folded on the box" < /dev/null; fi
