@@ -128,6 +128,8 @@ int onedc_unpack_indices(const uint8_t *bytes, int64_t nbytes, int64_t count, in
                          int32_t *out);
 
 const char *onedc_coder_version(void);
+/* identity (sha256 prefix) of coder.cpp + this header as compiled into the library (onedc_amd/build.py: coder_source_id) */
+const char *onedc_coder_build_id(void);
 
 #ifdef __cplusplus
 }

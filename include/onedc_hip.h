@@ -257,6 +257,9 @@ int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *s
 int onedc_add(const void *a, const void *b, void *y, int64_t n, void *stream);
 
 const char *onedc_hip_version(void);
+/* identity (sha256 prefix) of the kernel sources, headers and compiler flags this library was built from; the Python loader
+ * refuses a library whose id differs from the sources beside it (set ONEDC_ALLOW_STALE_LIB=1 for experiment builds) */
+const char *onedc_hip_build_id(void);
 /* "bf16" or "f16": the 16-bit activation format this build of the library computes in (exact token) */
 const char *onedc_hip_act_format(void);
 

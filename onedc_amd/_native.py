@@ -75,14 +75,30 @@ def coder():
         "onedc_pack_indices": (_L, [_P, _L, _I, _P, _L]),
         "onedc_unpack_indices": (_I, [_P, _L, _L, _I, _P]),
         "onedc_coder_version": (C.c_char_p, []),
+        "onedc_coder_build_id": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     lib._signatures = sig
+    check_build_id(CODER_SO, lib.onedc_coder_build_id().decode(), "coder")
     _coder = lib
     return lib
+
+
+def check_build_id(path, built, kind):
+    """A library that was compiled from OTHER sources than the ones beside it is an error, not a wrong answer (the .so files
+    travel untracked next to the tree).  Only the in-tree default paths are checked: ONEDC_HIP_SO / ONEDC_HIP_F16_SO point at
+    experiment builds on purpose; ONEDC_ALLOW_STALE_LIB=1 switches the check off."""
+    if os.environ.get("ONEDC_ALLOW_STALE_LIB") == "1":
+        return
+    from . import build
+    want = build.coder_source_id() if kind == "coder" else build.hip_source_id()
+    if built != want:
+        raise NativeLibraryError(
+            f"{path} was built from other sources (library id {built}, sources {want}): rebuild with "
+            "`python -c 'import __graft_entry__ as g; g.build()'`")
 
 
 CODER_SYMBOLS = [
@@ -93,7 +109,7 @@ CODER_SYMBOLS = [
     "onedc_rans_dec_add_cdf", "onedc_rans_dec_empty_cdf_buffer", "onedc_rans_dec_set_stream",
     "onedc_rans_dec_decode_stream", "onedc_rans_dec_finished", "onedc_rans_dec_decode_batch", "onedc_rans_enc_encode_batch",
     "onedc_pmf_to_quantized_cdf", "onedc_container_parse", "onedc_container_write",
-    "onedc_pack_indices", "onedc_unpack_indices", "onedc_coder_version",
+    "onedc_pack_indices", "onedc_unpack_indices", "onedc_coder_version", "onedc_coder_build_id",
 ]
 
 

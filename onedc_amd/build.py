@@ -28,11 +28,55 @@ def _run(cmd):
     subprocess.run(cmd, check=True)
 
 
+def _digest(paths, extra=""):
+    """sha256 over (name, bytes) of the given files + `extra`: the identity of what a library is built from."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def coder_sources():
+    return [os.path.join(_native.CSRC, "coder.cpp"), os.path.join(ROOT, "include", "onedc_coder.h")]
+
+
+def coder_source_id():
+    return _digest(coder_sources())
+
+
+def hip_source_id():
+    """Identity of the kernel sources, headers and per-file compiler flags (both activation formats are built from them)."""
+    return _digest(hip_sources() + glob.glob(os.path.join(_native.CSRC, "*.h")) + [os.path.join(ROOT, "include", "onedc_hip.h")],
+                   repr(sorted(FILE_FLAGS.items())))
+
+
+BUILD_ID_MARKER = b"@(#)onedc-build-id:"
+
+
+def _built_id(so, symbol=None):
+    """The source id a built library carries (None: missing library or a build from before the id existed).  Read from the
+    file's bytes, not through dlopen: a process that has loaded an older build of the same path would get that one back."""
+    if not os.path.exists(so):
+        return None
+    with open(so, "rb") as f:
+        data = f.read()
+    i = data.find(BUILD_ID_MARKER)
+    if i < 0:
+        return None
+    j = i + len(BUILD_ID_MARKER)
+    return data[j:data.index(b"\0", j)].decode(errors="replace")
+
+
 def build_coder(force=False):
-    src = [os.path.join(_native.CSRC, "coder.cpp"), os.path.join(ROOT, "include", "onedc_coder.h")]
-    if force or _stale(_native.CODER_SO, src):
-        _run(["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall",
+    src = coder_sources()
+    sid = coder_source_id()
+    if force or _stale(_native.CODER_SO, src) or _built_id(_native.CODER_SO, "onedc_coder_build_id") != sid:
+        _run(["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wall", f'-DONEDC_BUILD_ID="{sid}"',
               "-o", _native.CODER_SO, src[0]])
+    print(f"[build] {os.path.relpath(_native.CODER_SO, ROOT)}: source id {_built_id(_native.CODER_SO, 'onedc_coder_build_id')}", flush=True)
     return _native.CODER_SO
 
 
@@ -61,16 +105,22 @@ def build_hip(force=False, extra_flags=()):
     if not srcs:
         raise RuntimeError("no HIP sources found")
     variants = ((_native.HIP_SO, ".o", ()), (_native.HIP_F16_SO, ".f16.o", ("-DONEDC_ACT_F16",)))
+    sid = hip_source_id()
     jobs, links = [], []
     for so, suffix, defs in variants:
-        if not (force or _stale(so, srcs + headers)):
+        # a library is current when it is newer than its sources AND carries the id of exactly these sources (mtimes do
+        # not survive every way a tree is copied; the id does): onedc_hip_build_id(), checked again when it is loaded
+        wrong_id = _built_id(so, "onedc_hip_build_id") != sid
+        if not (force or wrong_id or _stale(so, srcs + headers)):
             continue
         objs = []
         for s in srcs:
             o = s[:-4] + suffix
-            if force or _stale(o, [s] + headers):
+            carries_id = os.path.basename(s) == "elementwise.hip"
+            if force or _stale(o, [s] + headers) or (carries_id and wrong_id):
                 jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-result",
-                             *FILE_FLAGS.get(os.path.basename(s), ()), *defs, *extra_flags, "-o", o, s])
+                             *FILE_FLAGS.get(os.path.basename(s), ()), *defs, *extra_flags,
+                             *((f'-DONEDC_BUILD_ID="{sid}"',) if carries_id else ()), "-o", o, s])
             objs.append(o)
         links.append([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs])
     if jobs:              # one hipcc per file, a few at a time (each is single-threaded and needs ~1-2 GB)
@@ -79,6 +129,12 @@ def build_hip(force=False, extra_flags=()):
             list(pool.map(_run, jobs))
     for cmd in links:
         _run(cmd)
+    for so, _, _ in variants:
+        got = _built_id(so, "onedc_hip_build_id")
+        print(f"[build] {os.path.relpath(so, ROOT)}: source id {got} ({'compiled now' if any(so in c for c in links) else 'up to date'})",
+              flush=True)
+        if got != sid:
+            raise RuntimeError(f"{so} carries source id {got}, the sources are {sid}")
     return _native.HIP_SO
 
 

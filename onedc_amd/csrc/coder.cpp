@@ -335,6 +335,11 @@ struct onedc_rans_dec {
 extern "C" {
 
 const char *onedc_coder_version(void) { return "onedc-coder 0.2"; }
+#ifndef ONEDC_BUILD_ID
+#define ONEDC_BUILD_ID "unidentified"
+#endif
+static const char onedc_build_id_marker[] = "@(#)onedc-build-id:" ONEDC_BUILD_ID;      // (found in the file by build.py)
+const char *onedc_coder_build_id(void) { return onedc_build_id_marker + 19; }
 
 onedc_rans_enc *onedc_rans_enc_create(int /*multi_thread*/, int stream_part) {
     if (stream_part < 1 || stream_part > 16) return nullptr;

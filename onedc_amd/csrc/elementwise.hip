@@ -468,6 +468,13 @@ inline int grid_for(int64_t n, int per = 256) { return (int)min((int64_t)16384, 
 extern "C" {
 
 const char *onedc_hip_version(void) { return "onedc-hip 0.3 (gfx950, " ONEDC_ACT_NAME " activations)"; }
+// identity of the sources this library was compiled from (onedc_amd/build.py: hip_source_id); the loader compares it with the
+// sources next to it, so a stale .so is an error instead of a wrong answer
+#ifndef ONEDC_BUILD_ID
+#define ONEDC_BUILD_ID "unidentified"
+#endif
+static const char onedc_build_id_marker[] = "@(#)onedc-build-id:" ONEDC_BUILD_ID;      // (found in the file by build.py)
+const char *onedc_hip_build_id(void) { return onedc_build_id_marker + 19; }
 // the 16-bit activation format this library was built for: "bf16" or "f16" (exactly; the loader compares it)
 const char *onedc_hip_act_format(void) { return ONEDC_ACT_NAME; }
 

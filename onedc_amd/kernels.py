@@ -126,6 +126,7 @@ SIGNATURES = {
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
     "onedc_hip_version": (C.c_char_p, []),
     "onedc_hip_act_format": (C.c_char_p, []),
+    "onedc_hip_build_id": (C.c_char_p, []),
 }
 HIP_SYMBOLS = list(SIGNATURES)
 
@@ -146,6 +147,9 @@ def lib(fmt=None):
     if l is None:
         l = attach_signatures(_native.hip(fmt))
         check_library_format(fmt, l.onedc_hip_act_format(), l.onedc_hip_version())
+        path = _native.HIP_SO if fmt == "bf16" else _native.HIP_F16_SO
+        if not os.environ.get("ONEDC_HIP_SO" if fmt == "bf16" else "ONEDC_HIP_F16_SO"):    # (experiment builds: no id check)
+            _native.check_build_id(path, l.onedc_hip_build_id().decode(), "hip")
         _libs[fmt] = l
     return l
 

@@ -63,6 +63,33 @@ def test_library_of_the_other_format_is_refused(monkeypatch):
     monkeypatch.setattr(_native, "_hip_f16", None)
 
 
+def test_libraries_carry_the_id_of_the_sources_beside_them(monkeypatch):
+    """build() stamps every library with a digest of its sources, headers and per-file flags; the loaders compare it with the
+    tree they sit in, so a stale .so (they travel untracked) is an error instead of a wrong answer -- and the build log says
+    for each library whether it was compiled now or found current."""
+    build.build_coder()
+    build.build_hip()
+    assert build._built_id(_native.CODER_SO) == build.coder_source_id() == _native.coder().onedc_coder_build_id().decode()
+    for path, fmt in ((_native.HIP_SO, "bf16"), (_native.HIP_F16_SO, "f16")):
+        assert build._built_id(path) == build.hip_source_id() == kernels.lib(fmt).onedc_hip_build_id().decode()
+    # a tree whose sources moved on: the loader refuses the library
+    monkeypatch.setattr(kernels, "_libs", {})
+    monkeypatch.setattr(_native, "_hip_f16", None)
+    monkeypatch.setattr(build, "hip_source_id", lambda: "0123456789abcdef")
+    with pytest.raises(_native.NativeLibraryError, match="built from other sources"):
+        kernels.lib("f16")
+    monkeypatch.setenv("ONEDC_ALLOW_STALE_LIB", "1")                   # experiment builds opt out
+    monkeypatch.setattr(_native, "_hip_f16", None)
+    assert kernels.lib("f16") is not None
+    monkeypatch.delenv("ONEDC_ALLOW_STALE_LIB")
+    monkeypatch.setattr(_native, "_coder", None)
+    monkeypatch.setattr(build, "coder_source_id", lambda: "fedcba9876543210")
+    with pytest.raises(_native.NativeLibraryError, match="built from other sources"):
+        _native.coder()
+    monkeypatch.setattr(_native, "_coder", None)
+    monkeypatch.setattr(_native, "_hip_f16", None)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_native, "_hip", None)
     monkeypatch.setattr(_native, "HIP_SO", "/nonexistent/libonedc_hip.so")
