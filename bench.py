@@ -486,7 +486,7 @@ def main():
                          "win3x3_4w": "conv_win4_kernel", "ups2x2_4w": "conv_win4_kernel<ups>",
                          "ups2x2": "conv_ups_kernel"}.get(dom, f"conv_gemm_kernel<Tile<{dom.replace('f32_', '').replace('x', ',')}>>"
                                                            + (" f32" if dom.startswith("f32") else ""))
-        # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in
+        # HBM traffic and matrix-core utilisation of the dominant kernel: measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in
         # separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) and committed under
         # profiles/; PMC passes serialise every dispatch, so they cannot run inside the timed region.
         traffic = None
@@ -497,6 +497,11 @@ def main():
                 if t:
                     traffic = t["hbm_bytes_per_launch"]
                     break
+        mfma_util = None
+        upath = os.path.join(ROOT, "profiles", "r3_pmc_mfma.json")
+        if mode == "decode" and os.path.exists(upath):
+            u = json.load(open(upath)).get(kernel_symbol)
+            mfma_util = u and u["mfma_util"]
         all_flops = sum(v[0] for v in by_tile.values())
         all_secs = sum(v[1] for v in by_tile.values())
         achieved = flops / secs / 1e12
@@ -538,6 +543,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA16_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(dom_bytes / launches),
+                         "mfma_util_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024), profiles/r3_pmc_mfma.json
                          "kernel": kernel_symbol,
                          "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / args.steps * 1e3, 2),
                                            "launches_per_step": v[2] // args.steps} for k, v in sorted(by_tile.items())},

@@ -23,6 +23,10 @@ find "$out" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \; < /
 find "$out/seqprof" -name "*kernel_stats.csv" -exec cp {} "$out/sequential_kernel_stats.csv" \; < /dev/null
 rm -rf "$out/seqprof"
 [ -x tools/micro/mfma_rate ] && timeout 120 tools/micro/mfma_rate > "$out/mfma_rate.txt" 2>&1 < /dev/null
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$root/$out/pmc_mfma" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_mfma.err" < /dev/null; echo "pmc mfma rc=$?" )
+m=$(find "$out/pmc_mfma" -name "*counter_collection.csv" < /dev/null | head -1)
+if [ -n "$m" ]; then ( cd tools && python3 pmc_mfma.py "$root/$m" "$root/$out/pmc_mfma.json" "folded on the box" < /dev/null ); fi
+rm -rf "$out/pmc_mfma"
 f=$(find "$out/pmc_FETCH_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
 w=$(find "$out/pmc_WRITE_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 tools/pmc_traffic.py "$f" "$w" "$out/pmc_traffic.json" "folded on the box" < /dev/null; fi
