@@ -10,13 +10,13 @@ fp32 oracle, then swaps ONE product stage at a time into the oracle's chain:
 
 and prints PSNR(picture, oracle picture) on [0,1] for each, plus the north-star measure
 |PSNR(product, orig) - PSNR(oracle, orig)| for synthetic "originals" at 25 and 27 dB from the oracle picture
-(reference src/test_quality.py:234-235).  python tools/error_budget.py [--size 256] [--seed 0]
+(reference src/test_quality.py:234-235).  python tests/devtools/error_budget.py [--size 256] [--seed 0]
 """
 import argparse
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 import numpy as np
 import torch

@@ -4,14 +4,14 @@
 its output (`store`), and every residual block rounds the stream it hands on (`stream`), then compares the decoded
 picture with the pure-fp32 oracle.  Formats: f32, bf16, f16.
 
-    python tools/precision_sim.py --size 256 --stage vae
+    python tests/devtools/precision_sim.py --size 256 --stage vae
 """
 import argparse
 import os
 import re
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 import torch
 import torch.nn.functional as F

@@ -132,6 +132,25 @@ def test_activation_format_context_is_thread_local():
         kernels.set_act("fp8")
 
 
+def test_only_tests_smoke_and_the_bench_baseline_touch_the_oracle():
+    """oracle/ is test infrastructure: besides tests/, only __graft_entry__.smoke() and bench.py's cpu_baseline functions may
+    import it -- no module of the package, no script under tools/."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", flags=re.M)
+    for sub in ("onedc_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh")):
+                    assert not pat.search(open(os.path.join(dirpath, f)).read()), f"{sub}/{f} imports the oracle"
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    for m in pat.finditer(bench):                       # every import sits inside a cpu_baseline* / *_oracle_* function
+        head = bench[:m.start()]
+        fn = re.findall(r"^def (\w+)\(", head, flags=re.M)[-1]
+        assert fn.startswith(("cpu_baseline", "_time_oracle", "_oracle_weights", "host_rans_timing")), fn
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    for m in pat.finditer(entry):
+        assert re.findall(r"^def (\w+)\(", entry[:m.start()], flags=re.M)[-1] == "smoke"
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "onedc_amd")):
