@@ -301,9 +301,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    pinned = pin_host_threads(local_rank, world)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)          # before anything else asks the runtime about devices: a rank only ever touches its GPU
     device = torch.device("cuda", local_rank)
+    pinned = pin_host_threads(local_rank, world)
     if world > 1 or args.broadcast_weights:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
