@@ -344,8 +344,12 @@ class MultiHeadAttention:
                         flop_scale=self.d / self.DV, out_bf16=(vt_dtype == torch.bfloat16))
             vt_bs = 0
         else:
-            if kv is None:
-                kv = ContextKV([self], dev)(ctx, ws)[0]
+            if kv is None:                       # stand-alone use: this layer's own projections, packed once
+                if getattr(self, "_own_kv", None) is None:
+                    if self.wk_rows is None:
+                        raise RuntimeError("this cross-attention layer's to_k / to_v live in a shared ContextKV: pass its `kv`")
+                    self._own_kv = ContextKV([self], dev)
+                kv = self._own_kv(ctx, ws)[0]
             k_t, k_rs, vt, vt_bs = kv
             q = self.q(x)
             q_t, q_rs = q.t, HDQ
