@@ -43,12 +43,19 @@ class Workspace:
         """A buffer that is zero when it is made and never re-zeroed: for tensors whose writers always touch the SAME
         positions and whose other positions must read as zero (the padding keys of V^T).  The caller puts everything that
         decides the layout into `name`, so a buffer is never shared between two layouts."""
-        key = (torch.cuda.current_stream(self.device).cuda_stream, name)
+        key = (torch.cuda.current_stream(self.device).cuda_stream, "zeros", name)
         t = self._t.get(key)
         if t is None or t.numel() != n or t.dtype != dtype:
+            # a service that sees many picture sizes must not collect one buffer per layout for ever: keep the most
+            # recently made MAX_ZERO_LAYOUTS per stream (a dropped one is simply zeroed again when its layout returns)
+            mine = [k for k in self._t if len(k) == 3 and k[0] == key[0]]
+            for k in mine[:max(0, len(mine) + 1 - self.MAX_ZERO_LAYOUTS)]:
+                del self._t[k]
             t = torch.zeros(max(n, 1), dtype=dtype, device=self.device)
             self._t[key] = t
         return t
+
+    MAX_ZERO_LAYOUTS = 24
 
 
 USE_UPSAMPLE_PHASES = True    # tests switch it off to compare with the plain fused-upsample path
