@@ -48,9 +48,10 @@ class Workspace:
         if t is None or t.numel() != n or t.dtype != dtype:
             # a service that sees many picture sizes must not collect one buffer per layout for ever: keep the most
             # recently made MAX_ZERO_LAYOUTS per stream (a dropped one is simply zeroed again when its layout returns)
-            mine = [k for k in self._t if len(k) == 3 and k[0] == key[0]]
+            # (list(dict) is one atomic call: the pipeline's stream threads share this object)
+            mine = [k for k in list(self._t) if len(k) == 3 and k[0] == key[0]]
             for k in mine[:max(0, len(mine) + 1 - self.MAX_ZERO_LAYOUTS)]:
-                del self._t[k]
+                self._t.pop(k, None)
             t = torch.zeros(max(n, 1), dtype=dtype, device=self.device)
             self._t[key] = t
         return t
