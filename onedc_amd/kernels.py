@@ -288,6 +288,7 @@ def from_nchw(x, dtype=None, cs=None, pad_to=None):
 
 
 PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then bracketed by HIP events
+PROFILE_ONLY = None   # ... or, with a set of kernel-family names here, only the launches the dispatcher sends to those
 
 
 PROFILE_EVENT_KW = {}     # {"external": True} when the profiled launches are captured into a HIP graph
@@ -347,7 +348,7 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
             xn = new_view(x.B, x.H, x.W, x.C, x.t.device)
             group_norm(x, gamma, beta, xn, eps, silu, ws)
             p.x, p.x_cs, p.x_co = xn.ptr, xn.cs, xn.co
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and conv_kernel_name(p) not in PROFILE_ONLY):
         _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
         return y
     e0, e1 = torch.cuda.Event(enable_timing=True, **PROFILE_EVENT_KW), torch.cuda.Event(enable_timing=True, **PROFILE_EVENT_KW)
