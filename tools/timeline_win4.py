@@ -102,3 +102,20 @@ span = order[-1] - ks_rt.min()
 print(f"launch spans {span / 100:.1f} us = {span / T:.1f} workgroup times for {blocks / slots:.1f} rounds")
 hist, _ = np.histogram((order - order[0]) % T, bins=16, range=(0, T))
 print("K-loop end times modulo the workgroup time, 16 bins (flat = desynchronised):", hist.tolist())
+
+# ---- how long does a CU slot sit empty between two workgroups? -----------------------------------------------------------
+# consecutive workgroups on the same (CU, wave slot): entry stamp of the next minus end stamp of the previous (s_memtime of one
+# CU: one clock domain).  What a persistent loop over tiles could recover at most (before what its vmcnt ordering costs).
+gaps = []
+for c in np.unique(cu_key):
+    idx = np.where(cu_key == c)[0]
+    for s in (0, 1):
+        me = idx[(wave_id[idx] & 1) == s]
+        if len(me) < 3:
+            continue
+        me = me[np.argsort(st[me])]
+        g = st[me][1:] - en[me][:-1]
+        gaps.extend(g[(g > -1000) & (g < 100000)].tolist())
+gaps = np.asarray(gaps, dtype=np.float64)
+print(f"empty slot time between consecutive workgroups of a CU slot: median {np.median(gaps):.0f} cycles, mean {gaps.mean():.0f}, "
+      f"p90 {np.percentile(gaps, 90):.0f}  ({100 * gaps.mean() / (gaps.mean() + np.mean(t3 - t0)):.1f} % of a slot's time)")
