@@ -58,6 +58,11 @@ class Workspace:
 
     MAX_ZERO_LAYOUTS = 24
 
+    def drop_stream(self, cuda_stream):
+        """Forget the scratch tensors of one HIP stream (a DecodePipeline that is closed never launches on its streams again)."""
+        for k in [k for k in list(self._t) if k[0] == cuda_stream]:
+            self._t.pop(k, None)
+
 
 USE_UPSAMPLE_PHASES = True    # tests switch it off to compare with the plain fused-upsample path
 

@@ -476,6 +476,16 @@ class DecodePipeline:
         self._worker.join(timeout=10)
         for t in self._s_workers:
             t.join(timeout=10)
+        # the layers keep scratch tensors per HIP stream (layers.Workspace): this pipeline's streams are not used again
+        m = self.model
+        owners = [m.feedforward_model, m.vae_large, m.codec_model, getattr(m, "vae_encoder", None),
+                  getattr(getattr(m.codec_model, "enc", None), "unet", None)]
+        for st in [self.stream_e] + self.streams_s:
+            st.synchronize()
+            for o in owners:
+                ws = getattr(o, "ws", None)
+                if ws is not None:
+                    ws.drop_stream(st.cuda_stream)
 
 
 class _VaeGate:

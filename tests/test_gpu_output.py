@@ -171,3 +171,37 @@ def test_quality_metrics_on_device_tensors(model):
     u = model.decode(stream=blobs, out="u8").permute(0, 3, 1, 2).float() / 255.0
     p = Q.psnr(f, u)
     assert p > 10 * math.log10(12 * 255 ** 2) - 1.5, p
+
+
+def test_pipeline_with_mixed_picture_sizes_is_stable(model):
+    """A service sees batches of different sizes back to back: six (batch, size) combinations in shuffled order through ONE
+    pipeline, four rounds, 8-bit pictures in host memory -- every picture equals the sequential decode's, neither the device
+    memory held between rounds nor the workspaces' zero-once buffers grow from round to round, and closing the pipeline
+    releases its streams' scratch tensors."""
+    from onedc_amd.layers import Workspace
+    rng = np.random.default_rng(0)
+    sets = []
+    for i, (B, zh, zw) in enumerate([(4, 3, 3), (2, 2, 3), (5, 2, 2), (3, 3, 2), (1, 4, 4), (4, 3, 3)]):
+        idx = torch.from_numpy(rng.integers(0, 16384, (B, zh, zw)).astype(np.int32)).to(DEV)
+        sets.append(model.codec_model.encode_latents(idx, None, noise_seed=60 + i)[0])
+    ref = [model.decode(stream=s, out="u8").cpu() for s in sets]
+    pipe = model.pipeline()
+    ids = {st.cuda_stream for st in pipe.streams_s} | {pipe.stream_e.cuda_stream}
+    held = []
+    try:
+        for rnd in range(4):
+            order = rng.permutation(len(sets))
+            outs = pipe.map([sets[i] for i in order], out="u8", to_host=True)
+            for i, o in zip(order, outs):
+                assert torch.equal(o, ref[i]), (rnd, i)
+            del outs
+            torch.cuda.synchronize()
+            held.append(torch.cuda.memory_allocated())            # what is still held when a round is over
+        per_stream = [sum(1 for k in model.feedforward_model.ws._t if len(k) == 3 and k[0] == i) for i in ids]
+        assert 0 < max(per_stream) <= Workspace.MAX_ZERO_LAYOUTS, per_stream
+    finally:
+        pipe.close()
+    print(f"[mixed sizes] device memory held after rounds 0..3: {[round(h / 1e6) for h in held]} MB")
+    assert held[-1] <= held[1] + 128e6, held                      # (the workspaces reach their sizes in rounds 0 / 1)
+    for ws in (model.feedforward_model.ws, model.vae_large.ws, model.codec_model.ws):
+        assert not any(k[0] in ids for k in ws._t)                # a closed pipeline leaves nothing behind
