@@ -205,3 +205,30 @@ def test_pipeline_with_mixed_picture_sizes_is_stable(model):
     assert held[-1] <= held[1] + 128e6, held                      # (the workspaces reach their sizes in rounds 0 / 1)
     for ws in (model.feedforward_model.ws, model.vae_large.ws, model.codec_model.ws):
         assert not any(k[0] in ids for k in ws._t)                # a closed pipeline leaves nothing behind
+
+
+def test_pipeline_survives_a_corrupt_stream(model):
+    """One damaged container in the middle of a call: map() raises the decoder's own error for it (never a picture), and the
+    same pipeline decodes the next call correctly -- its worker threads and streams are not left in a broken state."""
+    from onedc_amd.codec_module import StreamDesyncError
+    good = _streams(model, 3, 71)
+    ref = model.decode(stream=good, out="u8").cpu()
+    bad = list(good)
+    blob = bytearray(bad[1])
+    for k in range(40, 60):                       # inside the y stream (16-byte header first): flips symbols -> desynchronises
+        blob[k] ^= 0x5A
+    bad[1] = bytes(blob)
+    pipe = model.pipeline()
+    try:
+        with pytest.raises(StreamDesyncError) as ei:
+            pipe.map([good, bad, good], out="u8")
+        assert ei.value.images == [1]
+        with pytest.raises(StreamDesyncError):
+            model.decode(stream=bad)
+        truncated = [good[0][:len(good[0]) // 2]] + good[1:]
+        with pytest.raises((StreamDesyncError, ValueError, RuntimeError)):
+            pipe.map([truncated], out="u8")
+        again = pipe.map([good, good], out="u8")
+        assert torch.equal(again[0].cpu(), ref) and torch.equal(again[1].cpu(), ref)
+    finally:
+        pipe.close()
