@@ -226,6 +226,25 @@ def test_mxfp8_up3_at_the_random_init_point(model, fullsize_pair):
     assert not torch.equal(img, whole) and abs(p - R.psnr(whole, ref_img)) < 1.0
 
 
+@pytest.mark.parametrize("B,zh,zw", [(1, 1, 1), (3, 1, 2), (2, 2, 1), (1, 1, 5)])
+def test_smallest_pictures_match_the_oracle(model_trained, oracle_weights_trained, B, zh, zw):
+    """The other end of the size range (the reference decodes any multiple of 64, src/modules/entropy/utils.py:7-16): 64x64 --
+    a 1x1 FSQ map, a 1x1 UNet bottom level, single-token attention, a VAE window larger than the map -- 64x128, 128x64, 64x320:
+    every layer takes a fallback kernel here.  Product vs oracle from the same latents."""
+    idx = torch.from_numpy(np.random.default_rng(zh * 10 + zw).integers(0, 16384, (B, zh, zw)).astype(np.int32)).to(DEV)
+    blobs, y_hat = model_trained.codec_model.encode_latents(idx, None, noise_seed=5)
+    img = model_trained.decode(stream=blobs, unit_range=True).cpu()
+    assert img.shape == (B, 3, 64 * zh, 64 * zw)
+    codec_sd, unet_sd, vae_sd = oracle_weights_trained
+    with torch.no_grad():
+        _, z_sem = R.z_indices_to_params(codec_sd, idx.cpu())
+        ref = R.to_unit_range(R.decode_from_latents(codec_sd, unet_sd, vae_sd, y_hat.torch_nchw().cpu(), z_sem)["image"])
+    p = R.psnr(img, ref)
+    print(f"[tiny] {B} x {64 * zh}x{64 * zw}: PSNR(product, oracle) = {p:.2f} dB")
+    assert p >= MIN_PSNR_TRAINED_DB_BY_ACT[K.act()] - 1.0            # measured 65.6 .. 66.6 dB (f16)
+    assert torch.equal(model_trained.decode(stream=blobs[:1], unit_range=True).cpu()[0], img[0])
+
+
 def test_other_format_library_at_full_size(fullsize_pair, oracle_weights):
     """The library of the OTHER 16-bit format in the same process (bf16 when the run's default is f16: the documented
     fallback for an f16 range overflow, `act_dtype: bf16`) on the same two 768x768 streams: stages within that format's
