@@ -243,6 +243,28 @@ int onedc_patchify8(const float *x, int x_cs, void *y, int B, int H, int W, void
 /* latent_dist.sample() * scaling_factor: moments f32 [n][8], noise f32 [n][4] or NULL (mode) -> f32 [n][4] */
 int onedc_latent_sample(const float *moments, const float *noise, float *out, int64_t n, float scale, void *stream);
 
+/* ---- the prior networks in the reference's CPU arithmetic (compatibility path; csrc/ref_arith.hip) ------------------------
+ * torch-CPU's f32 convolutions are fixed arrangements of fused-multiply-add chains (measured: DESIGN.md section 5); these entry
+ * points evaluate the same chains with v_fma_f32, so that a prior built from them takes the table-index decisions of the
+ * reference that wrote a stream (compression_model.py:369-407, entropy_models.py:355-362).  All tensors f32, NHWC views.
+ *   onedc_ref_conv1x1   y = act(conv1x1(x)) [+ res]: wT [C][OC] (transposed weights); input channels in blocks of `blk`: the
+ *                       first block one chain that starts from the bias (bias_first) or from 0, later blocks chains from 0
+ *                       added in order, the bias last when !bias_first.  act 0 none, 1 LeakyReLU(slope), 2 ConvFFN3's gate
+ *                       LeakyReLU(rows n, slope) + LeakyReLU(rows n + OC/2, slope2) (dcvc.py:353-367: OC/2 outputs);
+ *                       shuffle = 1 stores through F.pixel_shuffle(., 2) (dcvc.py:183-208; y is the (2H, 2W) map, no res)
+ *   onedc_ref_conv3x3   dense 3x3, pad 1: bias + per 16 input channels a chain from 0 over (ky, kx, channel); w3T [9][C][OC];
+ *                       y = [LeakyReLU(slope)](.) [+ res]
+ *   onedc_ref_prior_indexes  build_indexes with the writer's logarithm: index = number of thresholds <= sigma
+ *                       (thresholds: f32 [n], ascending, found by the host by bisection over torch.log) */
+int onedc_ref_conv1x1(const float *x, int x_cs, int x_co, const float *wT, const float *bias, const float *res, int r_cs,
+                      int r_co, float *y, int y_cs, int y_co, int64_t pixels, int C, int OC, int blk, int bias_first,
+                      int act, float slope, float slope2, int shuffle, int H, int W, void *stream);
+int onedc_ref_conv3x3(const float *x, int x_cs, int x_co, const float *w3T, const float *bias, const float *res, int r_cs,
+                      int r_co, float *y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int leaky_on, float slope,
+                      void *stream);
+int onedc_ref_prior_indexes(const float *params, const float *thresholds, int n_thresholds, int16_t *indexes, int B, int H,
+                            int W, int C, int step, void *stream);
+
 /* MXFP8 experiment (reference call the layers belong to: model_sd15_with_codec_stage1.py:184-188): quantise every
  * block of 32 consecutive channels of every pixel to OCP e4m3 with one shared power-of-two scale (OCP MX v1.0: what
  * v_mfma_scale_f32_16x16x128_f8f6f4 consumes along K) and write the values back dequantised, 16 bit -> 16 bit.  A conv that

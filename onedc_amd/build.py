@@ -88,8 +88,10 @@ def build_coder(force=False):
 # on one box: window kernel with GroupNorm on load 128->128 at 768x768 3.47 -> 3.38 ms, 256->128 5.80 -> 5.57; GEGLU
 # 320->2560 422 -> 410 us; d = 80 attention 0.951 -> 0.874 ms; everything else within noise.
 _NO_SLP = ("-fno-slp-vectorize",)
+# ref_arith.hip reproduces torch-CPU's rounding sequence: a multiply followed by an add must stay two roundings (the chains
+# themselves are explicit fmaf calls)
 FILE_FLAGS = {"attention.hip": ("-fno-honor-nans",) + _NO_SLP, "gemm_conv_win.hip": _NO_SLP, "gemm_conv_win4.hip": _NO_SLP, "gemm_conv.hip": _NO_SLP,
-              "gemm_conv256.hip": _NO_SLP, "gemm_conv_ups.hip": _NO_SLP}
+              "gemm_conv256.hip": _NO_SLP, "gemm_conv_ups.hip": _NO_SLP, "ref_arith.hip": ("-ffp-contract=off",)}
 
 
 def hip_sources():

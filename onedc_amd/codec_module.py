@@ -147,15 +147,26 @@ class Decoder:
 
 class IntraNoAR:
     def __init__(self, sd, device, bottleneck_ch=128, semantic_ch=768, z_fsq_levels=(4,) * 7, host_threads=None,
-                 prior_f32=True):
+                 prior_f32=True, prior_arith="mfma"):
         """prior_f32: run everything that feeds the integer decisions of the entropy coder (hyper
         decoder, prior fusion, the four-part prior's nets: 36 GFLOP of the 8047 per 768x768 picture)
         in exact f32 on the f32 matrix-core path, like the reference's CPU path; False = bf16 MFMA
-        like the reference under GPU autocast (SURVEY hard part 2)."""
+        like the reference under GPU autocast (SURVEY hard part 2).
+        prior_arith: "mfma" (default: this package's own prior, encoder and decoder side alike) or "torch_cpu": the prior
+        networks evaluated in the REFERENCE'S CPU arithmetic -- the fused-multiply-add chains torch-CPU's convolutions are
+        made of, calibrated against the local torch (onedc_amd/ref_arith.py) -- so that y streams written by the reference
+        decode here, and streams written here in this mode decode there.  ~10x slower prior; pictures above ~0.16 MP."""
         self.device = device
         self.act = K.act()                 # the format the weights below are packed in
         self.N = N = bottleneck_ch
         self.prior_f32 = f32 = bool(prior_f32)
+        if prior_arith not in ("mfma", "torch_cpu"):
+            raise ValueError(f"prior_arith must be 'mfma' or 'torch_cpu', not {prior_arith!r}")
+        self.prior_arith = prior_arith
+        self.ref_prior = None
+        if prior_arith == "torch_cpu":
+            from .ref_arith import ReferencePrior
+            self.ref_prior = ReferencePrior(sd, device, N)
         self.hyper_dec = HyperDecoder(sd, device, f32=f32)
         self.y_prior_fusion = [DepthConvBlock4(sd, f"y_prior_fusion.{i}", device, f32) for i in range(2)]
         self.y_spatial_prior_reduction = Conv(sd, "y_spatial_prior_reduction", device, f32=f32)
@@ -191,6 +202,8 @@ class IntraNoAR:
     @K.in_own_format
     def _params_from_indices(self, indices):
         """indices: int32 device tensor (B, h, w) -> (fused params f32 View (B,4h,4w,2N), z_semantic)."""
+        if self.ref_prior is not None:
+            return self.ref_prior.params_from_indices(indices)
         B, h, w = indices.shape
         codes = View(torch.empty(B * h * w * 8, dtype=torch.float32, device=self.device), B, h, w, 8)
         K.fsq_codes(indices.contiguous(), codes.t)
@@ -202,6 +215,8 @@ class IntraNoAR:
     @K.in_own_format
     def _next_params(self, k, y_hat, common_cat):
         """(scales, means) of step k >= 1 from y_hat_so_far and the reduced common params."""
+        if self.ref_prior is not None:
+            return self.ref_prior.next_params(k, common_cat)
         if not self.prior_f32:
             K.copy_channels(y_hat, common_cat.slice(0, self.N))           # f32 -> bf16 into the cat buffer
         a = self.y_spatial_prior_adaptor[k - 1](common_cat)
@@ -212,6 +227,8 @@ class IntraNoAR:
     @K.in_own_format
     def _prior_setup(self, fused):
         B, H, W, N = fused.B, fused.H, fused.W, self.N
+        if self.ref_prior is not None:
+            return self.ref_prior.prior_setup(fused)
         if self.prior_f32:
             # [y_hat_so_far | common] is ONE f32 buffer: y_hat is its first channel slice, so
             # torch.cat((y_hat_so_far, common_params)) (compression_model.py:387) costs nothing
@@ -252,7 +269,7 @@ class IntraNoAR:
         for k in range(4):
             if k > 0:
                 params = self._next_params(k, y_hat, common_cat)
-            K.prior_indexes(params, idx_dev, B, H, W, N, k)
+            self._prior_indexes(params, idx_dev, B, H, W, k)
             idx_host.copy_(idx_dev.view(B, n), non_blocking=True)
             torch.cuda.current_stream().synchronize()
             try:
@@ -269,6 +286,13 @@ class IntraNoAR:
             if bad:
                 raise StreamDesyncError(bad)
         return y_hat, z_semantic
+
+    def _prior_indexes(self, params, idx_dev, B, H, W, k):
+        """build_indexes of hop k (entropy_models.py:355-362): with this package's logarithm, or -- prior_arith "torch_cpu" --
+        through thresholds taken from the reference's own (torch-CPU) logarithm."""
+        if self.ref_prior is not None:
+            return self.ref_prior.indexes(params, idx_dev, B, H, W, k)
+        return K.prior_indexes(params, idx_dev, B, H, W, self.N, k)
 
     def _pinned(self, B, n):
         """Page-locked staging buffers of the rANS hops, one pair per (thread, shape), allocated once."""
@@ -455,7 +479,7 @@ class IntraNoAR:
                 y_k = y_k.contiguous()
             else:
                 y_k = y
-            K.prior_indexes(params, idx_dev, B, H, W, N, k)
+            self._prior_indexes(params, idx_dev, B, H, W, k)
             K.prior_update_enc(params, y_k, sym_dev, y_hat, k)
             torch.cuda.current_stream().synchronize()
             rans.encode_batch(encoders, sym_dev.view(B, n).cpu().numpy(), idx_dev.view(B, n).cpu().numpy(), 0,

@@ -123,6 +123,9 @@ SIGNATURES = {
     "onedc_window_partition": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
     "onedc_mxfp8_roundtrip": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "onedc_ref_conv1x1": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _L, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P]),
+    "onedc_ref_conv3x3": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_ref_prior_indexes": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
     "onedc_hip_version": (C.c_char_p, []),
     "onedc_hip_act_format": (C.c_char_p, []),
@@ -550,6 +553,31 @@ def window_partition(x, y, B, H, W, Cc, win, reverse=False, region=None, win_hw=
     _ok(lib().onedc_window_partition(x.data_ptr(), y.data_ptr(), B, H, W, Cc, y0, x0, RH, RW, wh, ww,
                                      int(reverse), stream()), "onedc_window_partition")
     return y
+
+
+def ref_conv1x1(x, wT, bias, y, *, blk, bias_first, act=0, slope=0.01, slope2=0.01, res=None, shuffle=False):
+    """Reference-arithmetic 1x1 conv (csrc/ref_arith.hip): x, y, res f32 Views; wT f32 [C][OC]; y = act(chains) [+ res]."""
+    C, OC = wT.shape
+    _ok(lib().onedc_ref_conv1x1(x.ptr, x.cs, x.co, wT.data_ptr(), _ptr(bias), (res.ptr if res is not None else None),
+                                (res.cs if res is not None else 0), (res.co if res is not None else 0), y.ptr, y.cs, y.co,
+                                x.B * x.H * x.W, C, OC, int(blk), int(bool(bias_first)), int(act), slope, slope2,
+                                int(bool(shuffle)), x.H, x.W, stream()), "onedc_ref_conv1x1")
+    return y
+
+
+def ref_conv3x3(x, w3T, bias, y, *, leaky=None, res=None):
+    """Reference-arithmetic dense 3x3 conv: w3T f32 [9][C][OC]; y = [LeakyReLU(leaky)](bias + block chains) [+ res]."""
+    _, C, OC = w3T.shape
+    _ok(lib().onedc_ref_conv3x3(x.ptr, x.cs, x.co, w3T.data_ptr(), _ptr(bias), (res.ptr if res is not None else None),
+                                (res.cs if res is not None else 0), (res.co if res is not None else 0), y.ptr, y.cs, y.co,
+                                x.B, x.H, x.W, C, OC, int(leaky is not None), float(leaky or 0.0), stream()), "onedc_ref_conv3x3")
+    return y
+
+
+def ref_prior_indexes(params, thresholds, indexes, B, H, W, Cc, step):
+    _ok(lib().onedc_ref_prior_indexes(params.ptr, thresholds.data_ptr(), thresholds.numel(), indexes.data_ptr(), B, H, W, Cc,
+                                      step, stream()), "onedc_ref_prior_indexes")
+    return indexes
 
 
 def mxfp8_roundtrip(x, y):

@@ -1,0 +1,254 @@
+"""The prior networks in the reference's CPU arithmetic, on the GPU (compatibility path, `IntraNoAR(prior_arith="torch_cpu")`).
+
+Why: a y stream can only be decoded by a prior that takes every table-index decision its writer took (reference
+src/modules/entropy/compression_model.py:369-407; build_indexes truncates: entropy_models.py:355-362).  The reference's
+writer is torch-CPU fp32, and its convolutions turn out to be fixed arrangements of fused-multiply-add chains (measured;
+DESIGN.md section 5, csrc/ref_arith.hip has the list).  The kernels of csrc/ref_arith.hip evaluate those chains with
+v_fma_f32; this module
+
+  * holds the prior-side layers (HyperDecoder, y_prior_fusion, y_spatial_prior_reduction, the three adaptors, y_spatial_prior:
+    reference src/models/sd15_onedc_codec_stage1/codec_module.py:145-166, 205-217) on those kernels,
+  * CALIBRATES them: which block length R and which bias position torch-CPU uses for a 1x1 convolution depends on the layer
+    shape, the map size and torch's thread count (oneDNN's blocking heuristics, torch's use_mkldnn rule), so for every
+    (C, OC, H, W) it meets, `Calibration` runs that convolution once on random data with the LOCAL torch-CPU and takes the
+    (R, bias position) whose GPU result is bit-identical; dense 3x3 and depthwise layers have one known structure that is
+    checked the same way.  A shape nothing reproduces (a dense 3x3 on a map of <= 20 480 elements goes through MKL's sgemm,
+    whose order is not a chain) raises `ReferenceArithmeticUnavailable`: pictures under ~0.16 megapixels,
+  * builds the index thresholds from torch's own logarithm.
+
+The calibration describes the torch of THIS host at its CURRENT thread count (`torch.get_num_threads()`): a stream decodes
+when its writer ran the same configuration class -- e.g. the reference on an AVX-512 CPU with 2-8 threads, which is what wrote
+tests/golden/g8_* / g9_*; `torch.set_num_threads(1)` before building calibrates for the single-threaded reference harness
+(src/inference.py:29).  Streams of this package's own encoder do not need any of this (exact-f32 MFMA prior on both sides).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .kernels import View, new_view
+
+
+class ReferenceArithmeticUnavailable(RuntimeError):
+    pass
+
+
+def _v(B, H, W, C, device):
+    return new_view(B, H, W, C, device, torch.float32)
+
+
+class Calibration:
+    """(block length, bias first) of torch-CPU's 1x1 convolution per (C, OC, H, W), found by trial against the local torch."""
+
+    def __init__(self, device):
+        self.device = device
+        self.table = {}
+        self.checked = set()
+        self.threads = torch.get_num_threads()
+
+    def _rand(self, C, OC, H, W, k, groups=1):
+        g = torch.Generator().manual_seed(C * 131 + OC * 7 + H)
+        x = torch.randn(1, C, H, W, generator=g)
+        w = torch.randn(OC, C // groups, k, k, generator=g) / math.sqrt(C * k * k / groups)
+        b = torch.randn(OC, generator=g) * 0.05
+        return x, w, b
+
+    def conv1x1(self, C, OC, H, W):
+        key = (C, OC, H, W)
+        if key in self.table:
+            return self.table[key]
+        x, w, b = self._rand(C, OC, H, W, 1)
+        with torch.no_grad():
+            ref = torch.nn.functional.conv2d(x, w, b)[0].permute(1, 2, 0).contiguous()             # (H, W, OC)
+        dev = self.device
+        cs = (C + 3) // 4 * 4
+        xv = _v(1, H, W, cs, dev)
+        xv.t[:H * W * cs].view(H, W, cs)[..., :C] = x[0].permute(1, 2, 0).to(dev)
+        xv = xv.slice(0, C)
+        wT = w.reshape(OC, C).t().contiguous().to(dev)
+        bd = b.to(dev)
+        yv = _v(1, H, W, OC, dev)
+        found = None
+        for bias_first in (1, 0):
+            for blk in sorted(set([C] + list(range(16, C, 16))), reverse=True):
+                K.ref_conv1x1(xv, wT, bd, yv, blk=blk, bias_first=bias_first)
+                if torch.equal(yv.t[:H * W * OC].view(H, W, OC).cpu(), ref):
+                    found = (blk, bias_first)
+                    break
+            if found:
+                break
+        if found is None:
+            raise ReferenceArithmeticUnavailable(
+                f"no fma-chain structure reproduces torch-CPU's 1x1 convolution {C}->{OC} on a {H}x{W} map with "
+                f"{self.threads} thread(s) on this host")
+        self.table[key] = found
+        return found
+
+    def check_conv3x3(self, C, OC, H, W):
+        key = ("3x3", C, OC, H, W)
+        if key in self.checked:
+            return
+        x, w, b = self._rand(C, OC, H, W, 3)
+        with torch.no_grad():
+            ref = torch.nn.functional.conv2d(x, w, b, padding=1)[0].permute(1, 2, 0).contiguous()
+        dev = self.device
+        xv = _v(1, H, W, C, dev)
+        xv.t[:H * W * C].view(H, W, C).copy_(x[0].permute(1, 2, 0))
+        yv = _v(1, H, W, OC, dev)
+        K.ref_conv3x3(xv, w.permute(2, 3, 1, 0).reshape(9, C, OC).contiguous().to(dev), b.to(dev), yv)
+        if not torch.equal(yv.t[:H * W * OC].view(H, W, OC).cpu(), ref):
+            raise ReferenceArithmeticUnavailable(
+                f"torch-CPU's dense 3x3 convolution {C}->{OC} on a {H}x{W} map does not follow oneDNN's direct kernel here "
+                f"(maps of <= 20 480 elements go through aten's im2col + MKL sgemm, whose summation is not a chain): pictures "
+                f"under ~0.16 megapixels cannot be decoded in the reference's arithmetic")
+        self.checked.add(key)
+
+    def check_dw3x3(self, C, H, W):
+        key = ("dw", C, H, W)
+        if key in self.checked:
+            return
+        x, w, b = self._rand(C, C, H, W, 3, groups=C)
+        with torch.no_grad():
+            ref = torch.nn.functional.conv2d(x, w, b, padding=1, groups=C)[0].permute(1, 2, 0).contiguous()
+        dev = self.device
+        xv = _v(1, H, W, C, dev)
+        xv.t[:H * W * C].view(H, W, C).copy_(x[0].permute(1, 2, 0))
+        yv = _v(1, H, W, C, dev)
+        K.dwconv3x3(xv, w[:, 0].permute(1, 2, 0).reshape(9, -1).contiguous().to(dev), b.to(dev), yv)
+        if not torch.equal(yv.t[:H * W * C].view(H, W, C).cpu(), ref):
+            raise ReferenceArithmeticUnavailable(f"torch-CPU's depthwise 3x3 convolution ({C} channels, {H}x{W}) is not the "
+                                                 f"bias-first row-major chain on this host")
+        self.checked.add(key)
+
+
+def index_thresholds(scale_min=0.11, scale_max=64.0, levels=256):
+    """thresholds[i] = the smallest f32 sigma whose index under the reference's build_indexes (entropy_models.py:355-362, run
+    with the local torch-CPU) is >= i + 1; index(sigma) = #{i : thresholds[i] <= sigma}.  Bisection over the bit patterns of
+    positive floats (monotone with the value), all 255 in parallel."""
+    log_min = math.log(scale_min)
+    log_step = (math.log(scale_max) - log_min) / (levels - 1)
+
+    def index(s):
+        s = torch.maximum(s, torch.zeros_like(s) + 1e-5)
+        return ((torch.log(s) - log_min) / log_step).clamp_(0, levels - 1).int()
+
+    want = torch.arange(1, levels, dtype=torch.int32)
+    lo = torch.full((levels - 1,), np.float32(1e-6).view(np.int32).item(), dtype=torch.int32)       # index 0 for sure
+    hi = torch.full((levels - 1,), np.float32(128.0).view(np.int32).item(), dtype=torch.int32)      # index 255 for sure
+    with torch.no_grad():
+        while int((hi - lo).max()) > 1:
+            mid = lo + (hi - lo) // 2
+            ok = index(mid.view(torch.float32)) >= want
+            hi = torch.where(ok, mid, hi)
+            lo = torch.where(ok, lo, mid)
+        thr = hi.view(torch.float32)
+        assert bool((index(thr) >= want).all()) and bool((index(lo.view(torch.float32)) < want).all())
+    return thr.contiguous()
+
+
+class _Conv1x1:
+    def __init__(self, sd, name, device, cal):
+        w = sd[f"{name}.weight"].float()
+        self.OC, self.C = w.shape[0], w.shape[1]
+        self.wT = w.reshape(self.OC, self.C).t().contiguous().to(device)
+        b = sd.get(f"{name}.bias")
+        self.b = None if b is None else b.float().contiguous().to(device)
+        self.cal, self.device = cal, device
+
+    def __call__(self, x, y=None, *, act=0, slope=0.01, slope2=0.01, res=None, shuffle=False):
+        blk, bias_first = self.cal.conv1x1(self.C, self.OC, x.H, x.W)
+        if y is None:
+            c = self.OC // 2 if act == 2 else self.OC
+            y = _v(x.B, 2 * x.H, 2 * x.W, c // 4, self.device) if shuffle else _v(x.B, x.H, x.W, c, self.device)
+        return K.ref_conv1x1(x, self.wT, self.b, y, blk=blk, bias_first=bias_first, act=act, slope=slope, slope2=slope2,
+                             res=res, shuffle=shuffle)
+
+
+class _DCB4:
+    """DepthConvBlock4 (dcvc.py:424-433) in the reference's arithmetic."""
+
+    def __init__(self, sd, p, device, cal):
+        self.cal, self.device = cal, device
+        self.conv1 = _Conv1x1(sd, f"{p}.block.0.conv1.0", device, cal)
+        w = sd[f"{p}.block.0.depth_conv.weight"].float()
+        self.dw_w = w[:, 0].permute(1, 2, 0).reshape(9, -1).contiguous().to(device)
+        self.dw_b = sd[f"{p}.block.0.depth_conv.bias"].float().contiguous().to(device)
+        self.conv2 = _Conv1x1(sd, f"{p}.block.0.conv2", device, cal)
+        self.adaptor = _Conv1x1(sd, f"{p}.block.0.adaptor", device, cal) if f"{p}.block.0.adaptor.weight" in sd else None
+        self.ffn_in = _Conv1x1(sd, f"{p}.block.1.conv", device, cal)
+        self.ffn_out = _Conv1x1(sd, f"{p}.block.1.conv_out", device, cal)
+
+    def __call__(self, x, y=None):
+        self.cal.check_dw3x3(x.C, x.H, x.W)
+        identity = self.adaptor(x) if self.adaptor is not None else x
+        t = self.conv1(x, act=1, slope=0.01)
+        t2 = K.dwconv3x3(t, self.dw_w, self.dw_b, _v(t.B, t.H, t.W, t.C, self.device))
+        h = self.conv2(t2, res=identity)
+        u = self.ffn_in(h, act=2, slope=0.1, slope2=0.01)
+        return self.ffn_out(u, y, res=h)
+
+
+class _RBU:
+    """ResidualBlockUpsample (dcvc.py:183-208) in the reference's arithmetic."""
+
+    def __init__(self, sd, p, device, cal):
+        self.cal, self.device = cal, device
+        self.subpel = _Conv1x1(sd, f"{p}.subpel_conv.0", device, cal)
+        self.upsample = _Conv1x1(sd, f"{p}.upsample.0", device, cal)
+        w = sd[f"{p}.conv.weight"].float()
+        self.OC, self.C = w.shape[0], w.shape[1]
+        self.w3T = w.permute(2, 3, 1, 0).reshape(9, self.C, self.OC).contiguous().to(device)
+        self.b3 = sd[f"{p}.conv.bias"].float().contiguous().to(device)
+
+    def __call__(self, x):
+        t = self.subpel(x, act=1, slope=0.01, shuffle=True)
+        identity = self.upsample(x, shuffle=True)
+        self.cal.check_conv3x3(self.C, self.OC, t.H, t.W)
+        return K.ref_conv3x3(t, self.w3T, self.b3, _v(t.B, t.H, t.W, self.OC, self.device), leaky=0.1, res=identity)
+
+
+class ReferencePrior:
+    """The prior side of IntraNoAR on the reference-arithmetic kernels: same call surface as the MFMA path's pieces in
+    codec_module.IntraNoAR (`params_from_indices`, `prior_setup`, `next_params`), same f32 NHWC Views out."""
+
+    def __init__(self, sd, device, N=128):
+        self.device, self.N = device, N
+        self.cal = cal = Calibration(device)
+        self.feat_in = _Conv1x1(sd, "hyper_dec.feat_in.0", device, cal)
+        self.hyper = [_DCB4(sd, "hyper_dec.to_entropy.0", device, cal), _RBU(sd, "hyper_dec.to_entropy.1", device, cal),
+                      _DCB4(sd, "hyper_dec.to_entropy.2", device, cal), _RBU(sd, "hyper_dec.to_entropy.3", device, cal),
+                      _DCB4(sd, "hyper_dec.to_entropy.4", device, cal)]
+        self.fusion = [_DCB4(sd, f"y_prior_fusion.{i}", device, cal) for i in range(2)]
+        self.reduction = _Conv1x1(sd, "y_spatial_prior_reduction", device, cal)
+        self.adaptors = [_DCB4(sd, f"y_spatial_prior_adaptor_{i}", device, cal) for i in (1, 2, 3)]
+        self.spatial = [_DCB4(sd, f"y_spatial_prior.{i}", device, cal) for i in range(3)]
+        self.thresholds = index_thresholds().to(device)
+
+    def params_from_indices(self, indices):
+        """indices int32 (B, h, w) -> (fused params f32 View (B, 4h, 4w, 2N), z_semantic 16-bit View)."""
+        B, h, w = indices.shape
+        codes = View(torch.empty(B * h * w * 8 + 8, dtype=torch.float32, device=self.device), B, h, w, 8)
+        K.fsq_codes(indices.contiguous(), codes.t)
+        z = self.feat_in(codes.slice(0, 7), act=1, slope=0.01)
+        x = z
+        for layer in self.hyper:
+            x = layer(x)
+        fused = self.fusion[1](self.fusion[0](x))
+        z16 = K.copy_channels(z, new_view(z.B, z.H, z.W, z.C, self.device))
+        return fused, z16
+
+    def prior_setup(self, fused):
+        B, H, W, N = fused.B, fused.H, fused.W, self.N
+        common_cat = _v(B, H, W, 2 * N, self.device)
+        self.reduction(fused, common_cat.slice(N, N))
+        return common_cat, common_cat.slice(0, N)
+
+    def next_params(self, k, common_cat):
+        a = self.adaptors[k - 1](common_cat)
+        for layer in self.spatial:
+            a = layer(a)
+        return a
+
+    def indexes(self, params, idx_dev, B, H, W, step):
+        return K.ref_prior_indexes(params, self.thresholds, idx_dev, B, H, W, self.N, step)

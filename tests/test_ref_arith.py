@@ -1,0 +1,125 @@
+"""The prior in the reference's CPU arithmetic (IntraNoAR(prior_arith="torch_cpu"); onedc_amd/ref_arith.py, csrc/ref_arith.hip).
+
+torch-CPU's f32 convolutions are fixed arrangements of fused-multiply-add chains (oneDNN jit_1x1 / jit_dw / jit direct, or aten's
+native path); the GPU kernels evaluate the same chains, calibrated against the local torch.  What is asserted:
+
+  * every convolution shape of the prior nets at 768x768 has a structure that reproduces torch-CPU bit for bit (calibration),
+  * the two 768x768 streams written by the REFERENCE's own modules (tests/golden/g8_ref_stream_768.npz random-init weights,
+    g9_ref_stream_768_trained.npz trained-like weights; written under torch-CPU with 8 threads) decode on the GPU:
+    teacher-forced table-index flips [0, 0, 0, 0], free-running decode clean, y_hat equal to the reference's sample points
+    EXACTLY -- where the MFMA prior flips 91 / 6 of the 294 912 decisions and raises StreamDesyncError,
+  * the other direction: a stream this package writes in that mode carries the symbols and table indexes the reference's CPU
+    arithmetic (the oracle on torch-CPU) computes for the same latent -- "identical bitstreams on encode" for the prior side,
+  * index thresholds == torch's build_indexes (CPU test), small pictures are refused, not mis-decoded.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from onedc_amd import synth
+
+
+def test_index_thresholds_equal_torch_build_indexes():
+    """index(sigma) = #{thresholds <= sigma} against the reference's formula (entropy_models.py:355-362) evaluated by torch on
+    the CPU: random sigmas over the table's range and the two floats around every threshold."""
+    from onedc_amd.ref_arith import index_thresholds
+    from oracle import torch_ref as R
+    thr = index_thresholds()
+    assert thr.shape == (255,) and bool((thr[1:] > thr[:-1]).all())
+    g = torch.Generator().manual_seed(0)
+    s = torch.exp(torch.rand(200000, generator=g) * (np.log(80.0) - np.log(0.05)) + np.log(0.05)).float()
+    bits = thr.view(torch.int32)
+    s = torch.cat([s, thr, (bits - 1).view(torch.float32), (bits + 1).view(torch.float32), torch.tensor([-1.0, 0.0, 1e-6, 1e-5, 64.0, 1e3])])
+    want = R.build_indexes(s)
+    got = torch.searchsorted(thr, s, right=True).int()
+    assert torch.equal(got, want)
+
+
+@pytest.fixture(scope="module")
+def eight_threads():
+    prev = torch.get_num_threads()
+    torch.set_num_threads(8)                    # the configuration class that wrote the golden streams (2-8 threads, AVX-512)
+    yield
+    torch.set_num_threads(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,preset", [("g8_ref_stream_768.npz", None), ("g9_ref_stream_768_trained.npz", "trained_like")])
+def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_threads, name, preset):
+    from onedc_amd import kernels as K
+    from onedc_amd.codec_module import IntraNoAR, StreamDesyncError
+    DEV = "cuda:0"
+    g = golden(name)
+    codec = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="torch_cpu")
+    codec.update(force=True)
+    idx = torch.from_numpy(g["indices"]).to(DEV)
+    # teacher-forced: the reference's symbols are fed back, every table-index decision is compared
+    fused, _ = codec._params_from_indices(idx)
+    common_cat, y_hat = codec._prior_setup(fused)
+    B, H, W, N = fused.B, fused.H, fused.W, codec.N
+    n = (N // 4) * H * W
+    idx_dev = torch.empty(B * n, dtype=torch.int16, device=DEV)
+    flips, params = [], fused
+    for k in range(4):
+        if k > 0:
+            params = codec._next_params(k, y_hat, common_cat)
+        codec._prior_indexes(params, idx_dev, B, H, W, k)
+        flips.append(int((idx_dev.view(B, N // 4, H, W).cpu().numpy() != g["index_planes"][k]).sum()))
+        K.prior_update_dec(params, torch.from_numpy(np.ascontiguousarray(g["symbols"][k])).to(DEV).reshape(-1), y_hat, k)
+    print(f"[ref-arith] {name}: teacher-forced table-index flips per hop {flips}; calibrated structures: "
+          f"{dict(sorted(codec.ref_prior.cal.table.items()))}")
+    assert flips == [0, 0, 0, 0]
+    flat = y_hat.torch_nchw().cpu().reshape(-1)
+    assert torch.equal(flat[torch.from_numpy(g["y_hat.idx"])], torch.from_numpy(g["y_hat.val"]))      # bit for bit
+    # free-running: the reference's stream through the whole entropy decode
+    trace = []
+    y2, _ = codec.decompress([g["stream"].tobytes()], idx, trace=trace)
+    assert all(np.array_equal(sy, g["symbols"][k]) for k, (ix, sy) in enumerate(trace))
+    assert torch.equal(y2.torch_nchw(), y_hat.torch_nchw())
+    # the MFMA prior on the same stream: desynchronises (the reason this path exists)
+    mfma = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV)
+    mfma.update(force=True)
+    with pytest.raises(StreamDesyncError):
+        mfma.decompress([g["stream"].tobytes()], idx)
+
+
+@pytest.mark.gpu
+def test_streams_written_in_the_reference_arithmetic_carry_the_references_decisions(eight_threads):
+    """The other direction (BASELINE north_star: "identical bitstreams on encode"): for a given latent y, the encoder side of the
+    prior in torch_cpu mode produces the symbols, the table indexes and therefore the y stream that the reference's CPU
+    arithmetic produces (oracle compress_four_part_prior on torch-CPU + the C port of the coder)."""
+    from onedc_amd.codec_module import IntraNoAR
+    from oracle import rans_port
+    from oracle import torch_ref as R
+    DEV = "cuda:0"
+    sd = synth.codec_state_dict(0, preset="trained_like")
+    codec = IntraNoAR(sd, DEV, prior_arith="torch_cpu")
+    codec.update(force=True)
+    idx = torch.from_numpy(np.random.default_rng(5).integers(0, 16384, (1, 12, 12)).astype(np.int32))
+    with torch.no_grad():
+        fused, _ = R.z_indices_to_params(sd, idx.long())
+        means = fused.chunk(2, 1)[1]
+        y = means + 1.5 * torch.randn(means.shape, generator=torch.Generator().manual_seed(6))
+        y_q_w, s_w, y_hat_ref = R.compress_four_part_prior(sd, y, fused)
+        sym = torch.stack(y_q_w).to(torch.int16).numpy().reshape(-1)
+        planes = torch.stack([R.build_indexes(s) for s in s_w]).to(torch.int16).numpy().reshape(-1)
+    want = rans_port.encode(sym, planes, rans_port.Tables(*codec._tables))
+    blobs, y_hat = codec.encode_latents(idx.to(DEV), y.permute(0, 2, 3, 1).contiguous().to(DEV))
+    from onedc_amd.entropy.utils import decode_i
+    got = decode_i(blobs[0], 14, 64)["bit_stream_y"]
+    assert got == want, (len(got), len(want))
+    assert torch.equal(y_hat.torch_nchw().cpu(), y_hat_ref)
+
+
+@pytest.mark.gpu
+def test_small_pictures_are_refused_not_misdecoded(eight_threads):
+    """128x192: the hyper decoder's dense 3x3 convolutions run on 4x6 / 8x12 maps, which torch sends through im2col + MKL sgemm
+    (not a chain): the calibration says so instead of decoding something else."""
+    from onedc_amd.codec_module import IntraNoAR
+    from onedc_amd.ref_arith import ReferenceArithmeticUnavailable
+    g = golden("g5_codec_path.npz")
+    codec = IntraNoAR(synth.codec_state_dict(0), "cuda:0", prior_arith="torch_cpu")
+    codec.update(force=True)
+    with pytest.raises(ReferenceArithmeticUnavailable):
+        codec.decompress([g["stream"].tobytes()], torch.from_numpy(g["indices"]).to("cuda:0"))
