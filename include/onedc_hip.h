@@ -249,7 +249,7 @@ int onedc_latent_sample(const float *moments, const float *noise, float *out, in
  * reference that wrote a stream (compression_model.py:369-407, entropy_models.py:355-362).  All tensors f32, NHWC views.
  *   onedc_ref_conv1x1   y = act(conv1x1(x)) [+ res]: wT [C][OC] (transposed weights); input channels in blocks of `blk`: the
  *                       first block one chain that starts from the bias (bias_first) or from 0, later blocks chains from 0
- *                       added in order, the bias last when !bias_first.  act 0 none, 1 LeakyReLU(slope), 2 ConvFFN3's gate
+ *                       added in order; when !bias_first the bias is added to the first block's sum (native gemm path).  act 0 none, 1 LeakyReLU(slope), 2 ConvFFN3's gate
  *                       LeakyReLU(rows n, slope) + LeakyReLU(rows n + OC/2, slope2) (dcvc.py:353-367: OC/2 outputs);
  *                       shuffle = 1 stores through F.pixel_shuffle(., 2) (dcvc.py:183-208; y is the (2H, 2W) map, no res)
  *   onedc_ref_conv3x3   dense 3x3, pad 1: bias + per 16 input channels a chain from 0 over (ky, kx, channel); w3T [9][C][OC];

@@ -22,6 +22,7 @@ from .entropy.entropy_models import EntropyCoder, GaussianEncoder
 from .entropy.utils import decode_i, encode_i, pack_indices, read_from_file, unpack_indices, write_to_file
 from .kernels import View, new_view
 from .layers import (Conv, DepthConvBlock4, ResidualBlockUpsample, VQAttnBlock, VQResnetBlock, Workspace)
+from .ref_arith import ReferenceArithmeticUnavailable
 
 
 class StreamDesyncError(RuntimeError):
@@ -147,7 +148,7 @@ class Decoder:
 
 class IntraNoAR:
     def __init__(self, sd, device, bottleneck_ch=128, semantic_ch=768, z_fsq_levels=(4,) * 7, host_threads=None,
-                 prior_f32=True, prior_arith="mfma"):
+                 prior_f32=True, prior_arith="mfma", ref_threads=None, ref_profile=None):
         """prior_f32: run everything that feeds the integer decisions of the entropy coder (hyper
         decoder, prior fusion, the four-part prior's nets: 36 GFLOP of the 8047 per 768x768 picture)
         in exact f32 on the f32 matrix-core path, like the reference's CPU path; False = bf16 MFMA
@@ -155,18 +156,27 @@ class IntraNoAR:
         prior_arith: "mfma" (default: this package's own prior, encoder and decoder side alike) or "torch_cpu": the prior
         networks evaluated in the REFERENCE'S CPU arithmetic -- the fused-multiply-add chains torch-CPU's convolutions are
         made of, calibrated against the local torch (onedc_amd/ref_arith.py) -- so that y streams written by the reference
-        decode here, and streams written here in this mode decode there.  ~10x slower prior; pictures above ~0.16 MP."""
+        decode here, and streams written here in this mode decode there.  ~10x slower prior; pictures above ~0.16 MP.
+        "auto": decode with the MFMA prior; a stream that desynchronises is tried again in the reference's arithmetic,
+        calibrated for torch's current thread count and then for the other configuration class (one thread <-> several:
+        torch picks oneDNN or its native gemm path by that), before StreamDesyncError is raised.
+        ref_threads: the writer's torch thread count to calibrate "torch_cpu" for (None: torch's current count).
+        ref_profile: the writer's 1x1 structures where known (ref_arith.Calibration: dict or callable), e.g.
+        ref_arith.native_gemm_profile() for a one-thread reference on an Intel host."""
         self.device = device
         self.act = K.act()                 # the format the weights below are packed in
         self.N = N = bottleneck_ch
         self.prior_f32 = f32 = bool(prior_f32)
-        if prior_arith not in ("mfma", "torch_cpu"):
-            raise ValueError(f"prior_arith must be 'mfma' or 'torch_cpu', not {prior_arith!r}")
+        if prior_arith not in ("mfma", "torch_cpu", "auto"):
+            raise ValueError(f"prior_arith must be 'mfma', 'torch_cpu' or 'auto', not {prior_arith!r}")
         self.prior_arith = prior_arith
-        self.ref_prior = None
+        self.ref_threads = ref_threads            # torch thread count of the writer's configuration (None: torch's current one)
+        self.ref_profile = ref_profile            # known 1x1 structures of the writer (ref_arith.Calibration), or None
+        self.ref_prior = None                     # the reference-arithmetic prior in use (None: the MFMA prior)
+        self._ref_priors = {}                     # per calibrated thread count
+        self._ref_sd = sd if prior_arith != "mfma" else None
         if prior_arith == "torch_cpu":
-            from .ref_arith import ReferencePrior
-            self.ref_prior = ReferencePrior(sd, device, N)
+            self.ref_prior = self._reference_prior(ref_threads)
         self.hyper_dec = HyperDecoder(sd, device, f32=f32)
         self.y_prior_fusion = [DepthConvBlock4(sd, f"y_prior_fusion.{i}", device, f32) for i in range(2)]
         self.y_spatial_prior_reduction = Conv(sd, "y_spatial_prior_reduction", device, f32=f32)
@@ -244,9 +254,32 @@ class IntraNoAR:
         return common_cat, y_hat
 
     # ------------------------------------------------------------------ decode
+    def decompress(self, streams_y, indices, trace=None):
+        """`_decompress_once`, and with prior_arith "auto" the retries in the reference's arithmetic for streams that
+        desynchronise under the MFMA prior."""
+        if self.prior_arith != "auto":
+            return self._decompress_once(streams_y, indices, trace)
+        cur = torch.get_num_threads()
+        attempts = [None, self.ref_threads or cur]
+        attempts.append(1 if attempts[1] > 1 else 8)
+        first_error = None
+        for threads in attempts:
+            self.ref_prior = None if threads is None else self._reference_prior(threads)
+            try:
+                if trace is not None:
+                    del trace[:]
+                return self._decompress_once(streams_y, indices, trace)
+            except StreamDesyncError as e:
+                first_error = first_error or e
+            except ReferenceArithmeticUnavailable:          # (pictures too small for that path: nothing more to try there)
+                pass
+            finally:
+                self.ref_prior = None
+        raise first_error
+
     @K.in_own_format
     @torch.no_grad()
-    def decompress(self, streams_y, indices, trace=None):
+    def _decompress_once(self, streams_y, indices, trace=None):
         """decompress_four_part_prior (compression_model.py:369-407) for a batch.
         streams_y: list of B rANS byte strings; indices: int32 (B,h,w) device tensor.
         trace: optional list; receives per hop (table indexes, symbols) as int16 arrays [B, 32, H, W] (what crossed
@@ -286,6 +319,14 @@ class IntraNoAR:
             if bad:
                 raise StreamDesyncError(bad)
         return y_hat, z_semantic
+
+    def _reference_prior(self, threads=None):
+        import torch as _t
+        from .ref_arith import ReferencePrior
+        threads = int(threads or _t.get_num_threads())
+        if threads not in self._ref_priors:
+            self._ref_priors[threads] = ReferencePrior(self._ref_sd, self.device, self.N, threads, self.ref_profile)
+        return self._ref_priors[threads]
 
     def _prior_indexes(self, params, idx_dev, B, H, W, k):
         """build_indexes of hop k (entropy_models.py:355-362): with this package's logarithm, or -- prior_arith "torch_cpu" --

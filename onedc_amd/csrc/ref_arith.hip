@@ -9,7 +9,7 @@
 //        input channels in blocks of R; the first block is ONE fma chain that starts from the bias, every later block a chain
 //        that starts from 0 and is added to the sum so far; R = 80, 128, 256 or 384 depending on the shape
 //   1x1, native (one thread, or a small input: aten _slow_conv2d_forward -> MKL sgemm, beta = 1 on a bias-filled output):
-//        one fma chain from 0 over the input channels, bias added last
+//        fma chains from 0 over blocks of 256 input channels; the bias is added to the first block's sum, later blocks to that
 //   depthwise 3x3, oneDNN jit_dw:avx512_core: one fma chain from the bias over the taps, row-major, padding taps skipped
 //        (csrc/elementwise.hip: dwconv3x3_f32_kernel is exactly this already)
 //   dense 3x3, oneDNN jit:avx512_core: per block of 16 input channels one fma chain from 0 over (ky, kx, channel in block),
@@ -49,9 +49,12 @@ __global__ void ref_conv1x1_kernel(const float *__restrict__ x, int x_cs, int x_
                 float acc = (bias_first && i0 == 0) ? b : 0.f;
                 const int i1 = i0 + blk < C ? i0 + blk : C;
                 for (int ic = i0; ic < i1; ++ic) acc = __builtin_fmaf(xp[ic], wT[(int64_t)ic * OC + oc], acc);
-                tot = i0 == 0 ? acc : tot + acc;
+                // native path (gemm with beta = 1 on a bias-filled output): the bias joins the FIRST block's sum, later
+                // blocks are added to that -- (chain_0 + b) + chain_1 -- as measured for K = 512 on one thread
+                if (i0 == 0) tot = bias_first ? acc : acc + b;
+                else tot = tot + acc;
             }
-            v[h] = bias_first ? tot : tot + b;
+            v[h] = tot;
         }
         float out = v[0];
         if (ACT == 1) out = ref_leaky(out, slope);

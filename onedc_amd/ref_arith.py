@@ -38,14 +38,37 @@ def _v(B, H, W, C, device):
     return new_view(B, H, W, C, device, torch.float32)
 
 
-class Calibration:
-    """(block length, bias first) of torch-CPU's 1x1 convolution per (C, OC, H, W), found by trial against the local torch."""
+class _Threads:
+    """torch's intra-op thread count for the duration of a calibration run (torch picks oneDNN or its native path by it)."""
 
-    def __init__(self, device):
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.n != self.prev:
+            torch.set_num_threads(self.n)
+
+    def __exit__(self, *exc):
+        if self.n != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
+
+
+class Calibration:
+    """(block length, bias first) of torch-CPU's 1x1 convolution per (C, OC, H, W), found by trial against the local torch
+    running with `threads` intra-op threads (default: what torch has now)."""
+
+    def __init__(self, device, threads=None, profile=None):
+        """profile: the WRITER'S structures where they are known and differ from this host's -- a dict {(C, OC, H, W): (block,
+        bias_first)} or a callable (C, OC, H, W) -> (block, bias_first) (e.g. dumped from `Calibration.table` on the machine
+        that writes the streams; torch's native gemm path blocks K differently on Intel and AMD CPUs, oneDNN's kernels do
+        not).  Shapes the profile does not cover are calibrated against the local torch."""
         self.device = device
         self.table = {}
         self.checked = set()
-        self.threads = torch.get_num_threads()
+        self.threads = int(threads or torch.get_num_threads())
+        self.profile = profile
 
     def _rand(self, C, OC, H, W, k, groups=1):
         g = torch.Generator().manual_seed(C * 131 + OC * 7 + H)
@@ -58,8 +81,13 @@ class Calibration:
         key = (C, OC, H, W)
         if key in self.table:
             return self.table[key]
+        if self.profile is not None:
+            known = self.profile(C, OC, H, W) if callable(self.profile) else self.profile.get(key)
+            if known is not None:
+                self.table[key] = (int(known[0]), int(known[1]))
+                return self.table[key]
         x, w, b = self._rand(C, OC, H, W, 1)
-        with torch.no_grad():
+        with torch.no_grad(), _Threads(self.threads):
             ref = torch.nn.functional.conv2d(x, w, b)[0].permute(1, 2, 0).contiguous()             # (H, W, OC)
         dev = self.device
         cs = (C + 3) // 4 * 4
@@ -90,7 +118,7 @@ class Calibration:
         if key in self.checked:
             return
         x, w, b = self._rand(C, OC, H, W, 3)
-        with torch.no_grad():
+        with torch.no_grad(), _Threads(self.threads):
             ref = torch.nn.functional.conv2d(x, w, b, padding=1)[0].permute(1, 2, 0).contiguous()
         dev = self.device
         xv = _v(1, H, W, C, dev)
@@ -109,7 +137,7 @@ class Calibration:
         if key in self.checked:
             return
         x, w, b = self._rand(C, C, H, W, 3, groups=C)
-        with torch.no_grad():
+        with torch.no_grad(), _Threads(self.threads):
             ref = torch.nn.functional.conv2d(x, w, b, padding=1, groups=C)[0].permute(1, 2, 0).contiguous()
         dev = self.device
         xv = _v(1, H, W, C, dev)
@@ -208,13 +236,23 @@ class _RBU:
         return K.ref_conv3x3(t, self.w3T, self.b3, _v(t.B, t.H, t.W, self.OC, self.device), leaky=0.1, res=identity)
 
 
+def native_gemm_profile(kc=256):
+    """The structure of torch's NATIVE 1x1 path (aten _slow_conv2d_forward -> MKL sgemm with beta = 1 on a bias-filled output) as
+    measured on an Intel AVX-512 host: fma chains from 0 over blocks of `kc` input channels, bias added to the first block's sum.
+    What a one-thread reference (src/inference.py:29) runs for EVERY 1x1 convolution; on AMD hosts MKL blocks K differently
+    (128 / 192 measured on an EPYC 9575F), which is why this is a profile and not a constant."""
+    return lambda C, OC, H, W: (min(C, kc), 0)
+
+
 class ReferencePrior:
     """The prior side of IntraNoAR on the reference-arithmetic kernels: same call surface as the MFMA path's pieces in
     codec_module.IntraNoAR (`params_from_indices`, `prior_setup`, `next_params`), same f32 NHWC Views out."""
 
-    def __init__(self, sd, device, N=128):
+    def __init__(self, sd, device, N=128, threads=None, profile=None):
+        """threads: the torch thread count of the WRITER'S configuration to calibrate for (None: torch's current one);
+        profile: known structures of the writer (`Calibration`)."""
         self.device, self.N = device, N
-        self.cal = cal = Calibration(device)
+        self.cal = cal = Calibration(device, threads, profile)
         self.feat_in = _Conv1x1(sd, "hyper_dec.feat_in.0", device, cal)
         self.hyper = [_DCB4(sd, "hyper_dec.to_entropy.0", device, cal), _RBU(sd, "hyper_dec.to_entropy.1", device, cal),
                       _DCB4(sd, "hyper_dec.to_entropy.2", device, cal), _RBU(sd, "hyper_dec.to_entropy.3", device, cal),

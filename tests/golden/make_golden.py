@@ -363,6 +363,39 @@ def main():
              y_hat=sample_points(y_hat9, 16384),
              y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat9.numpy().tobytes()).digest(), dtype=np.uint8))
 
+    # ---------------------------------------------------------------- G10 the reference harness's own CPU setting: ONE thread
+    # src/inference.py:29 sets torch.set_num_threads(1).  With one thread torch sends every 1x1 convolution through its native
+    # path (im2col-free gemm) instead of oneDNN: other fma-chain structures, other last bits -- the stream of G9's picture written
+    # that way (trained-like weights, 768x768) for the decoder's calibration at one thread (tests/test_ref_arith.py).
+    print("G10 reference-made stream, trained-like weights, torch.set_num_threads(1) (768x768)")
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        rng10 = np.random.default_rng(10)
+        indices10 = torch.from_numpy(rng10.integers(0, 16384, (1, 12, 12)))
+        z_hat10 = torch.stack([((indices10 // 4 ** d) % 4 - 2).float() / 2 for d in range(7)], dim=1)
+        params10, _ = hyper_dec_t(z_hat10)
+        fused10 = fusion_t(params10)
+        means10 = fused10.chunk(2, 1)[1]
+        y10 = means10 + 1.5 * torch.randn(means10.shape, generator=torch.Generator().manual_seed(1010))
+        out10 = cm.compress_four_part_prior(y10, fused10, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t,
+                                            y_spatial_prior_reduction=reduction_t)
+        yq10, s10, y_hat10 = out10[0:4], out10[4:8], out10[8]
+        ec.reset()
+        planes10 = []
+        for yq, sc in zip(yq10, s10):
+            planes10.append(cm.gaussian_encoder.build_indexes(sc))
+            cm.gaussian_encoder.encode(yq, sc)
+        ec.flush()
+        stream10 = ec.get_encoded_stream()
+        ec.set_stream(stream10)
+        back10 = cm.decompress_four_part_prior(fused10, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t, reduction_t)
+        assert torch.equal(back10, y_hat10)
+    torch.set_num_threads(8)
+    save("g10_ref_stream_768_trained_1thread.npz", indices=indices10.int(), stream=np.frombuffer(stream10, np.uint8),
+         symbols=torch.stack(list(yq10)).to(torch.int16), index_planes=torch.stack(planes10).to(torch.int16),
+         y_hat=sample_points(y_hat10, 16384),
+         y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat10.numpy().tobytes()).digest(), dtype=np.uint8))
+
     # ---------------------------------------------------------------- G7 hyper encoder (encode side)
     print("G7 hyper encoder")
     with torch.no_grad():

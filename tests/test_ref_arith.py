@@ -44,14 +44,24 @@ def eight_threads():
     torch.set_num_threads(prev)
 
 
+# (golden file, synthetic-weight preset, torch threads of its writer)
+REF_STREAMS = [("g8_ref_stream_768.npz", None, 8), ("g9_ref_stream_768_trained.npz", "trained_like", 8),
+               ("g10_ref_stream_768_trained_1thread.npz", "trained_like", 1)]      # one thread: the harness's own setting
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,preset", [("g8_ref_stream_768.npz", None), ("g9_ref_stream_768_trained.npz", "trained_like")])
-def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_threads, name, preset):
+@pytest.mark.parametrize("name,preset,threads", REF_STREAMS)
+def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_threads, name, preset, threads):
     from onedc_amd import kernels as K
     from onedc_amd.codec_module import IntraNoAR, StreamDesyncError
     DEV = "cuda:0"
     g = golden(name)
-    codec = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="torch_cpu")
+    # the one-thread stream was written on an Intel host: torch's native gemm path (MKL) blocks K by the CPU it runs on -- the
+    # writer's structure is given as a profile there; the oneDNN configurations are the same on Intel and AMD hosts: calibrated
+    from onedc_amd.ref_arith import native_gemm_profile
+    profile = native_gemm_profile() if threads == 1 else None
+    codec = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="torch_cpu", ref_threads=threads,
+                      ref_profile=profile)
     codec.update(force=True)
     idx = torch.from_numpy(g["indices"]).to(DEV)
     # teacher-forced: the reference's symbols are fed back, every table-index decision is compared
@@ -67,7 +77,7 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
         codec._prior_indexes(params, idx_dev, B, H, W, k)
         flips.append(int((idx_dev.view(B, N // 4, H, W).cpu().numpy() != g["index_planes"][k]).sum()))
         K.prior_update_dec(params, torch.from_numpy(np.ascontiguousarray(g["symbols"][k])).to(DEV).reshape(-1), y_hat, k)
-    print(f"[ref-arith] {name}: teacher-forced table-index flips per hop {flips}; calibrated structures: "
+    print(f"[ref-arith] {name} (writer: {threads} thread(s)): teacher-forced table-index flips per hop {flips}; calibrated structures: "
           f"{dict(sorted(codec.ref_prior.cal.table.items()))}")
     assert flips == [0, 0, 0, 0]
     flat = y_hat.torch_nchw().cpu().reshape(-1)
@@ -82,6 +92,24 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
     mfma.update(force=True)
     with pytest.raises(StreamDesyncError):
         mfma.decompress([g["stream"].tobytes()], idx)
+    # ... and so does the reference's arithmetic calibrated for the OTHER configuration class (one thread <-> several): loud
+    other = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="torch_cpu", ref_threads=1 if threads > 1 else 8)
+    other.update(force=True)
+    with pytest.raises(StreamDesyncError):
+        other.decompress([g["stream"].tobytes()], idx)
+    # prior_arith="auto" finds the class by itself (MFMA first, then the calibrations), and still raises for a corrupt stream
+    auto = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="auto", ref_profile=profile)
+    auto.update(force=True)
+    y3, _ = auto.decompress([g["stream"].tobytes()], idx)
+    assert torch.equal(y3.torch_nchw(), y_hat.torch_nchw()) and auto.ref_prior is None
+    bad = bytearray(g["stream"].tobytes())
+    bad[len(bad) // 2] ^= 0x3C
+    with pytest.raises(StreamDesyncError):
+        auto.decompress([bytes(bad)], idx)
+    blobs, own = auto.encode_latents(idx, None, noise_seed=3)          # its own streams: the MFMA prior, first try
+    from onedc_amd.entropy.utils import decode_i
+    y4, _ = auto.decompress([decode_i(blobs[0], 14, 64)["bit_stream_y"]], idx)
+    assert torch.equal(y4.torch_nchw(), own.torch_nchw())
 
 
 @pytest.mark.gpu
