@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: 16; encode_decode: 8)")
     ap.add_argument("--size", type=int, default=None, help="picture size (default: 768; encode_decode: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prior-arith", choices=["mfma", "torch_cpu", "auto"], default="mfma",
+                    help="arithmetic of the four-part prior: the exact-f32 MFMA path (default, the headline) or the reference's "
+                         "CPU arithmetic as fma chains on the GPU (compatibility path for reference-made streams, 8-thread class)")
     ap.add_argument("--sequential", action="store_true", help="no pipelining across batches")
     ap.add_argument("--s-streams", type=int, default=2, help="concurrent synthesis/UNet/VAE stages in the pipeline")
     ap.add_argument("--cpu-sample", type=int, default=None, help="picture size of the CPU baseline sample")
@@ -324,7 +327,10 @@ def main():
         sds_dev = broadcast_state_dicts(sds, specs, device, rank, world)
     else:                                  # synthetic weights are a pure function of (key, seed): every rank builds its own
         sds = sds_dev = [synth.unet_state_dict(0), synth.codec_state_dict(0), synth.vae_state_dict(0)]
-    model = SD15_1step_codec_stage1({"vae_attn_patch": 16}, device=device).load_state_dicts(*sds_dev)
+    model_cfg = {"vae_attn_patch": 16}
+    if args.prior_arith != "mfma":
+        model_cfg.update(prior_arith=args.prior_arith, ref_threads=8)
+    model = SD15_1step_codec_stage1(model_cfg, device=device).load_state_dicts(*sds_dev)
     enc_sds = None
     if mode == "encode_decode":
         enc_sds = [synth.codec_encoder_state_dict(0), synth.hyper_enc_state_dict(0), synth.vae_encoder_state_dict(0)]
@@ -560,8 +566,11 @@ def main():
                        "weights": "rank 0 builds, one flat RCCL broadcast" if args.broadcast_weights else
                                   "every rank builds the deterministic synthetic weights itself",
                        "setup_s": round(t_setup, 1),
-                       "arithmetic": f"{model.act} storage and MFMA operands (synthesis, UNet, VAE), exact f32 MFMA (prior "
-                                     f"networks, VAE conv_in), f64 (eps -> x0), f32 accumulation everywhere",
+                       "arithmetic": f"{model.act} storage and MFMA operands (synthesis, UNet, VAE), " +
+                                     ("exact f32 MFMA (prior networks, VAE conv_in)" if args.prior_arith == "mfma" else
+                                      f"prior networks in the reference's torch-CPU arithmetic as f32 fma chains on the GPU "
+                                      f"(prior_arith={args.prior_arith}, compatibility path), exact f32 MFMA (VAE conv_in)") +
+                                     ", f64 (eps -> x0), f32 accumulation everywhere",
                        "timed": {"decode": "container parse + host rANS + H2D/D2H + all device kernels + crop",
                                  "z_only": "container parse + index unpack + H2D + all device kernels + crop",
                                  "encode_decode": "encode (all device kernels + D2H + host rANS + container) then decode "

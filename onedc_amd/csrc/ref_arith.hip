@@ -27,50 +27,85 @@ namespace {
 __device__ __forceinline__ float ref_leaky(float v, float s) { return v >= 0.f ? v : v * s; }
 
 // ACT: 0 none, 1 LeakyReLU(slope), 2 ConvFFN3's gate: LeakyReLU(a, slope) + LeakyReLU(b, slope2), a = row n, b = row n + OC / 2
-template <int ACT>
+// One thread: one output channel of P consecutive pixels -- P independent chains share every weight load (the weights are the
+// traffic: a [C][OC] f32 matrix read once per pixel GROUP from L2 instead of once per pixel), and the pixel group is a function of
+// blockIdx alone, so the input values are wave-uniform (scalar loads, SGPR operands of v_fma_f32).  The order of the fma chain
+// of every single output is what the header says; P changes nothing in it.
+template <int ACT, int P>
 __global__ void ref_conv1x1_kernel(const float *__restrict__ x, int x_cs, int x_co, const float *__restrict__ wT,
                                    const float *__restrict__ bias, const float *__restrict__ res, int r_cs, int r_co,
                                    float *__restrict__ y, int y_cs, int y_co, int64_t pixels, int C, int OC, int blk,
                                    int bias_first, float slope, float slope2, int shuffle, int H, int W) {
     const int NO = ACT == 2 ? OC >> 1 : OC;                       // channels this launch produces
-    const int64_t total = pixels * NO;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t pix = i / NO;
-        const int n = (int)(i - pix * NO);
-        const float *xp = x + pix * x_cs + x_co;
-        float v[ACT == 2 ? 2 : 1];
+    const int n = blockIdx.y * blockDim.x + threadIdx.x;
+    if (n >= NO) return;
+    const int64_t groups = (pixels + P - 1) / P;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int64_t pix0 = grp * P;
+        const float *xp[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int64_t pix = pix0 + p < pixels ? pix0 + p : pixels - 1;      // the tail repeats the last pixel, not stored
+            xp[p] = x + pix * x_cs + x_co;
+        }
+        float v[ACT == 2 ? 2 : 1][P];
 #pragma unroll
         for (int h = 0; h < (ACT == 2 ? 2 : 1); ++h) {
             const int oc = n + h * NO;
             const float b = bias ? bias[oc] : 0.f;
-            float tot = 0.f;
+            float tot[P];
             for (int i0 = 0; i0 < C; i0 += blk) {
-                float acc = (bias_first && i0 == 0) ? b : 0.f;
+                float acc[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = (bias_first && i0 == 0) ? b : 0.f;
                 const int i1 = i0 + blk < C ? i0 + blk : C;
-                for (int ic = i0; ic < i1; ++ic) acc = __builtin_fmaf(xp[ic], wT[(int64_t)ic * OC + oc], acc);
+                const float *wp = wT + (int64_t)i0 * OC + oc;
+                int ic = i0;
+                for (; ic + 8 <= i1; ic += 8, wp += 8 * (int64_t)OC) {             // eight weight loads in flight
+                    float w[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) w[k] = wp[(int64_t)k * OC];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+#pragma unroll
+                        for (int p = 0; p < P; ++p) acc[p] = __builtin_fmaf(xp[p][ic + k], w[k], acc[p]);
+                }
+                for (; ic < i1; ++ic, wp += OC) {
+                    const float w = wp[0];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = __builtin_fmaf(xp[p][ic], w, acc[p]);
+                }
                 // native path (gemm with beta = 1 on a bias-filled output): the bias joins the FIRST block's sum, later
                 // blocks are added to that -- (chain_0 + b) + chain_1 -- as measured for K = 512 on one thread
-                if (i0 == 0) tot = bias_first ? acc : acc + b;
-                else tot = tot + acc;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (i0 == 0) tot[p] = bias_first ? acc[p] : acc[p] + b;
+                    else tot[p] = tot[p] + acc[p];
+                }
             }
-            v[h] = tot;
+#pragma unroll
+            for (int p = 0; p < P; ++p) v[h][p] = tot[p];
         }
-        float out = v[0];
-        if (ACT == 1) out = ref_leaky(out, slope);
-        if (ACT == 2) out = ref_leaky(v[0], slope) + ref_leaky(v[ACT == 2 ? 1 : 0], slope2);
-        int64_t dst;
-        if (shuffle) {                                             // F.pixel_shuffle(., 2): channel c * 4 + dy * 2 + dx -> (2 y + dy, 2 x + dx, c)
-            const int xx = (int)(pix % W);
-            const int yy = (int)((pix / W) % H);
-            const int64_t b = pix / ((int64_t)W * H);
-            const int c = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
-            dst = ((b * 2 * H + 2 * yy + dy) * (2 * W) + 2 * xx + dx) * y_cs + y_co + c;
-        } else {
-            dst = pix * y_cs + y_co + n;
-            if (res) out = out + res[pix * r_cs + r_co + n];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int64_t pix = pix0 + p;
+            if (pix >= pixels) break;
+            float out = v[0][p];
+            if (ACT == 1) out = ref_leaky(out, slope);
+            if (ACT == 2) out = ref_leaky(v[0][p], slope) + ref_leaky(v[ACT == 2 ? 1 : 0][p], slope2);
+            int64_t dst;
+            if (shuffle) {                                         // F.pixel_shuffle(., 2): channel c * 4 + dy * 2 + dx -> (2 y + dy, 2 x + dx, c)
+                const int xx = (int)(pix % W);
+                const int yy = (int)((pix / W) % H);
+                const int64_t bb = pix / ((int64_t)W * H);
+                const int c = n >> 2, dy = (n >> 1) & 1, dx = n & 1;
+                dst = ((bb * 2 * H + 2 * yy + dy) * (2 * W) + 2 * xx + dx) * y_cs + y_co + c;
+            } else {
+                dst = pix * y_cs + y_co + n;
+                if (res) out = out + res[pix * r_cs + r_co + n];
+            }
+            y[dst] = out;
         }
-        y[dst] = out;
     }
 }
 
@@ -156,12 +191,24 @@ int onedc_ref_conv1x1(const float *x, int x_cs, int x_co, const float *wT, const
                       int act, float slope, float slope2, int shuffle, int H, int W, void *stream) {
     if (!x || !wT || !y || C < 1 || OC < 1 || blk < 1 || pixels < 0 || act < 0 || act > 2) return -1;
     if ((act == 2 && (OC & 1)) || (shuffle && ((OC & 3) || act == 2 || res || H < 1 || W < 1))) return -2;
-    const int64_t n = pixels * (act == 2 ? OC / 2 : OC);
-    if (n == 0) return 0;
+    if (pixels == 0) return 0;
+    const int NO = act == 2 ? OC / 2 : OC;
     hipStream_t st = as_stream(stream);
+    const int threads = NO >= 256 ? 256 : ((NO + 63) / 64) * 64;
+    const int tiles = (NO + threads - 1) / threads;
+    // 8 pixels per thread where that still leaves every CU several waves; small maps keep the chip busy with 2
+    const bool wide = (pixels / 8) * ((NO + 63) / 64) >= 2048;
+    const int64_t groups = wide ? (pixels + 7) / 8 : (pixels + 1) / 2;
+    const dim3 grid((unsigned)(groups > 1048576 ? 1048576 : groups), (unsigned)tiles);
 #define REF_L(A)                                                                                                          \
-    hipLaunchKernelGGL(ref_conv1x1_kernel<A>, dim3(ref_grid(n)), dim3(256), 0, st, x, x_cs, x_co, wT, bias, res, r_cs, r_co, y, \
-                       y_cs, y_co, pixels, C, OC, blk, bias_first, slope, slope2, shuffle, H, W)
+    do {                                                                                                                  \
+        if (wide)                                                                                                         \
+            hipLaunchKernelGGL((ref_conv1x1_kernel<A, 8>), grid, dim3(threads), 0, st, x, x_cs, x_co, wT, bias, res, r_cs, r_co, \
+                               y, y_cs, y_co, pixels, C, OC, blk, bias_first, slope, slope2, shuffle, H, W);               \
+        else                                                                                                              \
+            hipLaunchKernelGGL((ref_conv1x1_kernel<A, 2>), grid, dim3(threads), 0, st, x, x_cs, x_co, wT, bias, res, r_cs, r_co, \
+                               y, y_cs, y_co, pixels, C, OC, blk, bias_first, slope, slope2, shuffle, H, W);               \
+    } while (0)
     if (act == 0) REF_L(0);
     else if (act == 1) REF_L(1);
     else REF_L(2);
