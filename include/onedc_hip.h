@@ -254,6 +254,10 @@ int onedc_latent_sample(const float *moments, const float *noise, float *out, in
  *                       shuffle = 1 stores through F.pixel_shuffle(., 2) (dcvc.py:183-208; y is the (2H, 2W) map, no res)
  *   onedc_ref_conv3x3   dense 3x3, pad 1: bias + per 16 input channels a chain from 0 over (ky, kx, channel); w3T [9][C][OC];
  *                       y = [LeakyReLU(slope)](.) [+ res]
+ *   onedc_ref_conv3x3_im2col  the same layer where torch takes its native path (maps of <= 20 480 elements: im2col + sgemm):
+ *                       wKT [9 C][OC] with k = c * 9 + ky * 3 + kx; K in `parts` equal parts, blocks of `blk` inside a part
+ *                       (chains from 0 added in order), bias joined to part 0, parts [0, split) and [split, parts) summed in
+ *                       order and then added (split == parts: one sequence)
  *   onedc_ref_prior_indexes  build_indexes with the writer's logarithm: index = number of thresholds <= sigma
  *                       (thresholds: f32 [n], ascending, found by the host by bisection over torch.log) */
 int onedc_ref_conv1x1(const float *x, int x_cs, int x_co, const float *wT, const float *bias, const float *res, int r_cs,
@@ -262,6 +266,9 @@ int onedc_ref_conv1x1(const float *x, int x_cs, int x_co, const float *wT, const
 int onedc_ref_conv3x3(const float *x, int x_cs, int x_co, const float *w3T, const float *bias, const float *res, int r_cs,
                       int r_co, float *y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int leaky_on, float slope,
                       void *stream);
+int onedc_ref_conv3x3_im2col(const float *x, int x_cs, int x_co, const float *wKT, const float *bias, const float *res, int r_cs,
+                             int r_co, float *y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int parts, int blk,
+                             int split, int leaky_on, float slope, void *stream);
 int onedc_ref_prior_indexes(const float *params, const float *thresholds, int n_thresholds, int16_t *indexes, int B, int H,
                             int W, int C, int step, void *stream);
 

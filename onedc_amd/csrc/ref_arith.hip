@@ -14,6 +14,11 @@
 //        (csrc/elementwise.hip: dwconv3x3_f32_kernel is exactly this already)
 //   dense 3x3, oneDNN jit:avx512_core: per block of 16 input channels one fma chain from 0 over (ky, kx, channel in block),
 //        padding taps skipped; the block sums are added one after the other to the bias
+//   dense 3x3 on maps of <= 20 480 elements (pictures under ~0.16 MP), native: im2col + MKL sgemm, beta = 1 on a bias-filled
+//        output; k = (channel, ky, kx).  K is cut into T equal parts (one per group of MKL threads), every part blocks of `blk`
+//        (chains from 0, added in order); the bias joins part 0; parts [0, s) are added in order, parts [s, T) are added in
+//        order, then the two sums.  Measured on the Intel build host: 1, 4, 6 threads T = 1, blk = 384; 2 and 8 threads T = 4,
+//        s = 2; 3 threads T = 3, s = 1 -- small pictures are as thread-dependent as it gets
 // -- and v_fma_f32 is the same IEEE operation as vfmadd231ps.  The kernels below evaluate those chains, one thread per
 // output element (consecutive lanes = consecutive output channels: the transposed weights are read coalesced, the
 // input value of a pixel is a broadcast), parameterised by (R, bias first / last); the host finds the parameters of each layer
@@ -145,6 +150,48 @@ __global__ void ref_conv3x3_kernel(const float *__restrict__ x, int x_cs, int x_
     }
 }
 
+// dense 3x3, pad 1, in aten's im2col order k = c * 9 + ky * 3 + kx: wKT [9 C][OC]; K in T parts of K / T, blocks of blk inside
+// a part, parts [0, s) and [s, T) summed in order, bias joined to part 0 (see the header).  Small maps only: one thread per output.
+__global__ void ref_conv3x3_im2col_kernel(const float *__restrict__ x, int x_cs, int x_co, const float *__restrict__ wKT,
+                                          const float *__restrict__ bias, const float *__restrict__ res, int r_cs, int r_co,
+                                          float *__restrict__ y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int T,
+                                          int blk, int split, int leaky_on, float slope) {
+    const int64_t total = (int64_t)B * H * W * OC;
+    const int K = 9 * C, per = K / T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / OC;
+        const int oc = (int)(i - pix * OC);
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        const int64_t b = pix / ((int64_t)W * H);
+        float side[2] = {0.f, 0.f};
+        for (int pi = 0; pi < T; ++pi) {
+            float tot = 0.f;
+            for (int k0 = pi * per; k0 < (pi + 1) * per; k0 += blk) {
+                const int k1 = k0 + blk < (pi + 1) * per ? k0 + blk : (pi + 1) * per;
+                float acc = 0.f;
+                int c = k0 / 9, t = k0 - 9 * c;
+                for (int k = k0; k < k1; ++k) {
+                    const int ky = t / 3, kx = t - 3 * ky;
+                    const int iy = yy + ky - 1, ix = xx + kx - 1;
+                    const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((b * H + iy) * W + ix) * x_cs + x_co + c] : 0.f;
+                    acc = __builtin_fmaf(xv, wKT[(int64_t)k * OC + oc], acc);       // the zero of a padding tap is multiplied, as im2col does
+                    if (++t == 9) t = 0, ++c;
+                }
+                // the bias joins the first block's sum (the gemm's beta = 1 on the bias-filled output), as in the 1x1 native path
+                tot = k0 == pi * per ? (pi == 0 ? acc + (bias ? bias[oc] : 0.f) : acc) : tot + acc;
+            }
+            const int sd = pi >= split;
+            side[sd] = (pi == 0 || pi == split) ? tot : side[sd] + tot;
+        }
+        float out = split < T ? side[0] + side[1] : side[0];
+        if (leaky_on) out = ref_leaky(out, slope);
+        if (res) out = out + res[pix * r_cs + r_co + oc];
+        y[pix * y_cs + y_co + oc] = out;
+    }
+}
+
 __device__ __constant__ int REF_PHASE[4][4] = {{0, 1, 2, 3}, {3, 2, 1, 0}, {2, 3, 0, 1}, {1, 0, 3, 2}};
 
 // build_indexes with the WRITER'S logarithm: index = number of thresholds <= sigma, thresholds[i] = the smallest f32 whose
@@ -224,6 +271,18 @@ int onedc_ref_conv3x3(const float *x, int x_cs, int x_co, const float *w3T, cons
     const int64_t n = (int64_t)B * H * W * OC;
     hipLaunchKernelGGL(ref_conv3x3_kernel, dim3(ref_grid(n)), dim3(256), 0, as_stream(stream), x, x_cs, x_co, w3T, bias, res,
                        r_cs, r_co, y, y_cs, y_co, B, H, W, C, OC, leaky_on, slope);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+int onedc_ref_conv3x3_im2col(const float *x, int x_cs, int x_co, const float *wKT, const float *bias, const float *res, int r_cs,
+                             int r_co, float *y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int parts, int blk,
+                             int split, int leaky_on, float slope, void *stream) {
+    if (!x || !wKT || !y || C < 1 || OC < 1 || B < 1 || H < 1 || W < 1 || parts < 1 || blk < 1) return -1;
+    if ((9 * C) % parts || split < 1 || split > parts) return -2;
+    const int64_t n = (int64_t)B * H * W * OC;
+    hipLaunchKernelGGL(ref_conv3x3_im2col_kernel, dim3(ref_grid(n)), dim3(256), 0, as_stream(stream), x, x_cs, x_co, wKT, bias,
+                       res, r_cs, r_co, y, y_cs, y_co, B, H, W, C, OC, parts, blk, split, leaky_on, slope);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

@@ -125,6 +125,7 @@ SIGNATURES = {
     "onedc_mxfp8_roundtrip": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "onedc_ref_conv1x1": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _L, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P]),
     "onedc_ref_conv3x3": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_ref_conv3x3_im2col": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_ref_prior_indexes": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
     "onedc_hip_version": (C.c_char_p, []),
@@ -571,6 +572,16 @@ def ref_conv3x3(x, w3T, bias, y, *, leaky=None, res=None):
     _ok(lib().onedc_ref_conv3x3(x.ptr, x.cs, x.co, w3T.data_ptr(), _ptr(bias), (res.ptr if res is not None else None),
                                 (res.cs if res is not None else 0), (res.co if res is not None else 0), y.ptr, y.cs, y.co,
                                 x.B, x.H, x.W, C, OC, int(leaky is not None), float(leaky or 0.0), stream()), "onedc_ref_conv3x3")
+    return y
+
+
+def ref_conv3x3_im2col(x, wKT, bias, y, *, parts, blk, split, leaky=None, res=None):
+    """Reference-arithmetic dense 3x3 conv on torch's native path (small maps): wKT f32 [9 C][OC], k = c * 9 + ky * 3 + kx."""
+    K9, OC = wKT.shape
+    _ok(lib().onedc_ref_conv3x3_im2col(x.ptr, x.cs, x.co, wKT.data_ptr(), _ptr(bias), (res.ptr if res is not None else None),
+                                       (res.cs if res is not None else 0), (res.co if res is not None else 0), y.ptr, y.cs,
+                                       y.co, x.B, x.H, x.W, K9 // 9, OC, int(parts), int(blk), int(split),
+                                       int(leaky is not None), float(leaky or 0.0), stream()), "onedc_ref_conv3x3_im2col")
     return y
 
 

@@ -81,11 +81,10 @@ class Calibration:
         key = (C, OC, H, W)
         if key in self.table:
             return self.table[key]
-        if self.profile is not None:
-            known = self.profile(C, OC, H, W) if callable(self.profile) else self.profile.get(key)
-            if known is not None:
-                self.table[key] = (int(known[0]), int(known[1]))
-                return self.table[key]
+        known = self._known(1, C, OC, H, W)
+        if known is not None:
+            self.table[key] = (int(known[0]), int(known[1]))
+            return self.table[key]
         x, w, b = self._rand(C, OC, H, W, 1)
         with torch.no_grad(), _Threads(self.threads):
             ref = torch.nn.functional.conv2d(x, w, b)[0].permute(1, 2, 0).contiguous()             # (H, W, OC)
@@ -113,10 +112,37 @@ class Calibration:
         self.table[key] = found
         return found
 
-    def check_conv3x3(self, C, OC, H, W):
+    def _known(self, k, C, OC, H, W):
+        if self.profile is None:
+            return None
+        if callable(self.profile):
+            return self.profile(C, OC, H, W, k)
+        return self.profile.get((C, OC, H, W) if k == 1 else ("3x3", C, OC, H, W))
+
+    @staticmethod
+    def im2col_candidates(K):
+        """(parts, block, split) of the native dense 3x3 (csrc/ref_arith.hip header), the measured ones first."""
+        out = [(1, 384, 1), (4, K // 4, 2), (3, K // 3, 1)]
+        for T in (1, 2, 3, 4, 6, 8):
+            if K % T:
+                continue
+            per = K // T
+            for blk in sorted({per, 384, 256, 192, 128, 96, 64} & set(range(1, per + 1)), reverse=True):
+                for split in range(T, 0, -1):
+                    if (T, blk, split) not in out:
+                        out.append((T, blk, split))
+        return out
+
+    def conv3x3(self, C, OC, H, W):
+        """-> ("direct",) (oneDNN's kernel: 16-channel block chains) or ("im2col", parts, block, split) (torch's native path on
+        maps of <= 20 480 elements), whichever reproduces the local torch (or what the writer's profile says)."""
         key = ("3x3", C, OC, H, W)
-        if key in self.checked:
-            return
+        if key in self.table:
+            return self.table[key]
+        known = self._known(3, C, OC, H, W)
+        if known is not None:
+            self.table[key] = tuple(known)
+            return self.table[key]
         x, w, b = self._rand(C, OC, H, W, 3)
         with torch.no_grad(), _Threads(self.threads):
             ref = torch.nn.functional.conv2d(x, w, b, padding=1)[0].permute(1, 2, 0).contiguous()
@@ -124,13 +150,27 @@ class Calibration:
         xv = _v(1, H, W, C, dev)
         xv.t[:H * W * C].view(H, W, C).copy_(x[0].permute(1, 2, 0))
         yv = _v(1, H, W, OC, dev)
-        K.ref_conv3x3(xv, w.permute(2, 3, 1, 0).reshape(9, C, OC).contiguous().to(dev), b.to(dev), yv)
-        if not torch.equal(yv.t[:H * W * OC].view(H, W, OC).cpu(), ref):
+        bd = b.to(dev)
+        got = lambda: yv.t[:H * W * OC].view(H, W, OC).cpu()
+        found = None
+        if C % 16 == 0:
+            K.ref_conv3x3(xv, w.permute(2, 3, 1, 0).reshape(9, C, OC).contiguous().to(dev), bd, yv)
+            if torch.equal(got(), ref):
+                found = ("direct",)
+        if found is None and C * H * W <= 20480:
+            wKT = w.reshape(OC, C * 9).t().contiguous().to(dev)
+            for T, blk, split in self.im2col_candidates(9 * C):
+                K.ref_conv3x3_im2col(xv, wKT, bd, yv, parts=T, blk=blk, split=split)
+                if torch.equal(got(), ref):
+                    found = ("im2col", T, blk, split)
+                    break
+        if found is None:
             raise ReferenceArithmeticUnavailable(
-                f"torch-CPU's dense 3x3 convolution {C}->{OC} on a {H}x{W} map does not follow oneDNN's direct kernel here "
-                f"(maps of <= 20 480 elements go through aten's im2col + MKL sgemm, whose summation is not a chain): pictures "
-                f"under ~0.16 megapixels cannot be decoded in the reference's arithmetic")
-        self.checked.add(key)
+                f"no fma-chain structure reproduces torch-CPU's dense 3x3 convolution {C}->{OC} on a {H}x{W} map with "
+                f"{self.threads} thread(s) on this host (oneDNN's direct kernel, or aten's im2col + sgemm on maps of <= 20 480 "
+                f"elements, whose K split depends on the thread count and the BLAS)")
+        self.table[key] = found
+        return found
 
     def check_dw3x3(self, C, H, W):
         key = ("dw", C, H, W)
@@ -227,21 +267,45 @@ class _RBU:
         w = sd[f"{p}.conv.weight"].float()
         self.OC, self.C = w.shape[0], w.shape[1]
         self.w3T = w.permute(2, 3, 1, 0).reshape(9, self.C, self.OC).contiguous().to(device)
+        self.wKT = w.reshape(self.OC, self.C * 9).t().contiguous().to(device)          # im2col order, for small maps
         self.b3 = sd[f"{p}.conv.bias"].float().contiguous().to(device)
 
     def __call__(self, x):
         t = self.subpel(x, act=1, slope=0.01, shuffle=True)
         identity = self.upsample(x, shuffle=True)
-        self.cal.check_conv3x3(self.C, self.OC, t.H, t.W)
-        return K.ref_conv3x3(t, self.w3T, self.b3, _v(t.B, t.H, t.W, self.OC, self.device), leaky=0.1, res=identity)
+        how = self.cal.conv3x3(self.C, self.OC, t.H, t.W)
+        out = _v(t.B, t.H, t.W, self.OC, self.device)
+        if how[0] == "direct":
+            return K.ref_conv3x3(t, self.w3T, self.b3, out, leaky=0.1, res=identity)
+        return K.ref_conv3x3_im2col(t, self.wKT, self.b3, out, parts=how[1], blk=how[2], split=how[3], leaky=0.1, res=identity)
+
+
+def intel_profile(threads, kc=256):
+    """The WRITER'S structures of torch's NATIVE paths (aten _slow_conv2d_forward -> MKL sgemm with beta = 1 on a bias-filled
+    output) as measured on an Intel AVX-512 host, for a decoder whose own host blocks differently (MKL dispatches by CPU: K
+    blocks of 128 / 192 on an EPYC 9575F):
+      1x1 (every shape at one thread, inputs of <= 20 480 elements otherwise): chains from 0 over blocks of `kc` input
+          channels, bias added to the first block's sum;
+      dense 3x3 on inputs of <= 20 480 elements (K = 9 * 128): the K split of the thread count -- 1, 4, 6 threads: blocks of
+          384 in one sequence; 2, 8 threads: four parts of 288, (p0 + b + p1) + (p2 + p3); 3 threads: (p0 + b) + (p1 + p2).
+    Shapes that go through oneDNN are not covered (None): its kernels are the same on Intel and AMD hosts and are
+    calibrated against the local torch."""
+    im2col = {1: (1, 384, 1), 4: (1, 384, 1), 6: (1, 384, 1), 2: (4, None, 2), 8: (4, None, 2), 3: (3, None, 1)}
+
+    def profile(C, OC, H, W, k=1):
+        small = C * H * W <= 20480
+        if k == 1:
+            return (min(C, kc), 0) if (small or threads == 1) else None
+        if not small or threads not in im2col or C != 128:
+            return None
+        T, blk, split = im2col[threads]
+        return ("im2col", T, blk or 9 * C // T, split)
+    return profile
 
 
 def native_gemm_profile(kc=256):
-    """The structure of torch's NATIVE 1x1 path (aten _slow_conv2d_forward -> MKL sgemm with beta = 1 on a bias-filled output) as
-    measured on an Intel AVX-512 host: fma chains from 0 over blocks of `kc` input channels, bias added to the first block's sum.
-    What a one-thread reference (src/inference.py:29) runs for EVERY 1x1 convolution; on AMD hosts MKL blocks K differently
-    (128 / 192 measured on an EPYC 9575F), which is why this is a profile and not a constant."""
-    return lambda C, OC, H, W: (min(C, kc), 0)
+    """The one-thread writer on an Intel host (src/inference.py:29 sets one thread): `intel_profile(1, kc)`."""
+    return intel_profile(1, kc)
 
 
 class ReferencePrior:

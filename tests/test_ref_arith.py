@@ -78,7 +78,7 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
         flips.append(int((idx_dev.view(B, N // 4, H, W).cpu().numpy() != g["index_planes"][k]).sum()))
         K.prior_update_dec(params, torch.from_numpy(np.ascontiguousarray(g["symbols"][k])).to(DEV).reshape(-1), y_hat, k)
     print(f"[ref-arith] {name} (writer: {threads} thread(s)): teacher-forced table-index flips per hop {flips}; calibrated structures: "
-          f"{dict(sorted(codec.ref_prior.cal.table.items()))}")
+          f"{dict(sorted(codec.ref_prior.cal.table.items(), key=str))}")
     assert flips == [0, 0, 0, 0]
     flat = y_hat.torch_nchw().cpu().reshape(-1)
     assert torch.equal(flat[torch.from_numpy(g["y_hat.idx"])], torch.from_numpy(g["y_hat.val"]))      # bit for bit
@@ -140,12 +140,58 @@ def test_streams_written_in_the_reference_arithmetic_carry_the_references_decisi
     assert torch.equal(y_hat.torch_nchw().cpu(), y_hat_ref)
 
 
+# reference-made streams of SMALL pictures (128x192, 256x256; written at 8 threads on the Intel build host).  Under ~0.16 MP torch
+# sends the hyper decoder's dense 3x3 convolutions and most 1x1 convolutions through its native path (im2col + MKL sgemm), whose K
+# split depends on the thread count and on the CPU MKL dispatches for: the writer's structures come from
+# ref_arith.intel_profile(8), the oneDNN shapes from the local calibration.
+SMALL_STREAMS = [("g5_codec_path.npz", None), ("g8_ref_stream_256.npz", None), ("g9_ref_stream_256_trained.npz", "trained_like")]
+
+
 @pytest.mark.gpu
-def test_small_pictures_are_refused_not_misdecoded(eight_threads):
-    """128x192: the hyper decoder's dense 3x3 convolutions run on 4x6 / 8x12 maps, which torch sends through im2col + MKL sgemm
-    (not a chain): the calibration says so instead of decoding something else."""
+@pytest.mark.parametrize("name,preset", SMALL_STREAMS)
+def test_reference_made_small_streams_decode_in_the_reference_arithmetic(eight_threads, name, preset):
+    from onedc_amd import kernels as K
     from onedc_amd.codec_module import IntraNoAR
-    from onedc_amd.ref_arith import ReferenceArithmeticUnavailable
+    from onedc_amd.ref_arith import intel_profile
+    DEV = "cuda:0"
+    g = golden(name)
+    codec = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="torch_cpu", ref_threads=8,
+                      ref_profile=intel_profile(8))
+    codec.update(force=True)
+    idx = torch.from_numpy(g["indices"]).to(DEV)
+    fused, _ = codec._params_from_indices(idx)
+    common_cat, y_hat = codec._prior_setup(fused)
+    B, H, W, N = fused.B, fused.H, fused.W, codec.N
+    idx_dev = torch.empty(B * (N // 4) * H * W, dtype=torch.int16, device=DEV)
+    flips, params = [], fused
+    for k in range(4):
+        if k > 0:
+            params = codec._next_params(k, y_hat, common_cat)
+        codec._prior_indexes(params, idx_dev, B, H, W, k)
+        flips.append(int((idx_dev.view(B, N // 4, H, W).cpu().numpy() != g["index_planes"][k]).sum()))
+        K.prior_update_dec(params, torch.from_numpy(np.ascontiguousarray(g["symbols"][k])).to(DEV).reshape(-1), y_hat, k)
+    print(f"[ref-arith] {name}: teacher-forced table-index flips per hop {flips}; structures: "
+          f"{dict(sorted(codec.ref_prior.cal.table.items(), key=str))}")
+    assert flips == [0, 0, 0, 0]
+    got = y_hat.torch_nchw().cpu()
+    if "y_hat" in g:
+        assert torch.equal(got, torch.from_numpy(g["y_hat"]))
+    else:
+        assert torch.equal(got.reshape(-1)[torch.from_numpy(g["y_hat.idx"])], torch.from_numpy(g["y_hat.val"]))
+    trace = []
+    y2, _ = codec.decompress([g["stream"].tobytes()], idx, trace=trace)                 # free-running
+    assert all(np.array_equal(sy, g["symbols"][k]) for k, (ix, sy) in enumerate(trace))
+    assert torch.equal(y2.torch_nchw().cpu(), got)
+
+
+@pytest.mark.gpu
+def test_shapes_without_a_fitting_structure_are_refused_not_misdecoded(eight_threads, monkeypatch):
+    """A convolution whose torch-CPU summation none of the candidate structures reproduces raises
+    ReferenceArithmeticUnavailable (here: the native dense 3x3 of a 128x192 picture with the candidate list emptied) instead of
+    decoding with some other arithmetic."""
+    from onedc_amd.codec_module import IntraNoAR
+    from onedc_amd.ref_arith import Calibration, ReferenceArithmeticUnavailable
+    monkeypatch.setattr(Calibration, "im2col_candidates", staticmethod(lambda K: []))
     g = golden("g5_codec_path.npz")
     codec = IntraNoAR(synth.codec_state_dict(0), "cuda:0", prior_arith="torch_cpu")
     codec.update(force=True)

@@ -15,10 +15,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from onedc_amd import kernels as K  # noqa: E402
 from onedc_amd import synth  # noqa: E402
 from onedc_amd.codec_module import IntraNoAR, StreamDesyncError  # noqa: E402
-from onedc_amd.ref_arith import native_gemm_profile  # noqa: E402
+from onedc_amd.ref_arith import intel_profile  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-STREAMS = [("g8_ref_stream_768.npz", None, 8, None), ("g9_ref_stream_768_trained.npz", "trained_like", 8, None),
+STREAMS = [("g5_codec_path.npz", None, 8, "intel"), ("g8_ref_stream_256.npz", None, 8, "intel"),
+           ("g9_ref_stream_256_trained.npz", "trained_like", 8, "intel"),
+           ("g8_ref_stream_768.npz", None, 8, None), ("g9_ref_stream_768_trained.npz", "trained_like", 8, None),
            ("g10_ref_stream_768_trained_1thread.npz", "trained_like", 1, None),
            ("g10_ref_stream_768_trained_1thread.npz", "trained_like", 1, "intel")]
 DEV = "cuda:0"
@@ -45,7 +47,10 @@ def flips_of(codec, g):
         flips.append(int((idx_dev.view(B, N // 4, H, W).cpu().numpy() != g["index_planes"][k]).sum()))
         K.prior_update_dec(params, torch.from_numpy(np.ascontiguousarray(g["symbols"][k])).to(DEV).reshape(-1), y_hat, k)
     flat = y_hat.torch_nchw().cpu().reshape(-1)
-    same = bool(torch.equal(flat[torch.from_numpy(g["y_hat.idx"])], torch.from_numpy(g["y_hat.val"])))
+    if "y_hat" in g:
+        same = bool(torch.equal(flat, torch.from_numpy(g["y_hat"]).reshape(-1)))
+    else:
+        same = bool(torch.equal(flat[torch.from_numpy(g["y_hat.idx"])], torch.from_numpy(g["y_hat.val"])))
     return flips, same
 
 
@@ -72,16 +77,16 @@ def main():
         stream = g["stream"].tobytes()
         sd = synth.codec_state_dict(0, preset=preset)
         ref = IntraNoAR(sd, DEV, prior_arith="torch_cpu", ref_threads=threads,
-                        ref_profile=native_gemm_profile() if prof == "intel" else None)
+                        ref_profile=intel_profile(threads) if prof == "intel" else None)
         ref.update(force=True)
         flips, same = flips_of(ref, g)
         verdict, ms = timed(ref, stream, idx)
         tag = f"{name} (writer: {threads} thread(s), Intel AVX-512 host; structures: " + \
-              ("writer's profile native_gemm_profile(256)" if prof else f"calibrated on this host at {threads} thread(s)") + ")"
+              (f"native shapes from the writer's profile intel_profile({threads}), oneDNN shapes calibrated on this host" if prof else f"calibrated on this host at {threads} thread(s)") + ")"
         print(f"[ref-arith] {tag}")
         print(f"    torch_cpu prior: table-index flips per hop {flips} of {g['index_planes'].size}; y_hat bit-equal: {same}; "
               f"free-running {verdict}" + (f"; entropy decode {ms:.1f} ms / picture (median of 15)" if ms else ""))
-        print(f"    structures (C, OC, H, W): (K block, bias first): {dict(sorted(ref.ref_prior.cal.table.items()))}")
+        print(f"    structures (C, OC, H, W): (K block, bias first): {dict(sorted(ref.ref_prior.cal.table.items(), key=str))}")
         mf = IntraNoAR(sd, DEV)
         mf.update(force=True)
         flips, same = flips_of(mf, g)
