@@ -303,6 +303,21 @@ def intel_profile(threads, kc=256):
     return profile
 
 
+def load_profile(path):
+    """A writer's profile written by tools/cpu_chain_probe.py on the machine that writes the streams (no GPU needed there) ->
+    the dict form `Calibration` takes.  Shapes the probe could not fit (null) are left to the local calibration."""
+    import json
+    raw = json.load(open(path))
+    out = {}
+    for key, v in raw.get("1x1", {}).items():
+        if v is not None:
+            out[tuple(int(t) for t in key.split(","))] = (int(v[0]), int(v[1]))
+    for key, v in raw.get("3x3", {}).items():
+        if v is not None:
+            out[("3x3",) + tuple(int(t) for t in key.split(","))] = tuple(v)
+    return out
+
+
 def native_gemm_profile(kc=256):
     """The one-thread writer on an Intel host (src/inference.py:29 sets one thread): `intel_profile(1, kc)`."""
     return intel_profile(1, kc)

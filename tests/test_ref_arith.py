@@ -36,6 +36,45 @@ def test_index_thresholds_equal_torch_build_indexes():
     assert torch.equal(got, want)
 
 
+def test_cpu_probe_fits_torch_and_profiles_round_trip(tmp_path):
+    """tools/cpu_chain_probe.py (what a WRITER'S machine runs, no GPU): every probed shape gets a structure that reproduces the
+    local torch bit for bit; on an Intel host the native shapes are the ones ref_arith.intel_profile() states; the JSON it writes
+    loads into the dict form Calibration takes."""
+    import importlib.util
+    import json
+    import os
+    from onedc_amd.ref_arith import Calibration, intel_profile, load_profile
+    spec = importlib.util.spec_from_file_location(
+        "cpu_chain_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "cpu_chain_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    intel = any("GenuineIntel" in line for line in open("/proc/cpuinfo"))
+    prev = torch.get_num_threads()
+    try:
+        with __import__("tempfile").TemporaryDirectory() as tmp:
+            lib = probe.build_helper(tmp)
+            for threads in (8, 1):
+                torch.set_num_threads(threads)
+                want = intel_profile(threads)
+                for C, OC, ks, H, W in [(128, 128, 1, 4, 6), (256, 128, 1, 4, 4), (128, 128, 3, 4, 6), (128, 128, 3, 8, 8),
+                                        (256, 128, 1, 8, 12), (128, 128, 3, 16, 16)]:
+                    got = probe.fit(lib, C, OC, ks, H, W)
+                    assert got is not None, (threads, C, OC, ks, H, W)
+                    known = want(C, OC, H, W, ks)
+                    if intel and known is not None:
+                        assert tuple(got) == tuple(known), (threads, C, OC, ks, H, W, got, known)
+                    if ks == 3 and got[0] == "im2col":
+                        assert tuple(got[1:]) in Calibration.im2col_candidates(9 * C)     # the GPU side tries it too
+    finally:
+        torch.set_num_threads(prev)
+    path = tmp_path / "writer.json"
+    json.dump({"host": "x", "threads": 8, "1x1": {"256,128,4,4": [256, 0], "7,128,4,4": None},
+               "3x3": {"128,128,8,8": ["im2col", 4, 288, 2], "128,128,16,16": ["direct"]}}, open(path, "w"))
+    prof = load_profile(str(path))
+    assert prof == {(256, 128, 4, 4): (256, 0), ("3x3", 128, 128, 8, 8): ("im2col", 4, 288, 2),
+                    ("3x3", 128, 128, 16, 16): ("direct",)}
+
+
 @pytest.fixture(scope="module")
 def eight_threads():
     prev = torch.get_num_threads()
