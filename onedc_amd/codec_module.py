@@ -171,7 +171,10 @@ class IntraNoAR:
             raise ValueError(f"prior_arith must be 'mfma', 'torch_cpu' or 'auto', not {prior_arith!r}")
         self.prior_arith = prior_arith
         self.ref_threads = ref_threads            # torch thread count of the writer's configuration (None: torch's current one)
-        self.ref_profile = ref_profile            # known 1x1 structures of the writer (ref_arith.Calibration), or None
+        if isinstance(ref_profile, str):          # YAML form: "intel:<threads>" or the path of a tools/cpu_chain_probe.py JSON
+            from .ref_arith import intel_profile, load_profile
+            ref_profile = intel_profile(int(ref_profile[6:])) if ref_profile.startswith("intel:") else load_profile(ref_profile)
+        self.ref_profile = ref_profile            # known native-path structures of the writer (ref_arith.Calibration), or None
         self.ref_prior = None                     # the reference-arithmetic prior in use (None: the MFMA prior)
         self._ref_priors = {}                     # per calibrated thread count
         self._ref_sd = sd if prior_arith != "mfma" else None

@@ -126,6 +126,9 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
     y2, _ = codec.decompress([g["stream"].tobytes()], idx, trace=trace)
     assert all(np.array_equal(sy, g["symbols"][k]) for k, (ix, sy) in enumerate(trace))
     assert torch.equal(y2.torch_nchw(), y_hat.torch_nchw())
+    # in a batch (the pixel groups of the chain kernel run across picture borders): the same bits per picture
+    yb, _ = codec.decompress([g["stream"].tobytes()] * 3, idx.repeat(3, 1, 1))
+    assert all(torch.equal(yb.torch_nchw()[i], y_hat.torch_nchw()[0]) for i in range(3))
     # the MFMA prior on the same stream: desynchronises (the reason this path exists)
     mfma = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV)
     mfma.update(force=True)
