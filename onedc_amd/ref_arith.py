@@ -11,15 +11,20 @@ v_fma_f32; this module
   * CALIBRATES them: which block length R and which bias position torch-CPU uses for a 1x1 convolution depends on the layer
     shape, the map size and torch's thread count (oneDNN's blocking heuristics, torch's use_mkldnn rule), so for every
     (C, OC, H, W) it meets, `Calibration` runs that convolution once on random data with the LOCAL torch-CPU and takes the
-    (R, bias position) whose GPU result is bit-identical; dense 3x3 and depthwise layers have one known structure that is
-    checked the same way.  A shape nothing reproduces (a dense 3x3 on a map of <= 20 480 elements goes through MKL's sgemm,
-    whose order is not a chain) raises `ReferenceArithmeticUnavailable`: pictures under ~0.16 megapixels,
+    (R, bias position) whose GPU result is bit-identical; the dense 3x3 layers are either oneDNN's direct kernel or -- on maps
+    of <= 20 480 elements, i.e. pictures under ~0.16 megapixels -- aten's im2col + sgemm with a K split that depends on the
+    thread count, found the same way; depthwise layers have one known structure that is checked.  A shape nothing
+    reproduces raises `ReferenceArithmeticUnavailable`,
+  * takes the WRITER'S structures where this host's differ (`profile`): oneDNN's kernels calibrate identically on Intel and
+    AMD hosts, torch's native path (the BLAS sgemm: every 1x1 of a one-thread writer, small inputs of any writer) does not --
+    `intel_profile(threads)` holds what an Intel AVX-512 writer does, `load_profile(path)` what tools/cpu_chain_probe.py
+    measured on the writer's machine,
   * builds the index thresholds from torch's own logarithm.
 
-The calibration describes the torch of THIS host at its CURRENT thread count (`torch.get_num_threads()`): a stream decodes
-when its writer ran the same configuration class -- e.g. the reference on an AVX-512 CPU with 2-8 threads, which is what wrote
-tests/golden/g8_* / g9_*; `torch.set_num_threads(1)` before building calibrates for the single-threaded reference harness
-(src/inference.py:29).  Streams of this package's own encoder do not need any of this (exact-f32 MFMA prior on both sides).
+Without a profile the calibration describes the torch of THIS host at `threads` threads (default `torch.get_num_threads()`):
+a stream decodes when its writer ran the same configuration class -- e.g. the reference on an AVX-512 CPU with 2-8 threads,
+which is what wrote tests/golden/g8_* / g9_*; one thread is the reference harness's own setting (src/inference.py:29,
+tests/golden/g10_*).  Streams of this package's own encoder do not need any of this (exact-f32 MFMA prior on both sides).
 """
 import math
 
