@@ -314,6 +314,10 @@ static int conv_choose(const onedc_conv_params &p) {
         return p.tile == 131 ? -11 : ONEDC_KERNEL_UPS2X2;
     }
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
+#ifdef EXP_TILES
+    // (experiment) smaller LDS footprints = more workgroups per CU on the short-K layers
+    if (!p.in_f32 && p.tile >= 132 && p.tile <= 135) return 1000 + p.tile - 132;
+#endif
     if (p.in_f32) {
         // the f32 matrix cores run at 1/16 of the 16-bit rate: a 128x128x256 tile is 15 us of MFMA time, and the prior
         // networks' maps give 72 .. 576 such tiles for 512 workgroup slots.  Grids of less than two full rounds take the
@@ -401,6 +405,12 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         case ONEDC_KERNEL_128X128: return launch<Tile<128, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_F32_128X128: return launch<Tile<128, 128, 2, 2>, true>(p, st);
         case ONEDC_KERNEL_F32_64X128: return launch<Tile<64, 128, 2, 2>, true>(p, st);
+#ifdef EXP_TILES
+        case 1000: return launch<Tile<128, 64, 4, 1>>(p, st);      // 48 KB: three workgroups per CU
+        case 1001: return launch<Tile<64, 64, 4, 1>>(p, st);       // 32 KB: five
+        case 1002: return launch<Tile<64, 128, 2, 2>>(p, st);      // 48 KB (the existing 64-row tile, forced)
+        case 1003: return launch<Tile<128, 128, 2, 2>>(p, st);     // 64 KB (the existing tile, forced)
+#endif
         default: return id < 0 ? id : -14;
     }
 }

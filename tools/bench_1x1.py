@@ -29,7 +29,8 @@ for name, H, Cin, Cout, k, epi, res in SH:
         r.t.normal_()
     fl = 2.0 * B * H * H * Cout * k * k * Cin
     out = []
-    for tile in (0, 128, 129, 256):
+    tiles = (0, 128, 129, 256) + tuple(int(a) for a in sys.argv[1:])        # extra ids: experiment builds (EXP_TILES: 132..135)
+    for tile in tiles:
         if tile == 256 and Cout % 256:
             out.append("   n/a   ")
             continue
@@ -47,4 +48,5 @@ for name, H, Cin, Cout, k, epi, res in SH:
             out.append(f"{ms * 1e3:6.0f} us {fl / ms / 1e9:5.0f}")
         except Exception:
             out.append("   err   ")
-    print(f"{name:30s} auto {out[0]} | 4w {out[1]} | 129 {out[2]} | 256 {out[3]}")
+    print(f"{name:30s} auto {out[0]} | 4w {out[1]} | 129 {out[2]} | 256 {out[3]}" +
+          "".join(f" | {t} {o}" for t, o in zip(tiles[4:], out[4:])))
