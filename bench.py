@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: 16; encode_decode: 8)")
     ap.add_argument("--size", type=int, default=None, help="picture size (default: 768; encode_decode: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prior-16bit", action="store_true",
+                    help="prior networks on the 16-bit matrix cores (the reference's GPU-autocast precision class) instead of exact "
+                         "f32: a measurement of what the exact-f32 prior costs, not the headline configuration")
     ap.add_argument("--prior-arith", choices=["mfma", "torch_cpu", "auto"], default="mfma",
                     help="arithmetic of the four-part prior: the exact-f32 MFMA path (default, the headline) or the reference's "
                          "CPU arithmetic as fma chains on the GPU (compatibility path for reference-made streams, 8-thread class)")
@@ -327,7 +330,7 @@ def main():
         sds_dev = broadcast_state_dicts(sds, specs, device, rank, world)
     else:                                  # synthetic weights are a pure function of (key, seed): every rank builds its own
         sds = sds_dev = [synth.unet_state_dict(0), synth.codec_state_dict(0), synth.vae_state_dict(0)]
-    model_cfg = {"vae_attn_patch": 16}
+    model_cfg = {"vae_attn_patch": 16, "prior_f32": not args.prior_16bit}
     if args.prior_arith != "mfma":
         model_cfg.update(prior_arith=args.prior_arith, ref_threads=8)
     model = SD15_1step_codec_stage1(model_cfg, device=device).load_state_dicts(*sds_dev)
@@ -567,7 +570,8 @@ def main():
                                   "every rank builds the deterministic synthetic weights itself",
                        "setup_s": round(t_setup, 1),
                        "arithmetic": f"{model.act} storage and MFMA operands (synthesis, UNet, VAE), " +
-                                     ("exact f32 MFMA (prior networks, VAE conv_in)" if args.prior_arith == "mfma" else
+                                     ("16-bit MFMA prior networks (--prior-16bit), exact f32 MFMA (VAE conv_in)" if args.prior_16bit else
+                                      "exact f32 MFMA (prior networks, VAE conv_in)" if args.prior_arith == "mfma" else
                                       f"prior networks in the reference's torch-CPU arithmetic as f32 fma chains on the GPU "
                                       f"(prior_arith={args.prior_arith}, compatibility path), exact f32 MFMA (VAE conv_in)") +
                                      ", f64 (eps -> x0), f32 accumulation everywhere",
