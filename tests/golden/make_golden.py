@@ -396,6 +396,38 @@ def main():
          y_hat=sample_points(y_hat10, 16384),
          y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat10.numpy().tobytes()).digest(), dtype=np.uint8))
 
+    # ---------------------------------------------------------------- G11 a non-square picture, another thread count
+    # 512x768 (the Kodak size: z 8x12, y 32x48), trained-like weights, written with torch.set_num_threads(4): other map sizes for
+    # the decoder's calibration (oneDNN picks its 1x1 blocking by shape AND thread count) than G8-G10's square 768x768 at 8 / 1.
+    print("G11 reference-made stream, trained-like weights, 512x768, torch.set_num_threads(4)")
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        rng11 = np.random.default_rng(11)
+        indices11 = torch.from_numpy(rng11.integers(0, 16384, (1, 8, 12)))
+        z_hat11 = torch.stack([((indices11 // 4 ** d) % 4 - 2).float() / 2 for d in range(7)], dim=1)
+        params11, _ = hyper_dec_t(z_hat11)
+        fused11 = fusion_t(params11)
+        means11 = fused11.chunk(2, 1)[1]
+        y11 = means11 + 1.5 * torch.randn(means11.shape, generator=torch.Generator().manual_seed(1111))
+        out11 = cm.compress_four_part_prior(y11, fused11, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t,
+                                            y_spatial_prior_reduction=reduction_t)
+        yq11, s11, y_hat11 = out11[0:4], out11[4:8], out11[8]
+        ec.reset()
+        planes11 = []
+        for yq, sc in zip(yq11, s11):
+            planes11.append(cm.gaussian_encoder.build_indexes(sc))
+            cm.gaussian_encoder.encode(yq, sc)
+        ec.flush()
+        stream11 = ec.get_encoded_stream()
+        ec.set_stream(stream11)
+        back11 = cm.decompress_four_part_prior(fused11, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t, reduction_t)
+        assert torch.equal(back11, y_hat11)
+    torch.set_num_threads(8)
+    save("g11_ref_stream_512x768_trained_4threads.npz", indices=indices11.int(), stream=np.frombuffer(stream11, np.uint8),
+         symbols=torch.stack(list(yq11)).to(torch.int16), index_planes=torch.stack(planes11).to(torch.int16),
+         y_hat=sample_points(y_hat11, 16384),
+         y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat11.numpy().tobytes()).digest(), dtype=np.uint8))
+
     # ---------------------------------------------------------------- G7 hyper encoder (encode side)
     print("G7 hyper encoder")
     with torch.no_grad():

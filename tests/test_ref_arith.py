@@ -85,7 +85,8 @@ def eight_threads():
 
 # (golden file, synthetic-weight preset, torch threads of its writer)
 REF_STREAMS = [("g8_ref_stream_768.npz", None, 8), ("g9_ref_stream_768_trained.npz", "trained_like", 8),
-               ("g10_ref_stream_768_trained_1thread.npz", "trained_like", 1)]      # one thread: the harness's own setting
+               ("g10_ref_stream_768_trained_1thread.npz", "trained_like", 1),      # one thread: the harness's own setting
+               ("g11_ref_stream_512x768_trained_4threads.npz", "trained_like", 4)]  # non-square (Kodak size), four threads
 
 
 @pytest.mark.gpu
