@@ -428,6 +428,35 @@ def main():
          y_hat=sample_points(y_hat11, 16384),
          y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat11.numpy().tobytes()).digest(), dtype=np.uint8))
 
+    # ---------------------------------------------------------------- G12 a larger picture, stream and digests only
+    # 1024x1024 (z 16x16, y 64x64), trained-like weights, 8 threads.  Only what a decoder needs and what pins its result: indices,
+    # stream, sample points of y_hat and the sha256 of y_hat's f32 bytes / of the symbol planes (the planes themselves would be 2 MB).
+    print("G12 reference-made stream, trained-like weights, 1024x1024 (stream + digests)")
+    with torch.no_grad():
+        rng12 = np.random.default_rng(12)
+        indices12 = torch.from_numpy(rng12.integers(0, 16384, (1, 16, 16)))
+        z_hat12 = torch.stack([((indices12 // 4 ** d) % 4 - 2).float() / 2 for d in range(7)], dim=1)
+        params12, _ = hyper_dec_t(z_hat12)
+        fused12 = fusion_t(params12)
+        means12 = fused12.chunk(2, 1)[1]
+        y12 = means12 + 1.5 * torch.randn(means12.shape, generator=torch.Generator().manual_seed(1212))
+        out12 = cm.compress_four_part_prior(y12, fused12, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t,
+                                            y_spatial_prior_reduction=reduction_t)
+        yq12, s12, y_hat12 = out12[0:4], out12[4:8], out12[8]
+        ec.reset()
+        for yq, sc in zip(yq12, s12):
+            cm.gaussian_encoder.encode(yq, sc)
+        ec.flush()
+        stream12 = ec.get_encoded_stream()
+        ec.set_stream(stream12)
+        back12 = cm.decompress_four_part_prior(fused12, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t, reduction_t)
+        assert torch.equal(back12, y_hat12)
+    save("g12_ref_stream_1024_trained.npz", indices=indices12.int(), stream=np.frombuffer(stream12, np.uint8),
+         y_hat=sample_points(y_hat12, 4096),
+         y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat12.numpy().tobytes()).digest(), dtype=np.uint8),
+         symbols_sha256=np.frombuffer(hashlib.sha256(torch.stack(list(yq12)).to(torch.int16).numpy().tobytes()).digest(),
+                                      dtype=np.uint8))
+
     # ---------------------------------------------------------------- G7 hyper encoder (encode side)
     print("G7 hyper encoder")
     with torch.no_grad():

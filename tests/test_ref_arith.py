@@ -156,6 +156,25 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
 
 
 @pytest.mark.gpu
+def test_reference_made_1024_stream_decodes_to_the_references_digest(eight_threads):
+    """A larger picture (tests/golden/g12: 1024x1024, 524 288 symbols, written at 8 threads): free-running decode in the
+    reference's arithmetic ends on the encoder's state, and the WHOLE y_hat (sha256 of its f32 bytes, NCHW) and all symbol planes
+    (sha256) are the reference's."""
+    import hashlib
+    from onedc_amd.codec_module import IntraNoAR
+    g = golden("g12_ref_stream_1024_trained.npz")
+    codec = IntraNoAR(synth.codec_state_dict(0, preset="trained_like"), "cuda:0", prior_arith="torch_cpu", ref_threads=8)
+    codec.update(force=True)
+    trace = []
+    y_hat, _ = codec.decompress([g["stream"].tobytes()], torch.from_numpy(g["indices"]).to("cuda:0"), trace=trace)
+    got = y_hat.torch_nchw().cpu().contiguous()
+    assert torch.equal(got.reshape(-1)[torch.from_numpy(g["y_hat.idx"])], torch.from_numpy(g["y_hat.val"]))
+    assert hashlib.sha256(got.numpy().tobytes()).digest() == g["y_hat_sha256"].tobytes()
+    sym = np.stack([np.asarray(sy).reshape(1, 32, 64, 64) for _, sy in trace]).astype(np.int16)
+    assert hashlib.sha256(sym.tobytes()).digest() == g["symbols_sha256"].tobytes()
+
+
+@pytest.mark.gpu
 def test_streams_written_in_the_reference_arithmetic_carry_the_references_decisions(eight_threads):
     """The other direction (BASELINE north_star: "identical bitstreams on encode"): for a given latent y, the encoder side of the
     prior in torch_cpu mode produces the symbols, the table indexes and therefore the y stream that the reference's CPU
