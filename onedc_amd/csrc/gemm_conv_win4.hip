@@ -92,12 +92,23 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 
     // ---- patch of this workgroup (same order as the 8-wave kernel: channel tile fastest, bands of four patch rows) ----
     const int tiles_pi = tiles_x * tiles_y;
+#ifdef EXP_W4_PERSIST2
+    // (ablation) a workgroup runs TWO patches back to back; the second one without a prologue (no DMA of its first window and
+    // weights: its K loop multiplies what is in LDS) -- the time a persistent form could reach at best, results of the second
+    // patch are garbage.  Grid = half the tiles.
+    const int total_tiles = tiles_n * tiles_pi * p.B;
+    const int half_tiles = (total_tiles + 1) >> 1;
+    const int logical = xcd_logical_tile(blockIdx.x, half_tiles);
+#else
     const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_pi * p.B);
-    const int pt = dv_n.div(logical);
-    const int n0 = (logical - pt * tiles_n) * 128;
-    const int img = dv_pi.div(pt), pin = pt - img * tiles_pi;
-    int ty, tx;
-    {
+#endif
+    int pt, n0, img, pin, y0, x0;
+    auto decode_tile = [&](int lg) {
+        pt = dv_n.div(lg);
+        n0 = (lg - pt * tiles_n) * 128;
+        img = dv_pi.div(pt);
+        pin = pt - img * tiles_pi;
+        int ty, tx;
         const int band = dv_x.div(pin), inb = pin - band * 4 * tiles_x;
         const int left = tiles_y - band * 4, rows = left < 4 ? left : 4;
         int r;
@@ -115,8 +126,10 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
             r = inb - 3 * tx;
         }
         ty = band * 4 + r;
-    }
-    const int y0 = ty * 16, x0 = tx * 16;           // patch origin (UPS: on the low-resolution grid)
+        y0 = ty * 16;                               // patch origin (UPS: on the low-resolution grid)
+        x0 = tx * 16;
+    };
+    decode_tile(logical);
     const int phase = UPS ? dv_c.div(n0) : 0;       // a 128-row tile of the phase-packed matrix belongs to one phase
     const int PY = phase >> 1, PX = phase & 1;
 
@@ -245,6 +258,13 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) W4_PIN(wrd[kx]);
 
+#ifdef EXP_W4_PERSIST2
+    for (int rep = 0; rep < 2; ++rep) {
+    if (rep == 1) {
+        if (logical + half_tiles >= total_tiles) break;
+        decode_tile(logical + half_tiles);
+    }
+#endif
     f32x4 acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -533,6 +553,10 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
                 }
         }
     }
+#ifdef EXP_W4_PERSIST2
+    __builtin_amdgcn_s_barrier();               // every wave has read its staging rows back before the next K loop's DMA lands
+    }
+#endif
 }
 
 }  // namespace
@@ -555,7 +579,11 @@ static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
     if (blocks > 0x7fffffff) return -1;
     const OnedcFastDiv dv_n((uint32_t)tiles_n), dv_pi((uint32_t)(tiles_x * tiles_y)), dv_x((uint32_t)(4 * tiles_x)),
         dv_c((uint32_t)p.Cout);
+#ifdef EXP_W4_PERSIST2
+    const dim3 grid((unsigned)((blocks + 1) / 2)), block(256);
+#else
     const dim3 grid((unsigned)blocks), block(256);
+#endif
     if (!p.stats)
         hipLaunchKernelGGL((conv_win4_kernel<MODE, 0>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x, dv_c);
     else if (p.stats_gran == 2)
