@@ -278,7 +278,35 @@ class IntraNoAR:
                 pass
             finally:
                 self.ref_prior = None
+        if len(streams_y) > 1 and trace is None:
+            return self._decompress_one_by_one(streams_y, indices, first_error)
         raise first_error
+
+    def _decompress_one_by_one(self, streams_y, indices, batch_error):
+        """"auto" with a batch that no single arithmetic decodes: streams of different producers side by side (this package's
+        and the reference's).  Every picture goes through the attempts alone; the results are gathered into one batch.
+        Pictures that still fail are named in the StreamDesyncError."""
+        outs, bad = [], []
+        for b, s in enumerate(streams_y):
+            try:
+                outs.append(self.decompress([s], indices[b:b + 1]))
+            except StreamDesyncError:
+                outs.append(None)
+                bad.append(b)
+        if bad:
+            raise StreamDesyncError(bad) from batch_error
+        B = len(outs)
+        gathered = []
+        for part in range(2):                                   # y_hat (f32), z_semantic (16 bit)
+            v0 = outs[0][part]
+            n = v0.H * v0.W
+            allv = new_view(B, v0.H, v0.W, v0.C, self.device, v0.t.dtype)
+            for b, o in enumerate(outs):
+                v = o[part]
+                src = v.t[:n * v.cs].view(n, v.cs)[:, v.co:v.co + v.C]
+                allv.t[b * n * v.C:(b + 1) * n * v.C].view(n, v.C).copy_(src)
+            gathered.append(allv)
+        return gathered[0], gathered[1]
 
     @K.in_own_format
     @torch.no_grad()

@@ -156,6 +156,57 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
 
 
 @pytest.mark.gpu
+def test_auto_mode_decodes_a_batch_of_mixed_producers(eight_threads):
+    """prior_arith="auto" on a batch that holds a reference-made stream BETWEEN two streams of this package's encoder: no single
+    arithmetic decodes the batch, every picture is decoded in its writer's; a corrupt stream among them is named."""
+    from onedc_amd.codec_module import IntraNoAR, StreamDesyncError
+    from onedc_amd.entropy.utils import decode_i
+    DEV = "cuda:0"
+    g = golden("g9_ref_stream_768_trained.npz")
+    auto = IntraNoAR(synth.codec_state_dict(0, preset="trained_like"), DEV, prior_arith="auto")
+    auto.update(force=True)
+    idx_ref = torch.from_numpy(g["indices"]).to(DEV)
+    idx_own = torch.from_numpy(np.random.default_rng(3).integers(0, 16384, (2, 12, 12)).astype(np.int32)).to(DEV)
+    blobs, own = auto.encode_latents(idx_own, None, noise_seed=7)
+    own_streams = [decode_i(b, 14, 64)["bit_stream_y"] for b in blobs]
+    streams = [own_streams[0], g["stream"].tobytes(), own_streams[1]]
+    idx = torch.cat([idx_own[0:1], idx_ref, idx_own[1:2]])
+    y, z = auto.decompress(streams, idx)
+    got = y.torch_nchw().cpu()
+    assert torch.equal(got[0], own.torch_nchw().cpu()[0]) and torch.equal(got[2], own.torch_nchw().cpu()[1])
+    assert torch.equal(got[1].reshape(-1)[torch.from_numpy(g["y_hat.idx"])], torch.from_numpy(g["y_hat.val"]))
+    assert z.B == 3 and auto.ref_prior is None
+    bad = bytearray(own_streams[1])
+    bad[len(bad) // 3] ^= 0x55
+    with pytest.raises(StreamDesyncError) as e:
+        auto.decompress([own_streams[0], g["stream"].tobytes(), bytes(bad)], idx)
+    assert e.value.images == [2]
+
+
+@pytest.mark.gpu
+def test_model_decodes_container_files_of_both_producers_in_one_batch(eight_threads):
+    """The whole decoder (`SD15_1step_codec_stage1.decode`, config key `prior_arith: auto`) on three 768x768 container files in one
+    batch -- own, reference-made (tests/golden/g9: the y stream the reference wrote, in the reference's container format), own:
+    three finite pictures, each bit-identical to the picture the same file decodes to alone."""
+    from onedc_amd.entropy.utils import decode_i, encode_i, pack_indices
+    from onedc_amd.model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+    DEV = "cuda:0"
+    g = golden("g9_ref_stream_768_trained.npz")
+    model = SD15_1step_codec_stage1({"vae_attn_patch": 16, "prior_arith": "auto"}, device=DEV).load_synthetic(0, preset="trained_like")
+    model.codec_model.update(force=True)
+    idx_own = torch.from_numpy(np.random.default_rng(4).integers(0, 16384, (2, 12, 12)).astype(np.int32)).to(DEV)
+    own_blobs, _ = model.codec_model.encode_latents(idx_own, None, noise_seed=9)
+    ref_blob = encode_i(768, 768, g["stream"].tobytes(), pack_indices(g["indices"].reshape(-1), 14), b"", 0)
+    assert decode_i(ref_blob, 14, 64)["bit_stream_y"] == g["stream"].tobytes()
+    files = [own_blobs[0], ref_blob, own_blobs[1]]
+    batch = model.decode(stream=files, unit_range=True)
+    assert batch.shape == (3, 3, 768, 768) and bool(torch.isfinite(batch).all())
+    for b, f in enumerate(files):
+        alone = model.decode(stream=[f], unit_range=True)
+        assert torch.equal(alone[0], batch[b]), b
+
+
+@pytest.mark.gpu
 def test_reference_made_1024_stream_decodes_to_the_references_digest(eight_threads):
     """A larger picture (tests/golden/g12: 1024x1024, 524 288 symbols, written at 8 threads): free-running decode in the
     reference's arithmetic ends on the encoder's state, and the WHOLE y_hat (sha256 of its f32 bytes, NCHW) and all symbol planes
