@@ -252,8 +252,9 @@ int onedc_latent_sample(const float *moments, const float *noise, float *out, in
  *                       added in order; when !bias_first the bias is added to the first block's sum (native gemm path).  act 0 none, 1 LeakyReLU(slope), 2 ConvFFN3's gate
  *                       LeakyReLU(rows n, slope) + LeakyReLU(rows n + OC/2, slope2) (dcvc.py:353-367: OC/2 outputs);
  *                       shuffle = 1 stores through F.pixel_shuffle(., 2) (dcvc.py:183-208; y is the (2H, 2W) map, no res)
- *   onedc_ref_conv3x3   dense 3x3, pad 1: bias + per 16 input channels a chain from 0 over (ky, kx, channel); w3T [9][C][OC];
- *                       y = [LeakyReLU(slope)](.) [+ res]
+ *   onedc_ref_conv3x3   dense 3x3, pad 1, w3T [9][C][OC]: (icb 16, one_chain 0) oneDNN avx512: bias + per 16 input channels a chain
+ *                       from 0 over (ky, kx, channel); (icb 8, one_chain 1) oneDNN avx2: one chain from the bias over (8-channel
+ *                       block, ky, kx, channel); y = [LeakyReLU(slope)](.) [+ res]
  *   onedc_ref_conv3x3_im2col  the same layer where torch takes its native path (maps of <= 20 480 elements: im2col + sgemm):
  *                       wKT [9 C][OC] with k = c * 9 + ky * 3 + kx; K in `parts` equal parts, blocks of `blk` inside a part
  *                       (chains from 0 added in order), bias joined to part 0, parts [0, split) and [split, parts) summed in
@@ -265,7 +266,7 @@ int onedc_ref_conv1x1(const float *x, int x_cs, int x_co, const float *wT, const
                       int act, float slope, float slope2, int shuffle, int H, int W, void *stream);
 int onedc_ref_conv3x3(const float *x, int x_cs, int x_co, const float *w3T, const float *bias, const float *res, int r_cs,
                       int r_co, float *y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int leaky_on, float slope,
-                      void *stream);
+                      int icb, int one_chain, void *stream);
 int onedc_ref_conv3x3_im2col(const float *x, int x_cs, int x_co, const float *wKT, const float *bias, const float *res, int r_cs,
                              int r_co, float *y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int parts, int blk,
                              int split, int leaky_on, float slope, void *stream);

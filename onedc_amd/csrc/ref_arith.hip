@@ -14,6 +14,8 @@
 //        (csrc/elementwise.hip: dwconv3x3_f32_kernel is exactly this already)
 //   dense 3x3, oneDNN jit:avx512_core: per block of 16 input channels one fma chain from 0 over (ky, kx, channel in block),
 //        padding taps skipped; the block sums are added one after the other to the bias
+//   dense 3x3, oneDNN jit:avx2 (a writer without AVX-512, or DNNL_MAX_CPU_ISA=AVX2): ONE fma chain from the bias over
+//        (8-channel block, ky, kx, channel in block); its 1x1 kernel is the jit_1x1 family above with blocks of 128
 //   dense 3x3 on maps of <= 20 480 elements (pictures under ~0.16 MP), native: im2col + MKL sgemm, beta = 1 on a bias-filled
 //        output; k = (channel, ky, kx).  K is cut into T equal parts (one per group of MKL threads), every part blocks of `blk`
 //        (chains from 0, added in order); the bias joins part 0; parts [0, s) are added in order, parts [s, T) are added in
@@ -114,7 +116,10 @@ __global__ void ref_conv1x1_kernel(const float *__restrict__ x, int x_cs, int x_
     }
 }
 
-// dense 3x3, pad 1: total = bias; per 16 input channels a chain from 0 over (ky, kx, channel); total += chain.  w3T [9][C][OC]
+// dense 3x3, pad 1, oneDNN's direct kernels.  w3T [9][C][OC].
+//   avx512_core (ICB = 16, !ONE): total = bias; per 16 input channels a chain from 0 over (ky, kx, channel); total += chain
+//   avx2        (ICB = 8, ONE):   ONE chain that starts from the bias and runs over (8-channel block, ky, kx, channel)
+template <int ICB, bool ONE>
 __global__ void ref_conv3x3_kernel(const float *__restrict__ x, int x_cs, int x_co, const float *__restrict__ w3T,
                                    const float *__restrict__ bias, const float *__restrict__ res, int r_cs, int r_co,
                                    float *__restrict__ y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int leaky_on,
@@ -128,8 +133,9 @@ __global__ void ref_conv3x3_kernel(const float *__restrict__ x, int x_cs, int x_
         const int yy = (int)((pix / W) % H);
         const int64_t b = pix / ((int64_t)W * H);
         float tot = bias ? bias[oc] : 0.f;
-        for (int icb = 0; icb < C; icb += 16) {
-            float acc = 0.f;
+        float acc = ONE ? tot : 0.f;
+        for (int icb = 0; icb < C; icb += ICB) {
+            if (!ONE) acc = 0.f;
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = yy + ky - 1;
                 if (iy < 0 || iy >= H) continue;
@@ -139,12 +145,13 @@ __global__ void ref_conv3x3_kernel(const float *__restrict__ x, int x_cs, int x_
                     const float *xp = x + ((b * H + iy) * W + ix) * x_cs + x_co + icb;
                     const float *wp = w3T + ((int64_t)(ky * 3 + kx) * C + icb) * OC + oc;
 #pragma unroll
-                    for (int ii = 0; ii < 16; ++ii) acc = __builtin_fmaf(xp[ii], wp[(int64_t)ii * OC], acc);
+                    for (int ii = 0; ii < ICB; ++ii) acc = __builtin_fmaf(xp[ii], wp[(int64_t)ii * OC], acc);
                 }
             }
-            tot = tot + acc;
+            if (!ONE) tot = tot + acc;
         }
-        float out = leaky_on ? ref_leaky(tot, slope) : tot;
+        float out = ONE ? acc : tot;
+        if (leaky_on) out = ref_leaky(out, slope);
         if (res) out = out + res[pix * r_cs + r_co + oc];
         y[pix * y_cs + y_co + oc] = out;
     }
@@ -266,11 +273,16 @@ int onedc_ref_conv1x1(const float *x, int x_cs, int x_co, const float *wT, const
 
 int onedc_ref_conv3x3(const float *x, int x_cs, int x_co, const float *w3T, const float *bias, const float *res, int r_cs,
                       int r_co, float *y, int y_cs, int y_co, int B, int H, int W, int C, int OC, int leaky_on, float slope,
-                      void *stream) {
-    if (!x || !w3T || !y || (C & 15) || OC < 1 || B < 1 || H < 1 || W < 1) return -1;
+                      int icb, int one_chain, void *stream) {
+    if (!x || !w3T || !y || OC < 1 || B < 1 || H < 1 || W < 1) return -1;
+    if (!((icb == 16 && !one_chain) || (icb == 8 && one_chain)) || (C % icb)) return -2;
     const int64_t n = (int64_t)B * H * W * OC;
-    hipLaunchKernelGGL(ref_conv3x3_kernel, dim3(ref_grid(n)), dim3(256), 0, as_stream(stream), x, x_cs, x_co, w3T, bias, res,
-                       r_cs, r_co, y, y_cs, y_co, B, H, W, C, OC, leaky_on, slope);
+    if (icb == 16)
+        hipLaunchKernelGGL((ref_conv3x3_kernel<16, false>), dim3(ref_grid(n)), dim3(256), 0, as_stream(stream), x, x_cs, x_co,
+                           w3T, bias, res, r_cs, r_co, y, y_cs, y_co, B, H, W, C, OC, leaky_on, slope);
+    else
+        hipLaunchKernelGGL((ref_conv3x3_kernel<8, true>), dim3(ref_grid(n)), dim3(256), 0, as_stream(stream), x, x_cs, x_co,
+                           w3T, bias, res, r_cs, r_co, y, y_cs, y_co, B, H, W, C, OC, leaky_on, slope);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

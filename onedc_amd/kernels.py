@@ -124,7 +124,7 @@ SIGNATURES = {
     "onedc_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
     "onedc_mxfp8_roundtrip": (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "onedc_ref_conv1x1": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _L, _I, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P]),
-    "onedc_ref_conv3x3": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "onedc_ref_conv3x3": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "onedc_ref_conv3x3_im2col": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_ref_prior_indexes": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
@@ -566,12 +566,14 @@ def ref_conv1x1(x, wT, bias, y, *, blk, bias_first, act=0, slope=0.01, slope2=0.
     return y
 
 
-def ref_conv3x3(x, w3T, bias, y, *, leaky=None, res=None):
-    """Reference-arithmetic dense 3x3 conv: w3T f32 [9][C][OC]; y = [LeakyReLU(leaky)](bias + block chains) [+ res]."""
+def ref_conv3x3(x, w3T, bias, y, *, leaky=None, res=None, icb=16, one_chain=False):
+    """Reference-arithmetic dense 3x3 conv (oneDNN's direct kernels): w3T f32 [9][C][OC]; (icb 16, block chains added to the bias)
+    = avx512, (icb 8, one chain from the bias) = avx2; y = [LeakyReLU(leaky)](.) [+ res]."""
     _, C, OC = w3T.shape
     _ok(lib().onedc_ref_conv3x3(x.ptr, x.cs, x.co, w3T.data_ptr(), _ptr(bias), (res.ptr if res is not None else None),
                                 (res.cs if res is not None else 0), (res.co if res is not None else 0), y.ptr, y.cs, y.co,
-                                x.B, x.H, x.W, C, OC, int(leaky is not None), float(leaky or 0.0), stream()), "onedc_ref_conv3x3")
+                                x.B, x.H, x.W, C, OC, int(leaky is not None), float(leaky or 0.0), int(icb), int(bool(one_chain)),
+                                stream()), "onedc_ref_conv3x3")
     return y
 
 

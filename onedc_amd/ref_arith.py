@@ -139,8 +139,9 @@ class Calibration:
         return out
 
     def conv3x3(self, C, OC, H, W):
-        """-> ("direct",) (oneDNN's kernel: 16-channel block chains) or ("im2col", parts, block, split) (torch's native path on
-        maps of <= 20 480 elements), whichever reproduces the local torch (or what the writer's profile says)."""
+        """-> ("direct", 16, 0) (oneDNN avx512: 16-channel block chains added to the bias), ("direct", 8, 1) (oneDNN avx2: one chain
+        from the bias) or ("im2col", parts, block, split) (torch's native path on maps of <= 20 480 elements), whichever reproduces
+        the local torch (or what the writer's profile says; a bare ("direct",) there means the avx512 form)."""
         key = ("3x3", C, OC, H, W)
         if key in self.table:
             return self.table[key]
@@ -158,10 +159,12 @@ class Calibration:
         bd = b.to(dev)
         got = lambda: yv.t[:H * W * OC].view(H, W, OC).cpu()
         found = None
-        if C % 16 == 0:
-            K.ref_conv3x3(xv, w.permute(2, 3, 1, 0).reshape(9, C, OC).contiguous().to(dev), bd, yv)
-            if torch.equal(got(), ref):
-                found = ("direct",)
+        w3T = w.permute(2, 3, 1, 0).reshape(9, C, OC).contiguous().to(dev)
+        for icb, one in ((16, False), (8, True)):              # oneDNN's direct kernels: avx512_core, avx2
+            if C % icb == 0 and found is None:
+                K.ref_conv3x3(xv, w3T, bd, yv, icb=icb, one_chain=one)
+                if torch.equal(got(), ref):
+                    found = ("direct", icb, int(one))
         if found is None and C * H * W <= 20480:
             wKT = w.reshape(OC, C * 9).t().contiguous().to(dev)
             for T, blk, split in self.im2col_candidates(9 * C):
@@ -281,7 +284,8 @@ class _RBU:
         how = self.cal.conv3x3(self.C, self.OC, t.H, t.W)
         out = _v(t.B, t.H, t.W, self.OC, self.device)
         if how[0] == "direct":
-            return K.ref_conv3x3(t, self.w3T, self.b3, out, leaky=0.1, res=identity)
+            icb, one = (how[1], how[2]) if len(how) > 2 else (16, 0)
+            return K.ref_conv3x3(t, self.w3T, self.b3, out, leaky=0.1, res=identity, icb=icb, one_chain=one)
         return K.ref_conv3x3_im2col(t, self.wKT, self.b3, out, parts=how[1], blk=how[2], split=how[3], leaky=0.1, res=identity)
 
 

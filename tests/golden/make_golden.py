@@ -457,6 +457,40 @@ def main():
          symbols_sha256=np.frombuffer(hashlib.sha256(torch.stack(list(yq12)).to(torch.int16).numpy().tobytes()).digest(),
                                       dtype=np.uint8))
 
+    # ---------------------------------------------------------------- G13 a writer without AVX-512
+    # The same capture with oneDNN capped to AVX2 (DNNL_MAX_CPU_ISA=AVX2 in the environment of THIS process: what a reference on an
+    # AVX2-only host -- e.g. an EPYC before Zen 4 -- runs): other 1x1 blockings, and a dense 3x3 that is one chain from the bias.
+    # 768x768, trained-like weights, 8 threads; stream + digests.  Written only when the cap is set:
+    #     DNNL_MAX_CPU_ISA=AVX2 python tests/golden/make_golden.py g13
+    if os.environ.get("DNNL_MAX_CPU_ISA", "").upper() == "AVX2":
+        print("G13 reference-made stream, oneDNN capped to AVX2, trained-like weights, 768x768 (stream + digests)")
+        with torch.no_grad():
+            rng13 = np.random.default_rng(13)
+            indices13 = torch.from_numpy(rng13.integers(0, 16384, (1, 12, 12)))
+            z_hat13 = torch.stack([((indices13 // 4 ** d) % 4 - 2).float() / 2 for d in range(7)], dim=1)
+            params13, _ = hyper_dec_t(z_hat13)
+            fused13 = fusion_t(params13)
+            means13 = fused13.chunk(2, 1)[1]
+            y13 = means13 + 1.5 * torch.randn(means13.shape, generator=torch.Generator().manual_seed(1313))
+            out13 = cm.compress_four_part_prior(y13, fused13, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t,
+                                                y_spatial_prior_reduction=reduction_t)
+            yq13, s13, y_hat13 = out13[0:4], out13[4:8], out13[8]
+            ec.reset()
+            for yq, sc in zip(yq13, s13):
+                cm.gaussian_encoder.encode(yq, sc)
+            ec.flush()
+            stream13 = ec.get_encoded_stream()
+            ec.set_stream(stream13)
+            back13 = cm.decompress_four_part_prior(fused13, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t, reduction_t)
+            assert torch.equal(back13, y_hat13)
+        save("g13_ref_stream_768_trained_avx2.npz", indices=indices13.int(), stream=np.frombuffer(stream13, np.uint8),
+             y_hat=sample_points(y_hat13, 4096),
+             y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat13.numpy().tobytes()).digest(), dtype=np.uint8),
+             symbols_sha256=np.frombuffer(hashlib.sha256(torch.stack(list(yq13)).to(torch.int16).numpy().tobytes()).digest(),
+                                          dtype=np.uint8))
+    elif not ONLY or any(o.startswith("g13") for o in ONLY):
+        print("G13 skipped: needs DNNL_MAX_CPU_ISA=AVX2 in the environment (python tests/golden/make_golden.py g13)")
+
     # ---------------------------------------------------------------- G7 hyper encoder (encode side)
     print("G7 hyper encoder")
     with torch.no_grad():

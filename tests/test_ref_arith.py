@@ -69,10 +69,10 @@ def test_cpu_probe_fits_torch_and_profiles_round_trip(tmp_path):
         torch.set_num_threads(prev)
     path = tmp_path / "writer.json"
     json.dump({"host": "x", "threads": 8, "1x1": {"256,128,4,4": [256, 0], "7,128,4,4": None},
-               "3x3": {"128,128,8,8": ["im2col", 4, 288, 2], "128,128,16,16": ["direct"]}}, open(path, "w"))
+               "3x3": {"128,128,8,8": ["im2col", 4, 288, 2], "128,128,16,16": ["direct", 16, 0]}}, open(path, "w"))
     prof = load_profile(str(path))
     assert prof == {(256, 128, 4, 4): (256, 0), ("3x3", 128, 128, 8, 8): ("im2col", 4, 288, 2),
-                    ("3x3", 128, 128, 16, 16): ("direct",)}
+                    ("3x3", 128, 128, 16, 16): ("direct", 16, 0)}
 
 
 @pytest.fixture(scope="module")
@@ -223,6 +223,36 @@ def test_reference_made_1024_stream_decodes_to_the_references_digest(eight_threa
     assert hashlib.sha256(got.numpy().tobytes()).digest() == g["y_hat_sha256"].tobytes()
     sym = np.stack([np.asarray(sy).reshape(1, 32, 64, 64) for _, sy in trace]).astype(np.int16)
     assert hashlib.sha256(sym.tobytes()).digest() == g["symbols_sha256"].tobytes()
+
+
+@pytest.mark.gpu
+def test_stream_of_an_avx2_writer_decodes_with_the_writers_profile(eight_threads):
+    """A writer WITHOUT AVX-512 (tests/golden/g13: the reference with oneDNN capped to AVX2, 8 threads): its 1x1 blockings and its
+    one-chain dense 3x3 come from the profile tools/cpu_chain_probe.py wrote on the writer's machine
+    (tests/golden/profile_intel_avx2_8threads_768.json) -- this host's torch, whatever its instruction set, is not asked.
+    Whole y_hat and symbol planes to the reference's sha256; the avx512 calibration of this host raises StreamDesyncError."""
+    import hashlib
+    import os
+    from onedc_amd.codec_module import IntraNoAR, StreamDesyncError
+    from onedc_amd.ref_arith import load_profile
+    g = golden("g13_ref_stream_768_trained_avx2.npz")
+    prof = load_profile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "profile_intel_avx2_8threads_768.json"))
+    assert prof[("3x3", 128, 128, 48, 48)] == ("direct", 8, 1)
+    idx = torch.from_numpy(g["indices"]).to("cuda:0")
+    codec = IntraNoAR(synth.codec_state_dict(0, preset="trained_like"), "cuda:0", prior_arith="torch_cpu", ref_threads=8,
+                      ref_profile=prof)
+    codec.update(force=True)
+    trace = []
+    y_hat, _ = codec.decompress([g["stream"].tobytes()], idx, trace=trace)
+    got = y_hat.torch_nchw().cpu().contiguous()
+    assert hashlib.sha256(got.numpy().tobytes()).digest() == g["y_hat_sha256"].tobytes()
+    sym = np.stack([np.asarray(sy).reshape(1, 32, 48, 48) for _, sy in trace]).astype(np.int16)
+    assert hashlib.sha256(sym.tobytes()).digest() == g["symbols_sha256"].tobytes()
+    if torch.backends.cpu.get_cpu_capability() == "AVX512":
+        local = IntraNoAR(synth.codec_state_dict(0, preset="trained_like"), "cuda:0", prior_arith="torch_cpu", ref_threads=8)
+        local.update(force=True)
+        with pytest.raises(StreamDesyncError):
+            local.decompress([g["stream"].tobytes()], idx)
 
 
 @pytest.mark.gpu

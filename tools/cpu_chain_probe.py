@@ -13,7 +13,8 @@ real fused multiply-adds (a few lines of C compiled with `gcc -mfma -ffp-contrac
 with `F.conv2d` bit for bit.  The families are exactly the ones the GPU kernels implement:
     1x1   input channels in blocks of R; block sums added in order; the bias either starts the first chain (oneDNN jit_1x1) or
           is added to the first block's sum (native)
-    3x3   "direct": bias + per 16 input channels one chain over (ky, kx, channel) (oneDNN jit), or
+    3x3   "direct": bias + per 16 input channels one chain over (ky, kx, channel) (oneDNN jit avx512), or one chain from the
+          bias over (8-channel block, ky, kx, channel) (oneDNN jit avx2), or
           "im2col": k = (channel, ky, kx), K in T parts, blocks inside a part, parts [0, s) and [s, T) summed in order, then added
 """
 import argparse
@@ -48,6 +49,21 @@ void gemm_parts(const float *X, const float *Wm, const float *bias, float *out, 
                 out[((int64_t)p * OC + oc) * parts + pi] = tot;
             }
 }
+// depthwise 3x3, pad 1: one chain from the bias over the taps, row-major, padding taps skipped.  x [H][W][C], w [C][9]
+void dw3x3(const float *x, const float *w, const float *bias, float *y, int H, int W, int C) {
+    for (int yy = 0; yy < H; ++yy)
+        for (int xx = 0; xx < W; ++xx)
+            for (int c = 0; c < C; ++c) {
+                float acc = bias[c];
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        int iy = yy + ky - 1, ix = xx + kx - 1;
+                        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                        acc = __builtin_fmaf(x[(iy * W + ix) * C + c], w[c * 9 + ky * 3 + kx], acc);
+                    }
+                y[(yy * W + xx) * C + c] = acc;
+            }
+}
 """
 
 
@@ -75,7 +91,7 @@ def f32(a):
 
 
 def fit(lib, C, OC, ks, H, W):
-    """-> 1x1: [block, bias_first]; 3x3: ["direct"] or ["im2col", parts, block, split]; None when nothing fits."""
+    """-> 1x1: [block, bias_first]; 3x3: ["direct", icb, one_chain] or ["im2col", parts, block, split]; None when nothing fits."""
     g = torch.Generator().manual_seed(C * 131 + OC * 7 + H)
     x = torch.randn(1, C, H, W, generator=g)
     w = torch.randn(OC, C, ks, ks, generator=g) / math.sqrt(C * ks * ks)
@@ -112,7 +128,12 @@ def fit(lib, C, OC, ks, H, W):
         for i in range(C // 16):
             y = f32(y + po[..., i])
         if np.array_equal(y, ref):
-            return ["direct"]
+            return ["direct", 16, 0]
+    if C % 8 == 0:                       # oneDNN direct, avx2: ONE chain from the bias over (8-channel block, ky, kx, channel)
+        Xo = np.ascontiguousarray(X.reshape(-1, C // 8, 8, 9).transpose(0, 1, 3, 2).reshape(-1, K))
+        Wo = np.ascontiguousarray(Wm.reshape(OC, C // 8, 8, 9).transpose(0, 1, 3, 2).reshape(OC, K))
+        if np.array_equal(parts_of(lib, Xo, Wo, bn, [0, K], K, 1)[..., 0], ref):
+            return ["direct", 8, 1]
     for T in (1, 2, 3, 4, 6, 8):
         if K % T:
             continue
@@ -143,6 +164,23 @@ def fit(lib, C, OC, ks, H, W):
     return None
 
 
+def fit_dw(lib, C, H, W):
+    """Depthwise 3x3 (always oneDNN's jit_dw): is it the bias-first chain over the taps that csrc/elementwise.hip evaluates?"""
+    g = torch.Generator().manual_seed(C * 131 + H)
+    x = torch.randn(1, C, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    b = torch.randn(C, generator=g) * 0.05
+    with torch.no_grad():
+        ref = F.conv2d(x, w, b, padding=1, groups=C)[0].permute(1, 2, 0).contiguous().numpy()
+    xn = np.ascontiguousarray(x[0].permute(1, 2, 0).numpy())
+    wn = np.ascontiguousarray(w.reshape(C, 9).numpy())
+    bn = np.ascontiguousarray(b.numpy())
+    y = np.empty((H, W, C), np.float32)
+    ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
+    lib.dw3x3(ptr(xn), ptr(wn), ptr(bn), ptr(y), H, W, C)
+    return ["taps_from_bias"] if np.array_equal(y, ref) else None
+
+
 def prior_shapes(h, w):
     """Every convolution shape (C, OC, k, H, W) of the prior networks (codec_module.py:145-166, 205-209; compression_model.py:
     369-407) for a z map of h x w -- dense convolutions only (the depthwise ones always run in oneDNN's jit_dw)."""
@@ -165,7 +203,8 @@ def main(argv=None):
     a = ap.parse_args(argv)
     torch.set_num_threads(a.threads)
     cpu = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
-    prof = {"host": cpu, "torch": torch.__version__, "threads": a.threads, "1x1": {}, "3x3": {}}
+    prof = {"host": cpu, "torch": torch.__version__, "threads": a.threads, "onednn_isa_cap": os.environ.get("DNNL_MAX_CPU_ISA", ""),
+            "1x1": {}, "3x3": {}, "dw3x3": {}}
     with tempfile.TemporaryDirectory() as tmp:
         lib = build_helper(tmp)
         for size in a.size or ["768x768"]:
@@ -178,6 +217,11 @@ def main(argv=None):
                     continue
                 tab[key] = fit(lib, C, OC, ks, hh, ww)
                 print(f"[probe] {a.threads} thread(s) {ks}x{ks} {C:4d} -> {OC:4d} on {hh:3d}x{ww:<3d}: {tab[key]}", flush=True)
+            for lv, Cd in ((0, 128), (1, 128), (2, 128), (2, 256)):      # the depthwise 3x3 of the DCB4 blocks at each level
+                key = f"{Cd},{h << lv},{w << lv}"
+                if key not in prof["dw3x3"]:
+                    prof["dw3x3"][key] = fit_dw(lib, Cd, h << lv, w << lv)
+                    print(f"[probe] {a.threads} thread(s) depthwise 3x3 {Cd:4d} on {h << lv:3d}x{w << lv:<3d}: {prof['dw3x3'][key]}", flush=True)
     if a.out:
         json.dump(prof, open(a.out, "w"), indent=1)
         print(f"[probe] profile of {cpu} at {a.threads} thread(s) -> {a.out}")
