@@ -158,8 +158,8 @@ class IntraNoAR:
         made of, calibrated against the local torch (onedc_amd/ref_arith.py) -- so that y streams written by the reference
         decode here, and streams written here in this mode decode there.  ~10x slower prior; pictures above ~0.16 MP.
         "auto": decode with the MFMA prior; a stream that desynchronises is tried again in the reference's arithmetic,
-        calibrated for torch's current thread count and then for the other configuration class (one thread <-> several:
-        torch picks oneDNN or its native gemm path by that), before StreamDesyncError is raised.
+        calibrated for `ref_threads` / torch's current thread count and then for 8, 1 and 16 threads (the classes torch-CPU's
+        kernel choice falls into), a batch of mixed producers picture by picture, before StreamDesyncError is raised.
         ref_threads: the writer's torch thread count to calibrate "torch_cpu" for (None: torch's current count).
         ref_profile: the writer's 1x1 structures where known (ref_arith.Calibration: dict or callable), e.g.
         ref_arith.native_gemm_profile() for a one-thread reference on an Intel host."""
@@ -263,8 +263,13 @@ class IntraNoAR:
         if self.prior_arith != "auto":
             return self._decompress_once(streams_y, indices, trace)
         cur = torch.get_num_threads()
-        attempts = [None, self.ref_threads or cur]
-        attempts.append(1 if attempts[1] > 1 else 8)
+        # the MFMA prior, then the reference's arithmetic calibrated for the configuration classes a writer may have used: the
+        # stated / current thread count, 8 (2-8 threads are one class on pictures above ~0.16 MP), 1 (the reference harness's own
+        # setting, src/inference.py:29: torch's native gemm path), 16 (oneDNN blocks 1x1 differently from 16 threads on)
+        attempts = [None]
+        for t in (self.ref_threads or cur, 8, 1, 16):
+            if t not in attempts:
+                attempts.append(t)
         first_error = None
         for threads in attempts:
             self.ref_prior = None if threads is None else self._reference_prior(threads)
