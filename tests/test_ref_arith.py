@@ -156,6 +156,20 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
 
 
 @pytest.mark.gpu
+def test_z_only_latents_in_the_reference_arithmetic_are_the_references_bits(eight_threads):
+    """The ex-low-rate model (forward_four_part_prior_recon_with_z, compression_model.py:421-465: y_hat = the prior's means, no
+    symbols) in the reference's arithmetic: y_hat of tests/golden/g5 (written by the reference's modules, 128x192, 8 threads)
+    bit for bit -- with the exact-f32 MFMA prior the same tensor agrees to 1e-5 (tests/test_gpu_parity.py::test_z_only_prior)."""
+    from onedc_amd.codec_module import IntraNoAR
+    from onedc_amd.ref_arith import intel_profile
+    g = golden("g5_codec_path.npz")
+    codec = IntraNoAR(synth.codec_state_dict(0), "cuda:0", prior_arith="torch_cpu", ref_threads=8, ref_profile=intel_profile(8))
+    codec.update(force=True)
+    y_hat, _ = codec.recon_with_z(torch.from_numpy(g["indices"]).to("cuda:0"))
+    assert torch.equal(y_hat.torch_nchw().cpu(), torch.from_numpy(g["y_hat_zonly"]))
+
+
+@pytest.mark.gpu
 def test_auto_mode_decodes_a_batch_of_mixed_producers(eight_threads):
     """prior_arith="auto" on a batch that holds a reference-made stream BETWEEN two streams of this package's encoder: no single
     arithmetic decodes the batch, every picture is decoded in its writer's; a corrupt stream among them is named."""
