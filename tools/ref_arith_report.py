@@ -1,5 +1,5 @@
 """Report of the reference-arithmetic prior (IntraNoAR(prior_arith="torch_cpu")) on this machine: the calibrated structures of
-this host's torch at 1 and 8 threads, and for every reference-made 768x768 golden stream the teacher-forced table-index flips,
+this host's torch at the writer's thread count, and for the reference-made golden streams that carry their planes the teacher-forced table-index flips,
 the free-running verdict and the time of the entropy decode in both arithmetics.  Output: stdout (copy to profiles/).
 
     python tools/ref_arith_report.py
@@ -20,6 +20,7 @@ from onedc_amd.ref_arith import intel_profile  # noqa: E402
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 STREAMS = [("g5_codec_path.npz", None, 8, "intel"), ("g8_ref_stream_256.npz", None, 8, "intel"),
            ("g9_ref_stream_256_trained.npz", "trained_like", 8, "intel"),
+           ("g11_ref_stream_512x768_trained_4threads.npz", "trained_like", 4, None),
            ("g8_ref_stream_768.npz", None, 8, None), ("g9_ref_stream_768_trained.npz", "trained_like", 8, None),
            ("g10_ref_stream_768_trained_1thread.npz", "trained_like", 1, None),
            ("g10_ref_stream_768_trained_1thread.npz", "trained_like", 1, "intel")]
