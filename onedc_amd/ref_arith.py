@@ -75,6 +75,20 @@ class Calibration:
         self.threads = int(threads or torch.get_num_threads())
         self.profile = profile
 
+    def save_profile(self, path):
+        """What this calibration has settled so far, in the JSON form of tools/cpu_chain_probe.py / `load_profile`: a decoder
+        started with it asks no torch at all for these shapes."""
+        import json
+        out = {"host": "calibrated on the decoder", "threads": self.threads, "1x1": {}, "3x3": {}}
+        for key, v in self.table.items():
+            if key[0] == "3x3":
+                out["3x3"][",".join(str(t) for t in key[1:])] = list(v)
+            else:
+                out["1x1"][",".join(str(t) for t in key)] = list(v)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        return path
+
     def _rand(self, C, OC, H, W, k, groups=1):
         g = torch.Generator().manual_seed(C * 131 + OC * 7 + H)
         x = torch.randn(1, C, H, W, generator=g)

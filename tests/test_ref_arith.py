@@ -73,6 +73,10 @@ def test_cpu_probe_fits_torch_and_profiles_round_trip(tmp_path):
     prof = load_profile(str(path))
     assert prof == {(256, 128, 4, 4): (256, 0), ("3x3", 128, 128, 8, 8): ("im2col", 4, 288, 2),
                     ("3x3", 128, 128, 16, 16): ("direct", 16, 0)}
+    cal = Calibration("cpu", threads=8, profile=prof)             # a calibration that only knows the profile: saved == loaded
+    assert cal.conv1x1(256, 128, 4, 4) == (256, 0) and cal.conv3x3(128, 128, 8, 8) == ("im2col", 4, 288, 2)
+    assert load_profile(cal.save_profile(str(tmp_path / "again.json"))) == {(256, 128, 4, 4): (256, 0),
+                                                                            ("3x3", 128, 128, 8, 8): ("im2col", 4, 288, 2)}
 
 
 @pytest.fixture(scope="module")
