@@ -220,8 +220,12 @@ def index_thresholds(scale_min=0.11, scale_max=64.0, levels=256):
     log_step = (math.log(scale_max) - log_min) / (levels - 1)
 
     def index(s):
+        # torch's vectorised loops finish a tensor's tail (n mod 2 x vector width) with the SCALAR libm function; the reference's
+        # tensors are (B, 32, H, W), whole vectors always: pad to a multiple of 64 so that every element here takes the same path
+        n = s.numel()
+        s = torch.cat([s, s.new_ones((-n) % 64)])
         s = torch.maximum(s, torch.zeros_like(s) + 1e-5)
-        return ((torch.log(s) - log_min) / log_step).clamp_(0, levels - 1).int()
+        return ((torch.log(s) - log_min) / log_step).clamp_(0, levels - 1).int()[:n]
 
     want = torch.arange(1, levels, dtype=torch.int32)
     lo = torch.full((levels - 1,), np.float32(1e-6).view(np.int32).item(), dtype=torch.int32)       # index 0 for sure
