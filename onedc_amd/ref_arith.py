@@ -342,6 +342,8 @@ def load_profile(path):
     for key, v in raw.get("3x3", {}).items():
         if v is not None:
             out[("3x3",) + tuple(int(t) for t in key.split(","))] = tuple(v)
+    if raw.get("index_thresholds_bits"):                     # the writer's logarithm (255 f32 bit patterns)
+        out["index_thresholds"] = torch.tensor(raw["index_thresholds_bits"], dtype=torch.int32).view(torch.float32)
     return out
 
 
@@ -367,7 +369,8 @@ class ReferencePrior:
         self.reduction = _Conv1x1(sd, "y_spatial_prior_reduction", device, cal)
         self.adaptors = [_DCB4(sd, f"y_spatial_prior_adaptor_{i}", device, cal) for i in (1, 2, 3)]
         self.spatial = [_DCB4(sd, f"y_spatial_prior.{i}", device, cal) for i in range(3)]
-        self.thresholds = index_thresholds().to(device)
+        thr = profile.get("index_thresholds") if isinstance(profile, dict) else None
+        self.thresholds = (index_thresholds() if thr is None else thr).contiguous().to(device)
 
     def params_from_indices(self, indices):
         """indices int32 (B, h, w) -> (fused params f32 View (B, 4h, 4w, 2N), z_semantic 16-bit View)."""

@@ -181,6 +181,30 @@ def fit_dw(lib, C, H, W):
     return ["taps_from_bias"] if np.array_equal(y, ref) else None
 
 
+def index_thresholds(scale_min=0.11, scale_max=64.0, levels=256):
+    """thresholds[i] = the smallest f32 sigma whose table index under the reference's build_indexes (entropy_models.py:355-362) is
+    >= i + 1, with THIS machine's torch.log (bisection over bit patterns; whole vectors only, as in onedc_amd/ref_arith.py)."""
+    log_min = math.log(scale_min)
+    log_step = (math.log(scale_max) - log_min) / (levels - 1)
+
+    def index(s):
+        n = s.numel()
+        s = torch.cat([s, s.new_ones((-n) % 64)])
+        s = torch.maximum(s, torch.zeros_like(s) + 1e-5)
+        return ((torch.log(s) - log_min) / log_step).clamp_(0, levels - 1).int()[:n]
+
+    want = torch.arange(1, levels, dtype=torch.int32)
+    lo = torch.full((levels - 1,), int(np.float32(1e-6).view(np.int32)), dtype=torch.int32)
+    hi = torch.full((levels - 1,), int(np.float32(128.0).view(np.int32)), dtype=torch.int32)
+    with torch.no_grad():
+        while int((hi - lo).max()) > 1:
+            mid = lo + (hi - lo) // 2
+            ok = index(mid.view(torch.float32)) >= want
+            hi = torch.where(ok, mid, hi)
+            lo = torch.where(ok, lo, mid)
+    return [int(v) for v in hi]
+
+
 def prior_shapes(h, w):
     """Every convolution shape (C, OC, k, H, W) of the prior networks (codec_module.py:145-166, 205-209; compression_model.py:
     369-407) for a z map of h x w -- dense convolutions only (the depthwise ones always run in oneDNN's jit_dw)."""
@@ -222,6 +246,7 @@ def main(argv=None):
                 if key not in prof["dw3x3"]:
                     prof["dw3x3"][key] = fit_dw(lib, Cd, h << lv, w << lv)
                     print(f"[probe] {a.threads} thread(s) depthwise 3x3 {Cd:4d} on {h << lv:3d}x{w << lv:<3d}: {prof['dw3x3'][key]}", flush=True)
+    prof["index_thresholds_bits"] = index_thresholds()       # the writer's logarithm, as 255 f32 bit patterns
     if a.out:
         json.dump(prof, open(a.out, "w"), indent=1)
         print(f"[probe] profile of {cpu} at {a.threads} thread(s) -> {a.out}")
