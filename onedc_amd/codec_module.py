@@ -210,6 +210,14 @@ class IntraNoAR:
         self.entropy_coder = EntropyCoder(False, 1)
         self.gaussian_encoder.update(force=force, entropy_coder=self.entropy_coder)
         self._tables = self.gaussian_encoder.get_cdf_info()
+        want = self.ref_profile.get("gaussian_tables_sha16") if isinstance(self.ref_profile, dict) else None
+        if want:                               # a writer's profile names the CDF tables its torch built: they must be ours
+            import hashlib
+            import numpy as np
+            got = hashlib.sha256(np.asarray(self._tables[0]).astype(np.int32).tobytes()).hexdigest()[:16]
+            if got != want:
+                raise RuntimeError(f"the writer's Gaussian CDF tables (sha256[:16] {want}) are not the ones this host's torch builds "
+                                   f"({got}): torch versions differ in Normal.cdf; its streams cannot be decoded with these tables")
 
     # ------------------------------------------------------------------ prior nets
     @K.in_own_format

@@ -342,6 +342,8 @@ def load_profile(path):
     for key, v in raw.get("3x3", {}).items():
         if v is not None:
             out[("3x3",) + tuple(int(t) for t in key.split(","))] = tuple(v)
+    if raw.get("gaussian_tables_sha16"):                     # the CDF tables the writer's torch builds (codec_module.update checks)
+        out["gaussian_tables_sha16"] = str(raw["gaussian_tables_sha16"])
     if raw.get("index_thresholds_bits"):                     # the writer's logarithm (255 f32 bit patterns)
         out["index_thresholds"] = torch.tensor(raw["index_thresholds_bits"], dtype=torch.int32).view(torch.float32)
     return out

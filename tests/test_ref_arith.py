@@ -255,7 +255,10 @@ def test_stream_of_an_avx2_writer_decodes_with_the_writers_profile(eight_threads
     from onedc_amd.ref_arith import load_profile
     g = golden("g13_ref_stream_768_trained_avx2.npz")
     prof = load_profile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "profile_intel_avx2_8threads_768.json"))
-    assert prof[("3x3", 128, 128, 48, 48)] == ("direct", 8, 1)
+    assert prof[("3x3", 128, 128, 48, 48)] == ("direct", 8, 1) and prof["gaussian_tables_sha16"] == "681191522681e23f"
+    wrong = dict(prof, gaussian_tables_sha16="0" * 16)          # a writer whose torch built other CDF tables: refused by name
+    with pytest.raises(RuntimeError, match="Gaussian CDF tables"):
+        IntraNoAR(synth.codec_state_dict(0, preset="trained_like"), "cuda:0", prior_arith="torch_cpu", ref_profile=wrong).update(force=True)
     idx = torch.from_numpy(g["indices"]).to("cuda:0")
     codec = IntraNoAR(synth.codec_state_dict(0, preset="trained_like"), "cuda:0", prior_arith="torch_cpu", ref_threads=8,
                       ref_profile=prof)

@@ -247,6 +247,15 @@ def main(argv=None):
                     prof["dw3x3"][key] = fit_dw(lib, Cd, h << lv, w << lv)
                     print(f"[probe] {a.threads} thread(s) depthwise 3x3 {Cd:4d} on {h << lv:3d}x{w << lv:<3d}: {prof['dw3x3'][key]}", flush=True)
     prof["index_thresholds_bits"] = index_thresholds()       # the writer's logarithm, as 255 f32 bit patterns
+    try:                                                     # the Gaussian CDF tables this machine's torch builds (Normal.cdf in fp32)
+        import hashlib
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from onedc_amd.entropy.entropy_models import GaussianEncoder
+        cdf = GaussianEncoder().build_tables()[0]
+        prof["gaussian_tables_sha16"] = hashlib.sha256(np.asarray(cdf).astype(np.int32).tobytes()).hexdigest()[:16]
+        print(f"[probe] Gaussian CDF tables: sha256[:16] {prof['gaussian_tables_sha16']}")
+    except Exception as e:                                   # the coder library is not built here: the decoder cannot check
+        print(f"[probe] Gaussian CDF tables not digested ({type(e).__name__}: {e})")
     if a.out:
         json.dump(prof, open(a.out, "w"), indent=1)
         print(f"[probe] profile of {cpu} at {a.threads} thread(s) -> {a.out}")
