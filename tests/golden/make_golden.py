@@ -457,6 +457,37 @@ def main():
          symbols_sha256=np.frombuffer(hashlib.sha256(torch.stack(list(yq12)).to(torch.int16).numpy().tobytes()).digest(),
                                       dtype=np.uint8))
 
+    # ---------------------------------------------------------------- G14 BASELINE config 1's class: 256x256, ONE thread
+    # What `python src/inference.py` itself writes for a 256x256 picture (inference.py:29: one thread): small maps AND one thread,
+    # i.e. torch's native path for every 1x1 and for the hyper decoder's dense 3x3 at 8x8.  Trained-like weights; stream + digests.
+    print("G14 reference-made stream, trained-like weights, 256x256, torch.set_num_threads(1) (stream + digests)")
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        rng14 = np.random.default_rng(14)
+        indices14 = torch.from_numpy(rng14.integers(0, 16384, (1, 4, 4)))
+        z_hat14 = torch.stack([((indices14 // 4 ** d) % 4 - 2).float() / 2 for d in range(7)], dim=1)
+        params14, _ = hyper_dec_t(z_hat14)
+        fused14 = fusion_t(params14)
+        means14 = fused14.chunk(2, 1)[1]
+        y14 = means14 + 1.5 * torch.randn(means14.shape, generator=torch.Generator().manual_seed(1414))
+        out14 = cm.compress_four_part_prior(y14, fused14, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t,
+                                            y_spatial_prior_reduction=reduction_t)
+        yq14, s14, y_hat14 = out14[0:4], out14[4:8], out14[8]
+        ec.reset()
+        for yq, sc in zip(yq14, s14):
+            cm.gaussian_encoder.encode(yq, sc)
+        ec.flush()
+        stream14 = ec.get_encoded_stream()
+        ec.set_stream(stream14)
+        back14 = cm.decompress_four_part_prior(fused14, adaptors_t[0], adaptors_t[1], adaptors_t[2], spatial_t, reduction_t)
+        assert torch.equal(back14, y_hat14)
+    torch.set_num_threads(8)
+    save("g14_ref_stream_256_trained_1thread.npz", indices=indices14.int(), stream=np.frombuffer(stream14, np.uint8),
+         y_hat=sample_points(y_hat14, 4096),
+         y_hat_sha256=np.frombuffer(hashlib.sha256(y_hat14.numpy().tobytes()).digest(), dtype=np.uint8),
+         symbols_sha256=np.frombuffer(hashlib.sha256(torch.stack(list(yq14)).to(torch.int16).numpy().tobytes()).digest(),
+                                      dtype=np.uint8))
+
     # ---------------------------------------------------------------- G13 a writer without AVX-512
     # The same capture with oneDNN capped to AVX2 (DNNL_MAX_CPU_ISA=AVX2 in the environment of THIS process: what a reference on an
     # AVX2-only host -- e.g. an EPYC before Zen 4 -- runs): other 1x1 blockings, and a dense 3x3 that is one chain from the bias.

@@ -244,6 +244,27 @@ def test_reference_made_1024_stream_decodes_to_the_references_digest(eight_threa
 
 
 @pytest.mark.gpu
+def test_stream_of_the_reference_harness_class_256_one_thread(eight_threads):
+    """BASELINE config 1's class: a 256x256 picture written at ONE thread (what src/inference.py itself does, :29) -- small maps and
+    torch's native path everywhere (tests/golden/g14).  Native structures from ref_arith.intel_profile(1); whole y_hat and symbol
+    planes to the reference's sha256."""
+    import hashlib
+    from onedc_amd.codec_module import IntraNoAR
+    from onedc_amd.ref_arith import intel_profile
+    g = golden("g14_ref_stream_256_trained_1thread.npz")
+    codec = IntraNoAR(synth.codec_state_dict(0, preset="trained_like"), "cuda:0", prior_arith="torch_cpu", ref_threads=1,
+                      ref_profile=intel_profile(1))
+    codec.update(force=True)
+    trace = []
+    y_hat, _ = codec.decompress([g["stream"].tobytes()], torch.from_numpy(g["indices"]).to("cuda:0"), trace=trace)
+    got = y_hat.torch_nchw().cpu().contiguous()
+    assert hashlib.sha256(got.numpy().tobytes()).digest() == g["y_hat_sha256"].tobytes()
+    sym = np.stack([np.asarray(sy).reshape(1, 32, 16, 16) for _, sy in trace]).astype(np.int16)
+    assert hashlib.sha256(sym.tobytes()).digest() == g["symbols_sha256"].tobytes()
+    print(f"[ref-arith] g14: structures {dict(sorted(codec.ref_prior.cal.table.items(), key=str))}")
+
+
+@pytest.mark.gpu
 def test_stream_of_an_avx2_writer_decodes_with_the_writers_profile(eight_threads):
     """A writer WITHOUT AVX-512 (tests/golden/g13: the reference with oneDNN capped to AVX2, 8 threads): its 1x1 blockings and its
     one-chain dense 3x3 come from the profile tools/cpu_chain_probe.py wrote on the writer's machine
