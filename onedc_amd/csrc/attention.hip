@@ -807,14 +807,15 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
 #pragma unroll
         for (int t = 0; t < QT; ++t) move_ref(t, tmax[t], false);
     };
-    auto tile_math = [&](const char *stage, int k0, auto mask_tag) {
+    auto tile_math = [&](const char *stage, int k0, auto mask_tag, auto track_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr bool TRACK = decltype(track_tag)::value;
         const char *ldsK = stage, *ldsV = stage + 2 * FA64_K;
         f32x4 s[4][QT];                             // S^T tiles s[kt][t], kt = 2 st + hh
         s_chain(ldsK, s);
         if (MASK) mask_tail(s, k0);
         float tmax[QT];
-        lane_max(s, tmax);
+        if constexpr (TRACK) lane_max(s, tmax);
         a16x8 pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -845,46 +846,83 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
                 for (int t = 0; t < QT; ++t)
                     o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][st], o[d][t], 0, 0, 0);
             }
-        const float wmax = fmaxf(tmax[0], tmax[1]);
-        if (__any(wmax > FA64_THR)) {               // wave-uniform, rare
+        if constexpr (TRACK) {
+            const float wmax = fmaxf(tmax[0], tmax[1]);
+            if (__any(wmax > FA64_THR)) {           // wave-uniform, rare
 #pragma unroll
-            for (int t = 0; t < QT; ++t) (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
+                for (int t = 0; t < QT; ++t) (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
+            }
         }
     };
 
     const int ntiles = (Nk + 63) >> 6;
     const bool ragged = (Nk & 63) != 0;
-    issue(0, smem);
-    if (ntiles > 1) issue(1, smem + FA80_STAGE);
-    int slot = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        // tile t has landed for this wave once at most the DMAs of tile t + 1 are outstanding
-        if (t + 1 < ntiles) {
-            if (nvb == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto pass = [&](auto track_tag) {
+        issue(0, smem);
+        if (ntiles > 1) issue(1, smem + FA80_STAGE);
+        int slot = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            // tile t has landed for this wave once at most the DMAs of tile t + 1 are outstanding
+            if (t + 1 < ntiles) {
+                if (nvb == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();           // every wave's part of tile t is in LDS; tile t - 1 is fully read
+            if (t + 2 < ntiles) issue(t + 2, smem + (slot >= 1 ? slot - 1 : 2) * FA80_STAGE);
+            const char *cur = smem + slot * FA80_STAGE;
+            if (t == 0) first_reference(cur, ragged && ntiles == 1);
+            if (ragged && t == ntiles - 1) tile_math(cur, t * 64, std::true_type{}, track_tag);
+            else tile_math(cur, t * 64, std::false_type{}, track_tag);
+            slot = slot == 2 ? 0 : slot + 1;
         }
-        __builtin_amdgcn_s_barrier();               // every wave's part of tile t is in LDS; tile t - 1 is fully read
-        if (t + 2 < ntiles) issue(t + 2, smem + (slot >= 1 ? slot - 1 : 2) * FA80_STAGE);
-        const char *cur = smem + slot * FA80_STAGE;
-        if (t == 0) first_reference(cur, ragged && ntiles == 1);
-        if (ragged && t == ntiles - 1) tile_math(cur, t * 64, std::true_type{});
-        else tile_math(cur, t * 64, std::false_type{});
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-
-    // ---- normalise and store: lane (g, r) owns channels 16 d + 4 g + (0..3) of query q0 + 16 t + r
+    };
     const int dt = d_real >> 4, dq = (d_real >> 2) & 3, de = d_real & 3;
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
+    auto denominator = [&](int t) -> float {         // the riding row sum (half 0): channel d_real of the query's output
         float cand = 0.f;
 #pragma unroll
-        for (int d = 0; d < 3; ++d)                  // the denominator rides in half 0
+        for (int d = 0; d < 3; ++d)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (d == dt && e == de) cand = o[d][t][e];
-        const float l = __shfl(cand, dq * 16 + r);
+        return __shfl(cand, dq * 16 + r);
+    };
+    // fast pass / fallback exactly as in flash_attn64_kernel: no tile maxima while every row sum stays inside (2^-100, 2^100)
+#ifdef EXP_FA64_ALWAYS_TRACK
+    pass(std::true_type{});
+    if (false)
+#else
+    pass(std::false_type{});
+#endif
+    {
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const uint32_t lb = __builtin_bit_cast(uint32_t, denominator(t));
+            bad |= !(lb > 0x0d800000u && lb < 0x71800000u);
+        }
+        if (__syncthreads_or(bad)) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                m_run[t] = 0.f;
+                if (g == 1) {
+                    union { a16x8 v; uint32_t u[4]; } f;
+                    f.v = qf[t][1];
+                    f.u[0] &= 0xffff0000u;
+                    qf[t][1] = f.v;
+                }
+#pragma unroll
+                for (int d = 0; d < 6; ++d) o[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            pass(std::true_type{});
+        }
+    }
+
+    // ---- normalise and store: lane (g, r) owns channels 16 d + 4 g + (0..3) of query q0 + 16 t + r
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float l = denominator(t);
         const float inv = 1.f / l;
         const int qi = q0 + t * 16 + r;
         if (qi >= Nq) continue;

@@ -674,13 +674,14 @@ def test_flash_attention_reference_point_moves(d):
     close(got, ref, rms=1e-2, mx=4e-2, what="flash attention, moving reference")
 
 
-def test_flash_attention_fast_pass_falls_back_to_the_moving_reference():
-    """The d = 40 kernel first runs WITHOUT looking for tile maxima (reference point fixed by tile 0) and repeats the workgroup
+@pytest.mark.parametrize("d", [40, 80])
+def test_flash_attention_fast_pass_falls_back_to_the_moving_reference(d):
+    """The d = 40 / 80 kernels first run WITHOUT looking for tile maxima (reference point fixed by tile 0) and repeats the workgroup
     with the moving reference only when a row sum leaves (2^-100, 2^100).  Head 2 here has logits that climb by ~2^30 per tile of
     64 keys to ~2^320 above tile 0 -- exp2 overflows in the fast pass, the moving reference follows it (a jump of more than 2^127
     inside ONE tile is beyond either pass: P is bf16, f32's exponent range); the other heads never leave the fast pass.
     Full-tensor check against fp64."""
-    d, B, Hh, Nq, Nk = 40, 1, 8, 512, 704
+    B, Hh, Nq, Nk = 1, 8, 512, 704
     DQ, DV = pack.HEAD_PAD[d]
     pq, pv = pack.head_positions(d, DQ), pack.head_positions(d, DV)
     g = torch.Generator().manual_seed(78)
@@ -688,7 +689,7 @@ def test_flash_attention_fast_pass_falls_back_to_the_moving_reference():
     k = torch.randn(B, Hh, Nk, d, generator=g) * 0.5
     v = torch.randn(B, Hh, Nk, d, generator=g)
     q[:, 2] = 1.0 + 0.05 * q[:, 2]                                          # head 2: every query close to the all-ones direction
-    k[:, 2] = torch.linspace(0.0, 35.0, Nk).view(1, Nk, 1) * torch.ones(d) + 0.05 * k[:, 2]     # keys climb along it
+    k[:, 2] = torch.linspace(0.0, 35.0 * (40 / d) ** 0.5, Nk).view(1, Nk, 1) * torch.ones(d) + 0.05 * k[:, 2]   # keys climb along it
     q, k, v = (t.to(torch.float16).float() for t in (q, k, v))
     assert float((q[:, 2] @ k[:, 2].transpose(-1, -2)).max()) * d ** -0.5 * 1.4427 > 250
 
