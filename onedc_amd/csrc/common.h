@@ -73,6 +73,8 @@ __device__ __forceinline__ float silu_f(float v) {
 __device__ __forceinline__ float gelu_f(float v) {
 #ifdef ONEDC_GELU_LIBM
     return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+#elif defined(EXP_GELU_FREE)                     // (ablation) what the GEGLU layers cost without the function
+    return 0.5f * v;
 #else
     const float x = fabsf(v) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.f));
