@@ -66,7 +66,11 @@ __device__ __forceinline__ a16_t f2a(float f) { return (a16_t)(pack_a2(f, 0.f) &
 __device__ __forceinline__ float leaky(float v, float slope) { return v >= 0.f ? v : v * slope; }
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; the result is stored as bf16 or feeds one)
 __device__ __forceinline__ float silu_f(float v) {
+#ifdef EXP_SILU_FREE                             // (ablation) what GroupNorm-on-load costs without the two transcendentals
+    return v * 0.5f;
+#else
     return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+#endif
 }
 // exact-erf GELU (the reference's F.gelu).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
 // rounding of the result): one v_rcp_f32, one v_exp_f32 and a degree-5 Horner chain instead of libm's ~40-instruction erff.
