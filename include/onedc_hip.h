@@ -13,7 +13,8 @@
  *     channels is realised without copies
  *   - bf16 storage unless a field says f32; all accumulation is f32
  *   - no allocation and no synchronisation inside any entry point (graph-capturable)
- *   - results are deterministic and batch-invariant: no atomics, no split-K, fixed reduction order
+ *   - results are deterministic and batch-invariant: no atomics, fixed reduction order (the one split-K form is chosen
+ *     by layer shape, never by batch size, and adds its parts in a fixed order)
  *   - return value: 0 ok, <0 argument error, >0 hipError_t of the launch
  */
 #ifndef ONEDC_HIP_H
@@ -85,7 +86,31 @@ typedef struct onedc_conv_params {
     int32_t out_bf16;                   /* 1: a 16-bit output is stored as bf16 whatever the library's activation format (the
                                            IEEE-half build hands V^T to onedc_flash_attn's d = 40 kernel this way: its P / V^T
                                            product stays bf16 for the exponent range); ignored with out_f32 */
+    /* ---- version 0.4 (fields appended: a caller that zero-fills the struct keeps the 0.3 behaviour) ---- */
+    void *ws;                           /* NULL, or device scratch of ws_bytes for the split-K form below (the caller owns
+                                           it; one per stream) */
+    int64_t ws_bytes;
+    int32_t split_k;                    /* 0: the dispatcher decides BY LAYER SHAPE ONLY (never by B: a picture decodes to
+                                           the same bits alone and inside a batch); 1: never split; n > 1: n parts where the
+                                           layer qualifies.  Split form: the K-tiles of a 3x3 layer on a map of <= 256
+                                           pixels (the UNet's 12x12 level: 2 304 pixels per batch of 16 against 11 520 or
+                                           23 040 k) are cut into n contiguous ranges, one workgroup per (tile, range)
+                                           leaves f32 partial sums in ws, onedc_splitk_reduce adds them in range order
+                                           (fixed order, no atomics) and applies the epilogue.  Ask onedc_conv_splitk_ws_bytes
+                                           for the scratch size (0: this layer is not split) */
+    const void *x2;                     /* NULL, or the input of a 1x1 convolution that is accumulated into the same output
+                                           tile behind the 3x3 taps: y = alpha * (conv3x3(x) + conv1x1(x2)) + bias + res --
+                                           diffusers ResnetBlock2D.conv_shortcut riding on conv2 (called from
+                                           model_sd15_with_codec_stage1.py:184-188).  Same pixel grid as y, 16-bit NHWC; only the
+                                           4-wave window kernel takes it: ask onedc_conv_win_takes_x2 first */
+    const void *w2;                     /* packed [rows padded to 128][Cin2] weights of that 1x1 layer, divided by alpha by
+                                           the host where alpha != 1 (a power of two there) */
+    int32_t Cin2, x2_cs, x2_co;         /* Cin2: multiple of 32 */
 } onedc_conv_params;
+/* bytes of scratch (onedc_conv_params.ws) the split-K form of this layer needs; 0: the dispatcher does not split it */
+int64_t onedc_conv_splitk_ws_bytes(const onedc_conv_params *p);
+/* 1 if onedc_conv_gemm would run p (x2 / w2 / Cin2 / x2_cs / x2_co filled in) on the window kernel with the second source */
+int onedc_conv_win_takes_x2(const onedc_conv_params *p);
 int onedc_conv_gemm(const onedc_conv_params *p, void *stream);
 /* 1 if onedc_conv_gemm would run p on the 3x3 window kernel AND that kernel can apply a GroupNorm in front of the conv
  * while it stages the operand (gn_ab; p->gn_ab itself may still be NULL when asking): same conditions as the launch */
@@ -103,7 +128,8 @@ enum {
     ONEDC_KERNEL_F32_128X128 = 8,  /* conv_gemm_kernel<Tile<128,128>, f32> (exact-f32 path) */
     ONEDC_KERNEL_F32_64X128 = 9,   /* conv_gemm_kernel<Tile<64,128>, f32>: the same for grids of less than two rounds */
     ONEDC_KERNEL_WIN3X3_4W = 10,   /* conv_win4_kernel: the window kernel as 4-wave workgroups, two per CU */
-    ONEDC_KERNEL_UPS2X2_4W = 11    /* conv_win4_kernel<2>: the upsample phases on the same 4-wave machinery */
+    ONEDC_KERNEL_UPS2X2_4W = 11,   /* conv_win4_kernel<2>: the upsample phases on the same 4-wave machinery */
+    ONEDC_KERNEL_SPLITK_256 = 12   /* conv_gemm256_kernel over K ranges + splitk_reduce_kernel (onedc_conv_params.split_k) */
 };
 int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
 const char *onedc_conv_kernel_name(int kernel_id);

@@ -47,10 +47,12 @@ def coder_source_id():
     return _digest(coder_sources())
 
 
-def hip_source_id():
-    """Identity of the kernel sources, headers and per-file compiler flags (both activation formats are built from them)."""
+def hip_source_id(extra_flags=()):
+    """Identity of the kernel sources, headers, per-file compiler flags and extra (experiment) flags; both activation formats
+    are built from them.  The compiler's version is NOT part of it: the id must be reproducible on a box that only loads the
+    prebuilt libraries (no hipcc call at import); a compiler change rebuilds through force=True / a clean tree."""
     return _digest(hip_sources() + glob.glob(os.path.join(_native.CSRC, "*.h")) + [os.path.join(ROOT, "include", "onedc_hip.h")],
-                   repr(sorted(FILE_FLAGS.items())))
+                   repr(sorted(FILE_FLAGS.items())) + repr(tuple(extra_flags)))
 
 
 BUILD_ID_MARKER = b"@(#)onedc-build-id:"
@@ -107,7 +109,9 @@ def build_hip(force=False, extra_flags=()):
     if not srcs:
         raise RuntimeError("no HIP sources found")
     variants = ((_native.HIP_SO, ".o", ()), (_native.HIP_F16_SO, ".f16.o", ("-DONEDC_ACT_F16",)))
-    sid = hip_source_id()
+    # extra_flags (ablation builds: results wrong by design) are part of the id: such a library is refused by the loader
+    # (its id is not the sources' plain id) and the next plain build sees a wrong id and recompiles EVERY object
+    sid = hip_source_id(extra_flags)
     jobs, links = [], []
     for so, suffix, defs in variants:
         # a library is current when it is newer than its sources AND carries the id of exactly these sources (mtimes do
@@ -119,7 +123,9 @@ def build_hip(force=False, extra_flags=()):
         for s in srcs:
             o = s[:-4] + suffix
             carries_id = os.path.basename(s) == "elementwise.hip"
-            if force or _stale(o, [s] + headers) or (carries_id and wrong_id):
+            # a wrong id means the objects' provenance is unknown (a copied tree keeps no mtimes, an ablation build leaves
+            # mtime-fresh objects behind): all of them are compiled again, not only the one that carries the id
+            if force or wrong_id or _stale(o, [s] + headers):
                 jobs.append([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-result",
                              *FILE_FLAGS.get(os.path.basename(s), ()), *defs, *extra_flags,
                              *((f'-DONEDC_BUILD_ID="{sid}"',) if carries_id else ()), "-o", o, s])

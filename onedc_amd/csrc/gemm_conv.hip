@@ -256,6 +256,8 @@ int launch(const onedc_conv_params &p, hipStream_t st) {
 
 int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st);      // gemm_conv256.hip
 int onedc_conv_gemm128x256_launch(const onedc_conv_params &p, hipStream_t st);  // gemm_conv256.hip
+int onedc_conv_splitk_launch(const onedc_conv_params &p, hipStream_t st, int parts);   // gemm_conv256.hip
+int64_t onedc_conv_splitk_bytes(const onedc_conv_params &p, int parts);
 bool onedc_conv_win_ok(const onedc_conv_params &p);                             // gemm_conv_win.hip
 int onedc_conv_win_launch(const onedc_conv_params &p, hipStream_t st);
 bool onedc_conv_win_gn_ok(const onedc_conv_params &p);                          // gn_ab (if set) can be honoured
@@ -305,8 +307,34 @@ static bool conv_win_wanted(const onedc_conv_params &p) {
            rows128w * 5 <= p.Cout * 6;
 }
 
+// Split-K (gemm_conv256.hip): 3x3 layers on maps of at most 256 pixels with whole 256-channel tiles and >= 160 K-tiles -- the
+// UNet's 12x12 level.  Decided by the layer's SHAPE alone (not by B: determinism rule of the path), five K ranges
+// (1280 -> 1280: 36 K-tiles each, 2560 -> 1280: 72; 45 x 5 = 225 workgroups per batch of 16).  0: not split.
+static int conv_splitk_parts(const onedc_conv_params &p) {
+    if (p.split_k == 1 || p.in_f32 || p.batch > 1 || p.stats || p.gn_ab || p.x2 || p.pixel_shuffle || p.out_bf16 || p.up ||
+        p.tile != 0 || p.KH != 3 || p.KW != 3 || (p.Cout % 256) != 0 || p.OH * p.OW > 256 ||
+        !(p.epi == ONEDC_EPI_LINEAR || p.epi == ONEDC_EPI_LEAKY || p.epi == ONEDC_EPI_SILU) ||
+        ((p.y_cs | p.y_co) & 3) || (p.res && ((p.r_cs | p.r_co) & 3)))
+        return 0;
+    const int ktiles = p.KH * p.KW * (p.Cin >> 6);
+    const int parts = p.split_k > 1 ? p.split_k : 5;
+    if (ktiles < 160 && p.split_k <= 1) return 0;
+    if (ktiles < 4 * parts) return 0;
+    return parts;
+}
+
+extern "C" int64_t onedc_conv_splitk_ws_bytes(const onedc_conv_params *pp) {
+    if (!pp) return 0;
+    const int parts = conv_splitk_parts(*pp);
+    return parts ? onedc_conv_splitk_bytes(*pp, parts) : 0;
+}
+
 static int conv_choose(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
+    {
+        const int parts = conv_splitk_parts(p);
+        if (parts && p.ws && p.ws_bytes >= onedc_conv_splitk_bytes(p, parts)) return ONEDC_KERNEL_SPLITK_256;
+    }
     // up == 2: x2 upsample + 3x3 decomposed into four 2x2 phase convolutions; w is the phase-packed matrix
     if (p.up == 2) {
         if (!onedc_conv_ups_ok(p)) return -12;
@@ -334,9 +362,11 @@ static int conv_choose(const onedc_conv_params &p) {
     // 8-wave kernel.  tile 130 / 131 force one or the other.
     if (conv_win_wanted(p)) {
         if (p.tile != 130 && onedc_conv_win4_ok(p)) return ONEDC_KERNEL_WIN3X3_4W;
+        if (p.x2) return -16;                      // only the 4-wave window kernel accumulates a second source
         if (p.tile == 131) return -11;
         return onedc_conv_win_gn_ok(p) ? ONEDC_KERNEL_WIN3X3 : -13;
     }
+    if (p.x2) return -16;
     if (p.tile == 130 || p.tile == 131) return -11;
     if (p.gn_ab) return -13;                       // only the window kernel normalises on load
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
@@ -382,6 +412,7 @@ extern "C" const char *onedc_conv_kernel_name(int id) {
         case ONEDC_KERNEL_F32_64X128: return "f32_64x128";
         case ONEDC_KERNEL_WIN3X3_4W: return "win3x3_4w";
         case ONEDC_KERNEL_UPS2X2_4W: return "ups2x2_4w";
+        case ONEDC_KERNEL_SPLITK_256: return "splitk_256";
         default: return "?";
     }
 }
@@ -398,6 +429,7 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         case ONEDC_KERNEL_WIN3X3_4W: return onedc_conv_win4_launch(p, st);
         case ONEDC_KERNEL_UPS2X2: return onedc_conv_ups_launch(p, st);
         case ONEDC_KERNEL_UPS2X2_4W: return onedc_conv_ups4_launch(p, st);
+        case ONEDC_KERNEL_SPLITK_256: return onedc_conv_splitk_launch(p, st, conv_splitk_parts(p));
         case ONEDC_KERNEL_256X256: return onedc_conv_gemm256_launch(p, st);
         case ONEDC_KERNEL_128X256: return onedc_conv_gemm128x256_launch(p, st);
         case ONEDC_KERNEL_16X256: return launch<Tile<16, 256, 1, 4>>(p, st);
@@ -413,6 +445,15 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
 #endif
         default: return id < 0 ? id : -14;
     }
+}
+
+// Would onedc_conv_gemm run p with its second source (x2: the resnet's conv_shortcut accumulated behind the 3x3 taps)?  Asked
+// before any launch of the block; GroupNorm on load is an independent question (both variants take a second source).
+extern "C" int onedc_conv_win_takes_x2(const onedc_conv_params *pp) {
+    if (!pp || !pp->x2) return 0;
+    onedc_conv_params p = *pp;
+    if (conv_validate(p) < 0) return 0;
+    return conv_choose(p) == ONEDC_KERNEL_WIN3X3_4W ? 1 : 0;
 }
 
 // Would the window kernel take this layer INCLUDING a GroupNorm-on-load request (p.gn_ab may still be null: the caller

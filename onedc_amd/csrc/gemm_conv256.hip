@@ -46,8 +46,11 @@ constexpr int OFF_A0 = 0, OFF_A1 = HALF, OFF_B0 = 2 * HALF, OFF_B1 = 3 * HALF;
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
+// gridDim.y > 1: split-K.  Part blockIdx.y owns the contiguous K-tile range [part * T / parts, (part + 1) * T / parts)
+// and stores its raw f32 sums y_part elements behind the previous part's (the launcher points p.y at the scratch buffer and
+// strips bias / activation / residual: onedc_conv_splitk_launch below).
 __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_params p, int tiles_n, int tiles_m,
-                                                              int M, int Ktot) {
+                                                              int M, int Ktot, int64_t y_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,17 +96,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     const unsigned lane_off = (unsigned)(p.x_co * 2 + chunk * 16);
     const int pix_bytes = p.x_cs * 2;
     const int nc = p.Cin >> 6;                     // 64-channel K-tiles per tap
-    const int T = p.KH * p.KW * nc;                // K-tiles
+    const int T_all = p.KH * p.KW * nc;            // K-tiles of the layer
+    const int t_first = (int)((int64_t)blockIdx.y * T_all / gridDim.y);               // (wave-uniform: scalar registers)
+    const int T = (int)((int64_t)(blockIdx.y + 1) * T_all / gridDim.y) - t_first;    // K-tiles of this workgroup
 
     auto tap_sources = [&](int tap) {
         const int ky = tap / p.KW;
         px.tap_off(p, lane_off, pix_bytes, ky, tap - ky * p.KW, x_bytes);
     };
 
-    // stage half-tile A^h of K-tile t (weights are k-contiguous: K-tile t starts at byte t * 128 of a row)
+    // stage half-tile A^h of K-tile t of this workgroup (weights are k-contiguous: K-tile t starts at byte t * 128 of a row)
     auto stage_A = [&](int h, int t, char *stage) {
         char *dst = stage + (h ? OFF_A1 : OFF_A0) + wave * 1024;
-        const unsigned so = (unsigned)t * 128 + (h ? wrow64 : 0);
+        const unsigned so = (unsigned)(t_first + t) * 128 + (h ? wrow64 : 0);
         glds16_buf(w_rsrc, wvoff, so, dst);
         glds16_buf(w_rsrc, wvoff, so + 2 * wrow64, dst + 8192);
     };
@@ -156,12 +161,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
 
     // ---- prologue: K-tile 0 whole, K-tile 1 minus A^1 (which phase 0 of tile 0 stages) ---------------
     char *const st0 = smem, *const st1 = smem + STAGE;
-    int tap2 = 0, ci2 = 0;                         // (tap, channel step) of the K-tile the B stager is at
-    tap_sources(0);
+    int tap2 = t_first / nc, ci2 = t_first - tap2 * nc;   // (tap, channel step) of the K-tile the B stager is at
+    tap_sources(tap2);
     stage_A(0, 0, st0);
-    stage_B(0, 0, st0);
+    stage_B(0, ci2, st0);
     stage_A(1, 0, st0);
-    stage_B(1, 0, st0);
+    stage_B(1, ci2, st0);
     auto advance2 = [&]() {                        // move the B stager to the next K-tile
         if (++ci2 == nc) {
             ci2 = 0;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const onedc_conv_p
     // ---- epilogue --------------------------------------------------------------------------------------
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     const int cout_store = glu ? p.Cout / 2 : p.Cout;
-    char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
+    char *yb = (char *)p.y + ((int64_t)blockIdx.z * p.y_bs + (int64_t)blockIdx.y * y_part) * (p.out_f32 ? 4 : 2);
     const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
     const int nw = n0 + wr * 128;
     float ssum[2][4], ssq[2][4], stat_dummy = 0.f;  // quad statistics only (the dispatcher keeps pair buffers away)
@@ -593,7 +598,88 @@ int onedc_conv_gemm256_launch(const onedc_conv_params &p, hipStream_t st) {
     const int tiles_m = (M + 255) / 256;
     const int Ktot = p.KH * p.KW * p.Cin;
     dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
-    hipLaunchKernelGGL(conv_gemm256_kernel, grid, dim3(512), 2 * STAGE, st, p, tiles_n, tiles_m, M, Ktot);
+    hipLaunchKernelGGL(conv_gemm256_kernel, grid, dim3(512), 2 * STAGE, st, p, tiles_n, tiles_m, M, Ktot, (int64_t)0);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- split-K (onedc_conv_params.split_k) ---------------------------------------------------------------------------------
+// The UNet's 12x12 level (decoder_unet.py:204-293: two down resnets, the mid block, three up resnets) is 2 304 pixels per
+// batch of 16 against K = 11 520 / 23 040: 45 tiles of 256 x 256 for 256 CUs, each 180 - 360 K-tiles long (round 3: 64-row
+// tiles of the 4-wave kernel, 360 workgroups at 300 - 480 TFLOP/s, 3.85 ms per batch).  Here every tile is cut into `parts`
+// K ranges -- 225 workgroups of 36 / 72 K-tiles on the 8-phase kernel above -- and the ranges are added by
+// splitk_reduce_kernel in range order: one writer per scratch element, no atomics, the same bits on every launch, and the
+// number of parts depends on the layer's shape only (never on B), so a picture alone decodes like one inside a batch.
+namespace {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int parts, int64_t y_part,
+                                                            const onedc_conv_params p, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (pixel, channel quad)
+    if (i >= total4) return;
+    const int c4 = p.Cout >> 2;
+    const int64_t m = i / c4;
+    const int n = (int)(i - m * c4) * 4;
+    const float *src = ws + m * p.Cout + n;
+    float4 s = *(const float4 *)src;
+    for (int z = 1; z < parts; ++z) {                                // fixed order
+        const float4 t = *(const float4 *)(src + z * y_part);
+        s.x += t.x;
+        s.y += t.y;
+        s.z += t.z;
+        s.w += t.w;
+    }
+    float v[4] = {s.x, s.y, s.z, s.w};
+    const float4 b = p.bias ? *(const float4 *)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = __builtin_fmaf(v[k], p.alpha, bv[k]);
+        if (p.epi == ONEDC_EPI_LEAKY) v[k] = leaky(v[k], p.slope);
+        else if (p.epi == ONEDC_EPI_SILU) v[k] = silu_f(v[k]);
+    }
+    if (p.res) {
+        const uint2 r = *(const uint2 *)((const a16_t *)p.res + m * p.r_cs + p.r_co + n);
+        v[0] += a2f_lo(r.x);
+        v[1] += a2f_hi(r.x);
+        v[2] += a2f_lo(r.y);
+        v[3] += a2f_hi(r.y);
+    }
+    const int64_t yo = m * p.y_cs + p.y_co + n;
+    if (p.out_f32) *(float4 *)((float *)p.y + yo) = make_float4(v[0], v[1], v[2], v[3]);
+    else *(uint2 *)((a16_t *)p.y + yo) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
+}
+}  // namespace
+
+int64_t onedc_conv_splitk_bytes(const onedc_conv_params &p, int parts) {
+    return (int64_t)parts * p.B * p.OH * p.OW * p.Cout * 4;
+}
+
+int onedc_conv_splitk_launch(const onedc_conv_params &p0, hipStream_t st, int parts) {
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_gemm256_kernel, 2 * STAGE}});
+    const int64_t M64 = (int64_t)p0.B * p0.OH * p0.OW;
+    if (M64 > 0x7fffffff) return -1;
+    if (!p0.ws || p0.ws_bytes < onedc_conv_splitk_bytes(p0, parts)) return -15;
+    const int M = (int)M64;
+    onedc_conv_params p = p0;                      // pass 1: raw sums of every K range, f32, [part][pixel][Cout]
+    p.y = p0.ws;
+    p.out_f32 = 1;
+    p.y_cs = p0.Cout;
+    p.y_co = 0;
+    p.bias = nullptr;
+    p.res = nullptr;
+    p.stats = nullptr;
+    p.alpha = 1.f;
+    p.epi = ONEDC_EPI_LINEAR;
+    const int tiles_n = (p.Cout + 255) / 256;
+    const int tiles_m = (M + 255) / 256;
+    const int Ktot = p.KH * p.KW * p.Cin;
+    const int64_t y_part = M64 * p.Cout;
+    hipLaunchKernelGGL(conv_gemm256_kernel, dim3(tiles_n * tiles_m, parts, 1), dim3(512), 2 * STAGE, st, p, tiles_n, tiles_m, M,
+                       Ktot, y_part);
+    ONEDC_LAUNCH_CHECK();
+    const int64_t total4 = M64 * (p0.Cout >> 2);   // pass 2: add the parts in order, epilogue of the layer
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, (const float *)p0.ws, parts,
+                       y_part, p0, total4);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

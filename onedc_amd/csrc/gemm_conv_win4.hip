@@ -59,7 +59,12 @@ __device__ __forceinline__ void w4_static_for(F &&f) {
 // decomposition (gemm_conv_ups.hip: a 2x2 convolution of the low-resolution input with summed weights): tap (ty, tx) of
 // phase (PY, PX) reads exactly what tap (PY + ty, PX + tx) of the 3x3 kernel reads, so the phase is two per-lane base
 // addresses chosen at the start, four K-tiles per chunk instead of nine, and an output scatter to (2 y + PY, 2 x + PX).
-template <int MODE, int ST>
+// X2: a second source (onedc_conv_params.x2 / w2 / Cin2): the 1x1 convolution of a tensor on the output grid -- the resnet's
+// conv_shortcut, whose input is the block's input -- accumulated into the same tile behind the 3x3 K loop, 32 channels per
+// K-tile.  The separate shortcut launch, its output tensor and the residual read of it disappear (the VAE's 256 -> 128 block
+// at 768x768: 1.7 ms + 2.4 GB written + 2.4 GB re-read per batch of 16).  A template parameter so that the kernels without a
+// second source are compiled exactly as before.
+template <int MODE, int ST, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_params p, int tiles_n, int tiles_x, int tiles_y,
                                                            int Ktot, OnedcFastDiv dv_n, OnedcFastDiv dv_pi,
                                                            OnedcFastDiv dv_x, OnedcFastDiv dv_c) {
@@ -446,6 +451,85 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     for (; c2 + 2 < nc32; c2 += 2) chunk_pair(c2, std::false_type());
     chunk_pair(c2, std::true_type());
 
+    if constexpr (X2) {
+        // ---- second source: K-tiles of the 1x1 layer, one 32-channel chunk each ---------------------------------------
+        // The 3x3 loop has drained its DMA (vmcnt 0 at its last tap) and every wave has waited for its last fragments; a
+        // chunk of x2 is staged in the WINDOW layout (the same 21 blocks, offsets for x2's channel stride), so that its
+        // fragments are the reads of the centre tap (ky = kx = 1), its weights go to ring slots 0 / 1.  Two chunks in
+        // flight; per chunk: counted wait, barrier (landed everywhere), 12 fragment reads, barrier (buffers free), DMA of
+        // chunk c + 2, 32 MFMAs.  The partner workgroup on the CU covers the waits.
+        __builtin_amdgcn_s_barrier();                // every wave is past its last fragment read of the 3x3 part
+        const int64_t img2_bytes = (int64_t)p.OH * p.OW * p.x2_cs * 2;
+        const unsigned x2_bytes = img2_bytes < 0xfffff000ll ? (unsigned)img2_bytes : 0xfffff000u;
+        const __amdgpu_buffer_rsrc_t x2_rsrc = make_rsrc((const char *)p.x2 + img * img2_bytes, x2_bytes);
+        // (the lane index goes through an opaque asm: otherwise the compiler shares the window arithmetic below with the
+        // prologue's and keeps two dozen registers alive -- and spilled -- across the 3x3 loop)
+        int lane_t = lane;
+        W4_PIN(lane_t);
+        unsigned woff2[MAXWB];
+#pragma unroll
+        for (int k = 0; k < MAXWB; ++k) {
+            const int w = (wave + 4 * k) * 16 + (lane_t >> 2);
+            const int wy = (w * 3641) >> 16, wx = w - wy * 18;
+            const int iy = y0 - 1 + wy, ix = x0 - 1 + wx;
+            const bool ok = w < 324 && (unsigned)iy < (unsigned)p.OH && (unsigned)ix < (unsigned)p.OW;
+            const int sfq = (lane_t & 3) ^ (((wx >> 2) & 1) << 1);
+            woff2[k] = ok ? (unsigned)((iy * p.OW + ix) * p.x2_cs + p.x2_co) * 2u + sfq * 16 : x2_bytes;
+        }
+        const __amdgpu_buffer_rsrc_t w2_rsrc = make_rsrc(p.w2, (unsigned)((int64_t)w_rows * p.Cin2 * 2));
+        const unsigned wvoff2 = (unsigned)((n0 + wave * 16 + (lane_t & 15)) * p.Cin2 * 2) + (lane_t >> 4) * 16;
+        const unsigned w2row64 = (unsigned)(64 * p.Cin2 * 2);
+        auto stage2 = [&](int c32, int par) {        // chunk c32 into window buffer / ring slot `par`
+            char *dst = lds_a + par * W4_A + wave * 1024;
+            glds16_buf(w2_rsrc, wvoff2, (unsigned)c32 * 64, dst);
+            glds16_buf(w2_rsrc, wvoff2, (unsigned)c32 * 64 + w2row64, dst + 4096);
+#pragma unroll
+            for (int k = 0; k < MAXWB; ++k)
+                if (k < nwb) glds16_buf(x2_rsrc, woff2[k], (unsigned)c32 * 64, smem + W4_WOFF + par * W4_W + (wave + 4 * k) * 1024);
+        };
+        const int n2 = p.Cin2 >> 5;
+        stage2(0, 0);
+        if (n2 > 1) stage2(1, 1);
+        for (int c = 0; c < n2; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < n2) {                        // chunk c + 1 (2 weight + nwb window instructions) may fly on
+                if (wave == 0) W4_WAIT_VMCNT(8);
+                else W4_WAIT_VMCNT(7);
+            } else {
+                W4_WAIT_VMCNT(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int par = c & 1;
+            const int a_rd = fao + par * W4_A, b_rd = wrd[1] + par * W4_W;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) W4_RD(fa[0][i], a_rd, i * 1024);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W4_RD(fbA[r], b_rd, ((r + 1) * 18 + 1) * 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W4_RD(fbB[r], b_rd, ((4 + r + 1) * 18 + 1) * 64);
+            W4_WAIT_LGKM4(0, fa[0]);
+            W4_WAIT_LGKM4(0, fbA);
+            W4_WAIT_LGKM4(0, fbB);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();            // every wave holds its fragments: the buffers may be restaged
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < n2) stage2(c + 2, par);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W4_MFMA(acc[i][r], fa[0][i], fbA[r]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W4_MFMA(acc[i][4 + r], fa[0][i], fbB[r]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
     W4_TL(2);
     W4_RT(5);
     // ---- epilogue --------------------------------------------------------------------------------------------------------
@@ -564,6 +648,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 // Layers of the window kernel (onedc_conv_win_ok) whose epilogue is the fast linear one on whole 64-channel wave tiles;
 // with gn_ab, room for the image's (a, b) pairs behind the ring while two workgroups still fit a CU.
 bool onedc_conv_win4_ok(const onedc_conv_params &p) {
+    if (p.x2 && (!p.w2 || p.Cin2 < 32 || (p.Cin2 & 31) || ((p.x2_cs | p.x2_co) & 7) || p.stride != 1 ||
+                 (int64_t)((p.Cout + 127) / 128 * 128) * p.Cin2 * 2 > 0x7fffffffll))
+        return false;
     return !p.up && conv_epi_fast_ok(p, false) && p.epi == ONEDC_EPI_LINEAR && (p.Cout & 63) == 0 &&
            ((p.y_cs | p.y_co) & 7) == 0 && (!p.res || ((p.r_cs | p.r_co) & 3) == 0) &&
            (!p.gn_ab || W4_LDS + (int64_t)p.Cin * 8 <= 80 * 1024);
@@ -584,12 +671,22 @@ static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
 #else
     const dim3 grid((unsigned)blocks), block(256);
 #endif
-    if (!p.stats)
-        hipLaunchKernelGGL((conv_win4_kernel<MODE, 0>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x, dv_c);
-    else if (p.stats_gran == 2)
-        hipLaunchKernelGGL((conv_win4_kernel<MODE, 2>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x, dv_c);
-    else
-        hipLaunchKernelGGL((conv_win4_kernel<MODE, 4>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, dv_x, dv_c);
+#define W4_LAUNCH(ST_, X2_)                                                                                          \
+    hipLaunchKernelGGL((conv_win4_kernel<MODE, ST_, X2_>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, \
+                       dv_x, dv_c)
+    if constexpr (!UPS) {
+        if (p.x2) {
+            if (!p.stats) W4_LAUNCH(0, true);
+            else if (p.stats_gran == 2) W4_LAUNCH(2, true);
+            else W4_LAUNCH(4, true);
+            ONEDC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (!p.stats) W4_LAUNCH(0, false);
+    else if (p.stats_gran == 2) W4_LAUNCH(2, false);
+    else W4_LAUNCH(4, false);
+#undef W4_LAUNCH
     ONEDC_LAUNCH_CHECK();
     return 0;
 }
@@ -602,6 +699,12 @@ static void win4_attrs() {
                  {(const void *)conv_win4_kernel<1, 0>, 80 * 1024},
                  {(const void *)conv_win4_kernel<1, 2>, 80 * 1024},
                  {(const void *)conv_win4_kernel<1, 4>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<0, 0, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 2, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 4, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<1, 0, true>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 2, true>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 4, true>, 80 * 1024},
                  {(const void *)conv_win4_kernel<2, 0>, W4_LDS},
                  {(const void *)conv_win4_kernel<2, 2>, W4_LDS},
                  {(const void *)conv_win4_kernel<2, 4>, W4_LDS}});

@@ -76,6 +76,8 @@ class ConvParams(C.Structure):
         ("in_f32", C.c_int32),
         ("x_bs", _L), ("w_bs", _L), ("y_bs", _L), ("r_bs", _L),
         ("gn_ab", _P), ("gn_silu", C.c_int32), ("out_bf16", C.c_int32),
+        ("ws", _P), ("ws_bytes", _L), ("split_k", C.c_int32),
+        ("x2", _P), ("w2", _P), ("Cin2", C.c_int32), ("x2_cs", C.c_int32), ("x2_co", C.c_int32),
     ]
 
 
@@ -92,6 +94,8 @@ class DirectConvParams(C.Structure):
 SIGNATURES = {
     "onedc_conv_gemm": (_I, [C.POINTER(ConvParams), _P]),
     "onedc_conv_win_takes": (_I, [C.POINTER(ConvParams)]),
+    "onedc_conv_win_takes_x2": (_I, [C.POINTER(ConvParams)]),
+    "onedc_conv_splitk_ws_bytes": (_L, [C.POINTER(ConvParams)]),
     "onedc_conv_gemm_kernel_id": (_I, [C.POINTER(ConvParams)]),
     "onedc_conv_kernel_name": (C.c_char_p, [_I]),
     "onedc_direct_conv": (_I, [C.POINTER(DirectConvParams), _P]),
@@ -291,6 +295,20 @@ def from_nchw(x, dtype=None, cs=None, pad_to=None):
     return View(t.reshape(-1), B, H, W, Cp, cs, 0)
 
 
+SPLIT_K = int(os.environ.get("ONEDC_SPLIT_K", "0"))       # onedc_conv_params.split_k of every launch: 0 = the dispatcher decides by layer shape, 1 = never (tests, A/B)
+_splitk_ws = {}
+
+
+def splitk_workspace(device, nbytes):
+    """Scratch for the partial sums of a split-K launch: one buffer per (device, HIP stream), grown on demand."""
+    key = (str(device), stream())
+    t = _splitk_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _splitk_ws[key] = t
+    return t
+
+
 PROFILE = None   # bench.py sets this to a list: every conv_gemm launch is then bracketed by HIP events
 PROFILE_ONLY = None   # ... or, with a set of kernel-family names here, only the launches the dispatcher sends to those
 
@@ -308,8 +326,11 @@ def conv_kernel_name(p):
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
               pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0,
-              tile=0, stats=False, pad=None, gn=None, out_bf16=False):
+              tile=0, stats=False, pad=None, gn=None, out_bf16=False, x2=None, w2=None):
     """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None.
+    x2, w2: a second source on the output grid and its packed 1x1 weights (pre-divided by alpha), accumulated behind the 3x3
+    taps: y = alpha * (conv(x) + conv1x1(x2)) + bias + res.  Only the 4-wave window kernel does it; when the dispatcher
+    would not, NOTHING is launched and None is returned (the caller runs the two layers separately).
     gn = (gamma, beta, eps, silu, ws): the conv reads GroupNorm(x) (+SiLU).  On the 3x3 window kernel the
     normalisation is applied while the operand is staged (x is read raw, the normalised tensor never exists);
     any other kernel gets it from the separate scale/shift pass, with identical values."""
@@ -342,6 +363,11 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
         raise KernelError("f32 conv_gemm needs f32 weights and residual")
     p.alpha, p.slope = alpha, slope
     p.batch, p.x_bs, p.w_bs, p.y_bs, p.r_bs = batch, x_bs, w_bs, y_bs, r_bs
+    p.split_k = SPLIT_K
+    if x2 is not None:
+        p.x2, p.w2, p.Cin2, p.x2_cs, p.x2_co = x2.ptr, w2.data_ptr(), x2.C, x2.cs, x2.co
+        if (x2.B, x2.H, x2.W) != (y.B, y.H, y.W) or not lib().onedc_conv_win_takes_x2(C.byref(p)):
+            return None
     if gn is not None:
         gamma, beta, eps, silu, ws = gn
         # every 128-channel output tile normalises the window again: only worth it while there is one tile
@@ -352,6 +378,11 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
             xn = new_view(x.B, x.H, x.W, x.C, x.t.device)
             group_norm(x, gamma, beta, xn, eps, silu, ws)
             p.x, p.x_cs, p.x_co = xn.ptr, xn.cs, xn.co
+    if KH == 3 and p.OH * p.OW <= 256 and SPLIT_K != 1:        # (pre-filter only: the C dispatcher decides)
+        need = lib().onedc_conv_splitk_ws_bytes(C.byref(p))
+        if need:
+            wsb = splitk_workspace(x.t.device, need)
+            p.ws, p.ws_bytes = wsb.data_ptr(), wsb.numel()
     if PROFILE is None or (PROFILE_ONLY is not None and conv_kernel_name(p) not in PROFILE_ONLY):
         _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
         return y
@@ -360,11 +391,11 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     _ok(lib().onedc_conv_gemm(C.byref(p), stream()), "onedc_conv_gemm")
     e1.record()
     # executed multiply-adds: the phase-decomposed upsample conv (up == 2) runs 4 taps per output, not 9
-    flops = 2.0 * p.B * p.OH * p.OW * p.Cout * ((4 if up == 2 else p.KH * p.KW) * p.Cin) * max(batch, 1) * flop_scale
+    flops = 2.0 * p.B * p.OH * p.OW * p.Cout * ((4 if up == 2 else p.KH * p.KW) * p.Cin + p.Cin2) * max(batch, 1) * flop_scale
     es_in = 4 if p.in_f32 else 2
     es_out = 4 if p.out_f32 else 2
     cout_store = p.Cout // 2 if glu else p.Cout
-    nbytes = (p.B * p.IH * p.IW * p.Cin * es_in + p.B * p.OH * p.OW * cout_store * es_out +
+    nbytes = (p.B * p.IH * p.IW * (p.Cin + p.Cin2) * es_in + p.B * p.OH * p.OW * cout_store * es_out + p.Cout * p.Cin2 * es_in +
               p.Cout * p.KH * p.KW * p.Cin * es_in + (p.B * p.OH * p.OW * cout_store * es_in if res is not None else 0)) \
         * max(batch, 1)
     PROFILE.append((conv_kernel_name(p), flops, e0, e1, float(nbytes)))

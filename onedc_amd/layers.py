@@ -65,6 +65,7 @@ class Workspace:
 
 
 USE_UPSAMPLE_PHASES = True    # tests switch it off to compare with the plain fused-upsample path
+FUSE_SHORTCUT = __import__("os").environ.get("ONEDC_FUSE_SHORTCUT", "1") != "0"   # ResnetBlock2D.conv_shortcut inside conv2's launch
 
 
 class Conv:
@@ -107,10 +108,14 @@ class Conv:
         return self
 
     def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
-                 alpha=1.0, stats=False, pad=None, gn=None):
+                 alpha=1.0, stats=False, pad=None, gn=None, x2=None, w2=None, bias=None):
         """stats: the output feeds a GroupNorm -- leave its partial sums in the epilogue.
         gn = (GroupNorm layer, workspace, silu): the conv reads that norm of x (fused into the operand staging
-        where the kernel can, kernels.conv_gemm)."""
+        where the kernel can, kernels.conv_gemm).
+        x2, w2, bias: a second (1x1) source accumulated into the same output and the combined bias (kernels.conv_gemm);
+        returns None, with nothing launched, when the kernel this layer runs on does not take one."""
+        if x2 is not None and (self.mxfp8 or up or self.shuffle or self.glu):
+            return None
         if y is None:
             oh, ow = x.H, x.W
             if stride == 2:
@@ -143,9 +148,9 @@ class Conv:
                                Cout=self.cout, stats=stats)
         if gn is not None:
             gn = (gn[0].g, gn[0].b, gn[0].eps, gn[2], gn[1])
-        return K.conv_gemm(x, self.w, self.b, y, KH=self.k, stride=stride, up=up, epi=epi, slope=slope,
-                           alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
-                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad, gn=gn)
+        return K.conv_gemm(x, self.w, self.b if bias is None else bias, y, KH=self.k, stride=stride, up=up, epi=epi,
+                           slope=slope, alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
+                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad, gn=gn, x2=x2, w2=w2)
 
 
 _Conv = Conv
@@ -290,6 +295,12 @@ class ResnetBlock2D:
             self.c2.b = (self.c2.b * s).contiguous()
             if self.short is not None:
                 self.short.b = (self.short.b * s).contiguous()
+        # conv_shortcut riding on conv2 (onedc_conv_params.x2): its weights divided by conv2's alpha (a power of two), the
+        # two biases added; used wherever conv2 runs on the 4-wave window kernel (the dispatcher is asked per call)
+        self.short_w2 = self.short_b2 = None
+        if self.short is not None and self.short.k == 1 and FUSE_SHORTCUT:
+            self.short_w2 = pack.pack_matrix(pack.conv_matrix(sd[f"{p}.conv_shortcut.weight"]) / s, device)
+            self.short_b2 = (self.c2.b + self.short.b).contiguous()
         self.cin = cin
         self._c1_bias = sd[f"{p}.conv1.bias"].float()
         if f"{p}.time_emb_proj.weight" in sd:
@@ -304,6 +315,11 @@ class ResnetBlock2D:
 
     def __call__(self, x, ws, y=None):
         h = self.c1(x, stats=True, gn=(self.n1, ws, True))
+        if self.short_w2 is not None and FUSE_SHORTCUT:
+            out = self.c2(h, y, stats=True, gn=(self.n2, ws, True), alpha=self.stream_scale, x2=x, w2=self.short_w2,
+                          bias=self.short_b2)
+            if out is not None:
+                return out
         res = self.short(x) if self.short is not None else x
         return self.c2(h, y, res=res, stats=True, gn=(self.n2, ws, True), alpha=self.stream_scale)
 

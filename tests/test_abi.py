@@ -72,6 +72,9 @@ def test_libraries_carry_the_id_of_the_sources_beside_them(monkeypatch):
     assert build._built_id(_native.CODER_SO) == build.coder_source_id() == _native.coder().onedc_coder_build_id().decode()
     for path, fmt in ((_native.HIP_SO, "bf16"), (_native.HIP_F16_SO, "f16")):
         assert build._built_id(path) == build.hip_source_id() == kernels.lib(fmt).onedc_hip_build_id().decode()
+    # experiment flags (ablation builds compute wrong results by design) are part of the identity: such a build never
+    # passes for the plain one, and the next plain build finds a wrong id and recompiles every object
+    assert build.hip_source_id(("-DEXP_SILU_FREE",)) != build.hip_source_id()
     # a tree whose sources moved on: the loader refuses the library
     monkeypatch.setattr(kernels, "_libs", {})
     monkeypatch.setattr(_native, "_hip_f16", None)

@@ -1069,3 +1069,119 @@ def test_group_norm_pair_statistics_320_and_960_channels(tile):
     # a 320-channel buffer of its own picks pairs by itself
     y = new_view(B, H, W, 320, DEV, stats=True)
     assert y.stats.gran == 2
+
+
+# ---- round 4: split-K for the 12x12 level, conv_shortcut as a second source of the window kernel ------------------------
+@pytest.mark.parametrize("Cin,Cout,res", [(1280, 1280, True), (2560, 1280, False), (1280, 256, True)])
+def test_conv_splitk_small_maps(Cin, Cout, res):
+    """3x3 layers of the UNet's 12x12 level (decoder_unet.py:204-293) on the split-K form: against F.conv2d, against the
+    unsplit kernels, the same bits on every launch, and a picture alone == inside a batch (the number of parts follows
+    from the layer's shape, never from B)."""
+    B, H, W = 3, 12, 12
+    x, w, b = rnd(B, Cin, H, W, seed=401), rnd(Cout, Cin, 3, 3, seed=402, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=403)
+    r = rnd(B, Cout, H, W, seed=404) if res else None
+    xv, wp, rv = from_nchw(x.to(DEV)), packed(w), (from_nchw(r.to(DEV)) if res else None)
+    runs = []
+    for split in (0, 1, 0):
+        K.SPLIT_K = split
+        try:
+            y = new_view(B, H, W, Cout, DEV)
+            K.conv_gemm(xv, wp, b.to(DEV), y, KH=3, res=rv)
+        finally:
+            K.SPLIT_K = 0
+        runs.append(y.t[:B * H * W * Cout].clone())
+        if split == 0:
+            yk = y
+    ref = F.conv2d(x, w, b, padding=1) + (r if res else 0)
+    close(yk.torch_nchw(), ref, what="split-K")
+    assert torch.equal(runs[0], runs[2])                                       # deterministic
+    close(runs[0].float().view(B, H, W, Cout), runs[1].float().view(B, H, W, Cout), rms=2e-3, mx=1e-2, what="split vs unsplit")
+    y1 = new_view(1, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(x[1:2].to(DEV)), wp, b.to(DEV), y1, KH=3, res=(from_nchw(r[1:2].to(DEV)) if res else None))
+    assert torch.equal(y1.t[:H * W * Cout], runs[0].view(B, -1)[1])            # batch-invariant
+
+
+def test_conv_splitk_dispatch_is_by_shape():
+    """The dispatcher's own answer: split for the 12x12 level's 3x3 layers at any B, not for short K, large maps or 1x1."""
+    def kid(B, H, Cin, Cout, k, ws=True):
+        x = new_view(B, H, H, Cin, DEV)
+        y = new_view(B, H, H, Cout, DEV)
+        p = K.ConvParams()
+        p.x, p.w, p.y, p.zeros = x.ptr, x.ptr, y.ptr, K.zeros_page(DEV).data_ptr()
+        p.B, p.IH, p.IW, p.Cin, p.x_cs = B, H, H, Cin, Cin
+        p.OH, p.OW, p.Cout, p.y_cs = H, H, Cout, Cout
+        p.KH = p.KW = k
+        p.stride, p.pad, p.alpha = 1, k // 2, 1.0
+        need = K.lib().onedc_conv_splitk_ws_bytes(p)
+        if need and ws:
+            t = K.splitk_workspace(DEV, need)
+            p.ws, p.ws_bytes = t.data_ptr(), t.numel()
+        return K.conv_kernel_name(p), need
+    for B in (1, 2, 16):
+        name, need = kid(B, 12, 1280, 1280, 3)
+        assert name == "splitk_256" and need == 5 * B * 144 * 1280 * 4
+    assert kid(16, 12, 1280, 1280, 3, ws=False)[0] != "splitk_256"            # no scratch: the unsplit kernels
+    assert kid(16, 12, 1280, 1280, 1)[1] == 0 and kid(16, 24, 1280, 1280, 3)[1] == 0 and kid(16, 12, 320, 1280, 3)[1] == 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,Cin2,gn,alpha", [(2, 32, 16, 128, 128, 256, True, 2.0 ** -6), (1, 16, 48, 256, 256, 512, False, 1.0),
+                                                          (2, 16, 16, 320, 320, 960, False, 1.0), (1, 32, 32, 128, 128, 32, True, 1.0),
+                                                          (1, 16, 16, 64, 128, 96, False, 0.25)])
+def test_conv_win4_second_source(B, H, W, Cin, Cout, Cin2, gn, alpha):
+    """conv3x3([silu(GroupNorm(.))] h) + conv1x1(x2) in ONE launch of the 4-wave window kernel (diffusers ResnetBlock2D: conv2
+    + conv_shortcut, called from model_sd15_with_codec_stage1.py:184-188) against F.conv2d and against the two separate
+    launches; x2 is a channel slice of a wider buffer, GroupNorm statistics of the output left by the epilogue."""
+    h, w, b = rnd(B, Cin, H, W, seed=411), rnd(Cout, Cin, 3, 3, seed=412, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=413)
+    x2, w2, b2 = rnd(B, Cin2, H, W, seed=414), rnd(Cout, Cin2, 1, 1, seed=415, scale=Cin2 ** -0.5), rnd(Cout, seed=416)
+    g, be = 1 + 0.2 * rnd(Cin, seed=417), 0.5 * rnd(Cin, seed=418)
+    hv = from_nchw(h.to(DEV))
+    x2buf = from_nchw(torch.cat([rnd(B, 64, H, W, seed=419), x2], 1).to(DEV))
+    x2v = x2buf.slice(64, Cin2)
+    ws = _WS()
+    gnarg = (g.to(DEV), be.to(DEV), 1e-6, True, ws) if gn else None
+    y = new_view(B, H, W, Cout, DEV, stats=True)
+    w2p = pack.pack_matrix(pack.conv_matrix(w2) / alpha, DEV)
+    out = K.conv_gemm(hv, packed(w), (b + b2).to(DEV), y, KH=3, alpha=alpha, stats=True, gn=gnarg, x2=x2v, w2=w2p)
+    assert out is not None, "the dispatcher refused the second source"
+    hn = F.silu(F.group_norm(h, 32, g, be, 1e-6)) if gn else h
+    ref = alpha * F.conv2d(hn, w, None, padding=1) + b.view(1, -1, 1, 1) + F.conv2d(x2, w2, b2)
+    close(y.torch_nchw(), ref, rms=6e-3 if gn else 4e-3, mx=4e-2, what="second source")
+    # the two separate launches (shortcut first, its output as the residual; the generic kernels read 64-channel K-tiles)
+    if Cin2 % 64 == 0:
+        sc = new_view(B, H, W, Cout, DEV)
+        K.conv_gemm(x2v, packed(w2), b2.to(DEV), sc, KH=1)
+        y2 = new_view(B, H, W, Cout, DEV, stats=True)
+        K.conv_gemm(hv, packed(w), b.to(DEV), y2, KH=3, alpha=alpha, stats=True, gn=gnarg, res=sc)
+        close(y.torch_nchw(), y2.torch_nchw(), rms=3e-3, mx=2e-2, what="one launch vs two")
+    # the statistics the epilogue left are those of the stored values
+    gg, bb = rnd(Cout, seed=420), rnd(Cout, seed=421)
+    o = new_view(B, H, W, Cout, DEV)
+    ws2 = _WS()
+    K.group_norm(y, gg.to(DEV), bb.to(DEV), o, 1e-6, True, ws2)
+    assert "gn_partial" not in ws2.t
+    close(o.torch_nchw(), F.silu(F.group_norm(y.torch_nchw().cpu(), 32, gg, bb, 1e-6)), rms=6e-3, mx=4e-2, what="stats behind x2")
+
+
+def test_conv_win4_second_source_race_screen_and_refusal():
+    B, H, W, Cin, Cout, Cin2 = 4, 48, 48, 128, 128, 256
+    h, w = rnd(B, Cin, H, W, seed=431), rnd(Cout, Cin, 3, 3, seed=432, scale=(9 * Cin) ** -0.5)
+    x2, w2 = rnd(B, Cin2, H, W, seed=433), rnd(Cout, Cin2, 1, 1, seed=434, scale=Cin2 ** -0.5)
+    hv, x2v, wp, w2p = from_nchw(h.to(DEV)), from_nchw(x2.to(DEV)), packed(w), packed(w2)
+    ref = None
+    for it in range(30):
+        y = new_view(B, H, W, Cout, DEV)
+        assert K.conv_gemm(hv, wp, None, y, KH=3, x2=x2v, w2=w2p) is not None
+        got = y.t[:B * H * W * Cout].clone()
+        if ref is None:
+            ref = got
+            close(y.torch_nchw(), F.conv2d(h, w, None, padding=1) + F.conv2d(x2, w2), what="second source race ref")
+        else:
+            assert torch.equal(got, ref), f"run {it} differs"
+    y1 = new_view(1, H, W, Cout, DEV)
+    K.conv_gemm(from_nchw(h[2:3].to(DEV)), wp, None, y1, KH=3, x2=from_nchw(x2[2:3].to(DEV)), w2=w2p)
+    assert torch.equal(y1.t[:H * W * Cout], ref.view(B, -1)[2])
+    # a layer the window kernel does not take (12x12 map): nothing is launched, the caller is told
+    y = new_view(1, 12, 12, Cout, DEV)
+    y.t.fill_(7.0)
+    assert K.conv_gemm(from_nchw(h[:1, :, :12, :12].to(DEV)), wp, None, y, KH=3, x2=from_nchw(x2[:1, :, :12, :12].to(DEV)), w2=w2p) is None
+    assert float((y.t[:144 * Cout].float() - 7.0).abs().max()) == 0.0
