@@ -241,8 +241,12 @@ int onedc_x0_from_noise(const float *reduced, const float *eps, float *x0, int64
  * optional clamp(-1,1)*0.5+0.5 (inference.py:106).
  * nonfinite: NULL, or int32 [B] zero-filled by the caller; word b is set to 1 when picture b holds a NaN / Inf BEFORE the
  * clamp (which would turn it into a valid-looking pixel): the range guard of the IEEE-half build. */
-int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
-                    int unit_range, int32_t *nonfinite, void *stream);
+int onedc_image_out_checked(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
+                            int unit_range, int32_t *nonfinite, void *stream);
+/* the same without the range flag: the signature of library versions up to 0.2, kept so that a host built against it
+ * keeps working (version 0.3 had inserted `nonfinite` in front of `stream` under the old name) */
+int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W, int unit_range,
+                    void *stream);
 /* The same crop as 8-bit samples, converted on the device: clamp(-1,1)*0.5+0.5 (inference.py:106), then x255 + 0.5,
  * clamp(0,255), truncation (torchvision save_image, inference.py:107,120).  nhwc = 1: [B][H][W][3] (what an image
  * writer takes), 0: [B][3][H][W].  A batch then crosses PCIe as 1 byte per sample. */

@@ -148,16 +148,19 @@ class Decoder:
 
 class IntraNoAR:
     def __init__(self, sd, device, bottleneck_ch=128, semantic_ch=768, z_fsq_levels=(4,) * 7, host_threads=None,
-                 prior_f32=True, prior_arith="mfma", ref_threads=None, ref_profile=None):
+                 prior_f32=True, prior_arith="auto", ref_threads=None, ref_profile=None):
         """prior_f32: run everything that feeds the integer decisions of the entropy coder (hyper
         decoder, prior fusion, the four-part prior's nets: 36 GFLOP of the 8047 per 768x768 picture)
         in exact f32 on the f32 matrix-core path, like the reference's CPU path; False = bf16 MFMA
         like the reference under GPU autocast (SURVEY hard part 2).
-        prior_arith: "mfma" (default: this package's own prior, encoder and decoder side alike) or "torch_cpu": the prior
+        prior_arith: "mfma" (this package's own prior, encoder and decoder side alike) or "torch_cpu": the prior
         networks evaluated in the REFERENCE'S CPU arithmetic -- the fused-multiply-add chains torch-CPU's convolutions are
         made of, calibrated against the local torch (onedc_amd/ref_arith.py) -- so that y streams written by the reference
         decode here, and streams written here in this mode decode there.  ~10x slower prior; pictures above ~0.16 MP.
-        "auto": decode with the MFMA prior; a stream that desynchronises is tried again in the reference's arithmetic,
+        "auto" (the default: the only setting under which a .bin written by the reference decodes,
+        compression_model.py:369-407 / entropy_models.py:355-362, and it costs nothing on this package's own streams, which
+        pass at the first try; the ENCODER side always writes with the MFMA prior in this mode): decode with the MFMA prior;
+        a stream that desynchronises is tried again in the reference's arithmetic,
         calibrated for `ref_threads` / torch's current thread count and then for 8, 1 and 16 threads (the classes torch-CPU's
         kernel choice falls into), a batch of mixed producers picture by picture, before StreamDesyncError is raised.
         ref_threads: the writer's torch thread count to calibrate "torch_cpu" for (None: torch's current count).
@@ -177,6 +180,8 @@ class IntraNoAR:
         self.ref_profile = ref_profile            # known native-path structures of the writer (ref_arith.Calibration), or None
         self.ref_prior = None                     # the reference-arithmetic prior in use (None: the MFMA prior)
         self._ref_priors = {}                     # per calibrated thread count
+        import threading
+        self._auto_lock = threading.RLock()       # "auto" switches self.ref_prior while it retries: one decode at a time
         self._ref_sd = sd if prior_arith != "mfma" else None
         if prior_arith == "torch_cpu":
             self.ref_prior = self._reference_prior(ref_threads)
@@ -270,6 +275,10 @@ class IntraNoAR:
         desynchronise under the MFMA prior."""
         if self.prior_arith != "auto":
             return self._decompress_once(streams_y, indices, trace)
+        with self._auto_lock:
+            return self._decompress_auto(streams_y, indices, trace)
+
+    def _decompress_auto(self, streams_y, indices, trace):
         cur = torch.get_num_threads()
         # the MFMA prior, then the reference's arithmetic calibrated for the configuration classes a writer may have used: the
         # stated / current thread count, 8 (2-8 threads are one class on pictures above ~0.16 MP), 1 (the reference harness's own
@@ -280,15 +289,18 @@ class IntraNoAR:
                 attempts.append(t)
         first_error = None
         for threads in attempts:
-            self.ref_prior = None if threads is None else self._reference_prior(threads)
             try:
+                # (building / calibrating the reference prior for a thread count can itself fail -- no candidate structure
+                # matches this host's torch -- and must not end the attempts: the next class may still decode the stream)
+                self.ref_prior = None if threads is None else self._reference_prior(threads)
                 if trace is not None:
                     del trace[:]
                 return self._decompress_once(streams_y, indices, trace)
             except StreamDesyncError as e:
                 first_error = first_error or e
-            except ReferenceArithmeticUnavailable:          # (pictures too small for that path: nothing more to try there)
-                pass
+            except (ReferenceArithmeticUnavailable, AssertionError):         # nothing more to try in that class
+                if threads is None:                             # (not a calibration problem: the MFMA attempt itself)
+                    raise
             finally:
                 self.ref_prior = None
         if len(streams_y) > 1 and trace is None:

@@ -365,7 +365,10 @@ int onedc_rans_enc_empty_cdf_buffer(onedc_rans_enc *enc) {
 }
 int onedc_rans_enc_reset(onedc_rans_enc *enc) {
     if (!enc) return ONEDC_ERR_ARG;
-    for (auto &p : enc->parts) p.pending.clear();
+    for (auto &p : enc->parts) {
+        p.pending.clear();
+        p.oom = false;                                      // a failed allocation does not outlive the symbols it was for
+    }
     enc->flushed = false;
     return ONEDC_OK;
 }
@@ -379,10 +382,18 @@ int onedc_rans_enc_encode_with_indexes(onedc_rans_enc *enc, const int16_t *symbo
     // contiguous split over the parts, the last part takes the remainder (py_rans.cpp:31-36)
     const int np = (int)enc->parts.size();
     const int64_t each = n / np;
+    size_t at_entry[16];                                     // (stream parts: a 4-bit field of the flag byte)
+    for (int p = 0; p < np && p < 16; ++p) at_entry[p] = enc->parts[p].pending.n;
     for (int p = 0; p < np; ++p) {
         const int64_t cnt = p < np - 1 ? each : n - each * (np - 1);
         enc->parts[p].push(g, symbols + p * each, indexes + p * each, cnt);
-        if (enc->parts[p].oom) return ONEDC_ERR_CAPACITY;       // out of memory for the pending symbols
+        if (enc->parts[p].oom) {                             // out of memory for the pending symbols: the call did not happen
+            for (int q = 0; q < np && q < 16; ++q) {         // -- every part back to where it stood, the flag cleared
+                enc->parts[q].pending.n = at_entry[q];
+                enc->parts[q].oom = false;
+            }
+            return ONEDC_ERR_CAPACITY;
+        }
     }
     return ONEDC_OK;
 }

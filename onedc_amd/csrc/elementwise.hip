@@ -535,8 +535,13 @@ int onedc_x0_from_noise(const float *reduced, const float *eps, float *x0, int64
     return 0;
 }
 
-int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
-                    int unit_range, int32_t *nonfinite, void *stream) {
+int onedc_image_out(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W, int unit_range,
+                    void *stream) {                 // the 0.2 signature, kept: a host built against it must not break
+    return onedc_image_out_checked(x, x_f32, x_cs, out, B, PH, PW, H, W, unit_range, nullptr, stream);
+}
+
+int onedc_image_out_checked(const void *x, int x_f32, int x_cs, float *out, int B, int PH, int PW, int H, int W,
+                            int unit_range, int32_t *nonfinite, void *stream) {
     if (!x || !out || H > PH || W > PW) return -1;
     const int64_t n = (int64_t)B * 3 * H * W;
     if (x_f32) LAUNCH(image_out_kernel<true>, n, x, x_cs, out, B, PH, PW, H, W, unit_range, nonfinite);

@@ -12,6 +12,16 @@ Without --decoder_only the harness runs the reference's evaluate loop (:109-134)
 --eval_image_path is encoded to <output_path>/stream/<name>.bin, decoded to <output_path>/recon/<name>.png,
 and the bpp dictionaries land in detail_bpp_caption.xlsx / summary_bpp.xlsx (CSV content, like the
 reference, which calls to_csv on those names).
+
+Several processes (one per GPU: `torchrun --nproc-per-node N -m onedc_amd.inference ...`, or any launcher that sets RANK /
+WORLD_SIZE / LOCAL_RANK): the reference shards the pictures with `accelerator.prepare(img_dataloader)`, removes the output
+directory on the main process only and meets at a barrier per picture (inference.py:37,49-59,82,127).  Here rank r takes
+pictures r, r + world, ... (dataparallel.shard), rank 0 alone prepares the output directory and the others wait for it, every
+rank appends its bpp rows to a part file as it goes, and rank 0 merges the parts into the two tables (the reference lets every
+process overwrite them with its own shard).  The rendezvous is through files in --output_path: no process group is needed.
+The noise of latent_dist.sample() is drawn per picture from a generator seeded with the picture's index, so a picture's
+stream does not depend on how many processes shared the folder.  A directory given to --decoder_only goes through the
+overlapped pipeline (`model.pipeline().map(..., out="u8", to_host=True)`), sharded the same way.
 """
 import argparse
 import glob
@@ -57,6 +67,34 @@ def prepare_output_dir(out):
     os.makedirs(recon_path)
     os.makedirs(stream_path)
     return recon_path, stream_path
+
+
+def rank_world():
+    """(rank, world) of this process from the launcher's environment (torchrun / accelerate launch); (0, 1) alone."""
+    return int(os.environ.get("RANK", "0") or 0), max(1, int(os.environ.get("WORLD_SIZE", "1") or 1))
+
+
+def run_token():
+    """What the ranks of ONE launch share and another launch does not: the launcher's run id, else the parent's pid."""
+    return os.environ.get("ONEDC_RUN_ID") or f"{os.environ.get('TORCHELASTIC_RUN_ID', '')}-ppid{os.getppid()}"
+
+
+def wait_for(predicate, what, timeout=1800.0, poll=0.05):
+    """File-system rendezvous: poll until predicate() is true."""
+    import time
+    t0 = time.monotonic()
+    while not predicate():
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"rank {rank_world()[0]}: waited {timeout:.0f} s for {what}")
+        time.sleep(poll)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
 
 
 def check_mode_args(parser, cli):
@@ -105,16 +143,20 @@ def parse_args(argv=None):
 
 
 class Evaluator:
-    def __init__(self, args):
-        from .model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+    def __init__(self, args, model=None):
+        """model: an object with the wrapper's surface (tests); default: built and loaded like inference.py:69-74."""
         self.args = args
-        rank = args.get("local_rank", -1)
-        device = torch.device("cuda", rank if rank is not None and rank >= 0 else 0)
-        self.model = SD15_1step_codec_stage1(args, device=device)
-        self.model.load(args["checkpoint_path"], args.get("vae_path"))
-        self.model.prepare()
-        self.model.codec_model.update(force=True)
-        self.model.codec_model.debug = False
+        self.rank, self.world = rank_world()
+        if model is None:
+            from .model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+            rank = args.get("local_rank", -1)
+            device = torch.device("cuda", rank if rank is not None and rank >= 0 else 0)
+            model = SD15_1step_codec_stage1(args, device=device)
+            model.load(args["checkpoint_path"], args.get("vae_path"))
+            model.prepare()
+            model.codec_model.update(force=True)
+            model.codec_model.debug = False
+        self.model = model
 
     @torch.no_grad()
     def evaluate(self):
@@ -124,56 +166,121 @@ class Evaluator:
             return self.evaluate_folder()
         src, dst = args["decoder_bin_path"], args["decoder_out_path"]
         if os.path.isdir(src):
-            os.makedirs(dst, exist_ok=True)
-            files = sorted(glob.glob(os.path.join(src, "*.bin")))
-            by_size = {}
-            from .entropy.utils import decode_i, read_from_file
-            for f in files:
-                d = decode_i(read_from_file(f), 14, 64)
-                by_size.setdefault((d["pad_height"], d["pad_width"], d["height"], d["width"]), []).append(f)
-            for group in by_size.values():
-                for i in range(0, len(group), args["batch_size"]):
-                    chunk = group[i:i + args["batch_size"]]
-                    recon = self.model.decode(fp=chunk, out="u8")
-                    for f, img in zip(chunk, recon):
-                        save_image_u8(img, os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png"))
-            return
+            return self.decode_folder(src, dst)
         # clamp(-1,1)*0.5+0.5 and save_image's 8-bit quantisation (inference.py:106-107) happen in the output kernel;
         # a picture with NaN / Inf raises kernels.HalfRangeError there instead of being written
         recon = self.model.decode(fp=src, out="u8")
         save_image_u8(recon[0], dst)
 
+    @torch.no_grad()
+    def decode_folder(self, src, dst):
+        return decode_folder_pipelined(self.model, src, dst, self.args["batch_size"], self.rank, self.world)
 
     @torch.no_grad()
     def evaluate_folder(self):
-        """The encode + decode loop of the reference (inference.py:109-134), one picture at a time."""
-        import pandas as pd
-        args = self.args
-        out = args["output_path"]
-        recon_path, stream_path = prepare_output_dir(out)
-        src = args["eval_image_path"]
-        names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
-        torch.manual_seed(0)                                   # inference.py:28: the draw of latent_dist.sample()
-        rows = []
-        for idx, fname in enumerate(names):
-            name = os.path.splitext(fname)[0]
-            image = load_image(os.path.join(src, fname))[None].to(self.model.device)
-            _, _, H, W = image.shape
-            Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
-            noise = torch.randn(1, Hp // 8, Wp // 8, 4, device=self.model.device)
+        """The encode + decode loop of the reference (inference.py:109-134), one picture at a time; this rank's share of the
+        folder when several processes run it (module docstring)."""
+        out = self.args["output_path"]
+        recon_path, stream_path = os.path.join(out, "recon"), os.path.join(out, "stream")
+
+        def one_picture(idx, name, path):
+            image = load_image(path)[None].to(self.model.device)
+            noise = picture_noise(idx, image.shape[2], image.shape[3], self.model.device)
             stream_file = os.path.join(stream_path, f"{name}.bin")
             _, bpp = self.model.encode(image, fp=stream_file, noise=noise)
             recon = self.model.decode(fp=stream_file, out="u8")
             save_image_u8(recon[0], os.path.join(recon_path, f"{name}.png"))
             bpp = dict(bpp)
             bpp["image_name"] = name
-            rows.append(pd.DataFrame(bpp, index=[idx]))
-        detail = pd.concat(rows) if rows else pd.DataFrame()
-        detail.to_csv(os.path.join(out, "detail_bpp_caption.xlsx"))
-        avg = detail.mean(numeric_only=True).to_dict() if rows else {}
-        pd.DataFrame([avg]).to_csv(os.path.join(out, "summary_bpp.xlsx"))
-        print(avg)
-        return avg
+            return bpp
+
+        return evaluate_sharded(out, self.args["eval_image_path"], self.rank, self.world, one_picture,
+                                lambda frame, path: frame.to_csv(path))
+
+
+def picture_noise(idx, H, W, device):
+    """The draw of latent_dist.sample() for picture `idx` of the sorted folder.  inference.py:28 seeds the global generator
+    once and lets the pictures draw from it one after the other; here the draw belongs to the PICTURE (a generator seeded
+    with its index): the same stream whichever rank encodes it, however many ranks share the folder."""
+    Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
+    gen = torch.Generator(device=device).manual_seed(idx)
+    return torch.randn(1, Hp // 8, Wp // 8, 4, device=device, generator=gen)
+
+
+def evaluate_sharded(out, src, rank, world, one_picture, write_table):
+    """The folder loop shared by the two harnesses.  one_picture(idx, name, path) -> row dict (it writes the picture's
+    files itself).  Rank 0 prepares `out` (main process only: inference.py:49-54) and the others wait for its marker file;
+    rank r takes pictures r, r + world, ... of the sorted folder and appends every row to its part file at once (a failure
+    at picture k keeps the rows of the pictures before it); rank 0 merges the parts into detail_bpp_caption.xlsx /
+    summary_bpp.xlsx when every rank has left its done file."""
+    import pandas as pd
+    from . import dataparallel
+    marker, token = os.path.join(out, ".onedc_run"), run_token()
+    part_file = lambda r: os.path.join(out, f".detail_part{r}.csv")      # noqa: E731
+    done_file = lambda r: os.path.join(out, f".done{r}")                 # noqa: E731
+    if rank == 0:
+        prepare_output_dir(out)
+        with open(marker, "w") as f:
+            f.write(token)
+    else:
+        wait_for(lambda: _read(marker) == token, f"rank 0 to prepare {out!r}")
+    names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
+    for idx in dataparallel.shard(len(names), rank, world):
+        name = os.path.splitext(names[idx])[0]
+        row = pd.DataFrame(one_picture(idx, name, os.path.join(src, names[idx])), index=[idx])
+        row.to_csv(part_file(rank), mode="a", header=not os.path.exists(part_file(rank)))
+    with open(done_file(rank), "w") as f:
+        f.write(token)
+    if rank != 0:
+        return None
+    wait_for(lambda: all(_read(done_file(r)) == token for r in range(world)), "the other ranks to finish")
+    parts = [pd.read_csv(part_file(r), index_col=0) for r in range(world) if os.path.exists(part_file(r))]
+    detail = pd.concat(parts).sort_index() if parts else pd.DataFrame()
+    write_table(detail, os.path.join(out, "detail_bpp_caption.xlsx"))
+    avg = detail.mean(numeric_only=True).to_dict() if len(detail) else {}
+    write_table(pd.DataFrame([avg]), os.path.join(out, "summary_bpp.xlsx"))
+    for r in range(world):
+        for f in (part_file(r), done_file(r)):
+            if os.path.exists(f):
+                os.remove(f)
+    os.remove(marker)
+    print(avg)
+    return avg
+
+
+def decode_folder_pipelined(model, src, dst, batch_size, rank=0, world=1, z_only=False, group=8):
+    """Every *.bin of a directory -> <dst>/<name>.png in the throughput mode: batches of one padded size through the
+    overlapped pipeline (`model.pipeline().map(..., out="u8", to_host=True)`: 8-bit pictures in page-locked host memory),
+    `group` batches per map() call (bounds the host memory held), PNG writing on a small thread pool beside the next call.
+    Batches are dealt to the ranks round-robin.  Same pictures as sequential `model.decode` calls, bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import dataparallel
+    from .entropy.utils import decode_i, read_from_file
+    os.makedirs(dst, exist_ok=True)
+    by_size = {}
+    for f in sorted(glob.glob(os.path.join(src, "*.bin"))):
+        d = decode_i(read_from_file(f), 14, 64)
+        by_size.setdefault((d["pad_height"], d["pad_width"], d["height"], d["width"]), []).append(f)
+    batches = [g[i:i + batch_size] for g in by_size.values() for i in range(0, len(g), batch_size)]
+    mine = [batches[i] for i in dataparallel.shard(len(batches), rank, world)]
+    pipe = model.pipeline(z_only=z_only)
+    written = []
+    try:
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            pending = []
+            for i in range(0, len(mine), group):
+                chunk = mine[i:i + group]
+                outs = pipe.map([[read_from_file(f) for f in b] for b in chunk], out="u8", to_host=True)
+                for b, imgs in zip(chunk, outs):
+                    for f, img in zip(b, imgs):
+                        path = os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png")
+                        pending.append(pool.submit(save_image_u8, img, path))
+                        written.append(path)
+            for fut in pending:
+                fut.result()
+    finally:
+        pipe.close()
+    return written
 
 
 def main(argv=None):

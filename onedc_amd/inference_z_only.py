@@ -17,12 +17,12 @@ empty y part, 16 B header + ceil(14 n / 8) B of indices = 268 B for a 768x768 pi
 `--decoder_only --decoder_bin_path X.bin|DIR --decoder_out_path Y.png|DIR` which decodes such files.
 """
 import argparse
-import glob
 import os
 import torch
 import yaml
 
-from .inference import check_mode_args, load_image, prepare_output_dir, save_image, save_image_u8
+from .inference import (check_mode_args, decode_folder_pipelined, evaluate_sharded, load_image, picture_noise, rank_world,
+                        save_image, save_image_u8)
 
 
 def parse_args(argv=None):
@@ -58,20 +58,24 @@ def write_table(frame, path):
 
 
 class Evaluator:
-    def __init__(self, args):
-        from .model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+    def __init__(self, args, model=None):
         self.args = args
-        rank = args.get("local_rank", -1)
-        device = torch.device("cuda", rank if rank is not None and rank >= 0 else 0)
-        self.model = SD15_1step_codec_stage1(args, device=device)
-        self.model.load(args["checkpoint_path"], args.get("vae_path"))
-        self.model.prepare()
-        self.model.codec_model.update(force=True)
-        self.model.codec_model.debug = False
+        self.rank, self.world = rank_world()
+        if model is None:
+            from .model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+            rank = args.get("local_rank", -1)
+            device = torch.device("cuda", rank if rank is not None and rank >= 0 else 0)
+            model = SD15_1step_codec_stage1(args, device=device)
+            model.load(args["checkpoint_path"], args.get("vae_path"))
+            model.prepare()
+            model.codec_model.update(force=True)
+            model.codec_model.debug = False
+        self.model = model
 
     @torch.no_grad()
     def evaluate(self):
-        import pandas as pd
+        """This rank's share of the folder (inference.evaluate_sharded: rank 0 alone prepares the output directory, the
+        reference's `accelerator.is_main_process` guard :52-57, and merges the tables)."""
         args = self.args
         self.model.eval()
         if args["decoder_only"]:
@@ -79,29 +83,18 @@ class Evaluator:
         if getattr(self.model, "vae_encoder", None) is None:
             raise RuntimeError("the checkpoint carries no encoder weights (enc.*, hyper_enc.*, VAE encoder)")
         out = args["output_path"]
-        recon_path, stream_path = prepare_output_dir(out)
-        src = args["eval_image_path"]
-        names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
-        torch.manual_seed(0)                                   # :30, the draw of latent_dist.sample()
-        rows = []
-        for idx, fname in enumerate(names):
-            name = os.path.splitext(fname)[0]
-            image = load_image(os.path.join(src, fname))[None].to(self.model.device)
-            _, _, H, W = image.shape
-            Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
-            noise = torch.randn(1, Hp // 8, Wp // 8, 4, device=self.model.device)
+        recon_path, stream_path = os.path.join(out, "recon"), os.path.join(out, "stream")
+
+        def one_picture(idx, name, path):
+            image = load_image(path)[None].to(self.model.device)
+            noise = picture_noise(idx, image.shape[2], image.shape[3], self.model.device)      # (:30: the draw of latent_dist.sample())
             enc, recon = self.model.forward_z_only(image, noise=noise)
             save_image(recon[0].clamp(-1.0, 1.0) * 0.5 + 0.5, os.path.join(recon_path, f"{name}.png"))
             with open(os.path.join(stream_path, f"{name}.bin"), "wb") as f:
                 f.write(enc["stream"][0])
-            rows.append(pd.DataFrame({"image_name": name, "bpp_hard_y": enc["bpp_hard_y"], "bpp_z": enc["bpp_z"]},
-                                     index=[idx]))
-        detail = pd.concat(rows) if rows else pd.DataFrame()
-        write_table(detail, os.path.join(out, "detail_bpp_caption.xlsx"))
-        avg = detail.mean(numeric_only=True).to_dict() if rows else {}
-        write_table(pd.DataFrame([avg]), os.path.join(out, "summary_bpp.xlsx"))
-        print(avg)
-        return avg
+            return {"image_name": name, "bpp_hard_y": enc["bpp_hard_y"], "bpp_z": enc["bpp_z"]}
+
+        return evaluate_sharded(out, args["eval_image_path"], self.rank, self.world, one_picture, write_table)
 
     def decode_files(self):
         args = self.args
@@ -110,18 +103,7 @@ class Evaluator:
             recon = self.model.decode_z_only_stream(fp=src, out="u8")
             save_image_u8(recon[0], dst)
             return
-        from .entropy.utils import decode_i, read_from_file
-        os.makedirs(dst, exist_ok=True)
-        by_size = {}
-        for f in sorted(glob.glob(os.path.join(src, "*.bin"))):
-            d = decode_i(read_from_file(f), 14, 64)
-            by_size.setdefault((d["pad_height"], d["pad_width"], d["height"], d["width"]), []).append(f)
-        for group in by_size.values():
-            for i in range(0, len(group), args["batch_size"]):
-                chunk = group[i:i + args["batch_size"]]
-                recon = self.model.decode_z_only_stream(fp=chunk, out="u8")
-                for f, img in zip(chunk, recon):
-                    save_image_u8(img, os.path.join(dst, os.path.splitext(os.path.basename(f))[0] + ".png"))
+        return decode_folder_pipelined(self.model, src, dst, args["batch_size"], self.rank, self.world, z_only=True)
 
 
 def main(argv=None):

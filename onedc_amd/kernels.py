@@ -121,7 +121,8 @@ SIGNATURES = {
     "onedc_prior_update_enc": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_prior_update_zonly": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_x0_from_noise": (_I, [_P, _P, _P, _L, _D, _P]),
-    "onedc_image_out": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "onedc_image_out": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_image_out_checked": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "onedc_image_out_u8": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "onedc_copy_channels": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _L, _I, _P]),
     "onedc_window_partition": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -560,8 +561,8 @@ def x0_from_noise(reduced, eps, x0, alpha_bar):
 
 def image_out(x, out, H, W, unit_range=False, nonfinite=None):
     """nonfinite: int32 device tensor [B], zero-filled: word b becomes 1 when picture b holds a NaN / Inf (before the clamp)."""
-    _ok(lib().onedc_image_out(x.ptr, int(x.f32), x.cs, out.data_ptr(), x.B, x.H, x.W, H, W, int(unit_range),
-                              _ptr(nonfinite), stream()), "onedc_image_out")
+    _ok(lib().onedc_image_out_checked(x.ptr, int(x.f32), x.cs, out.data_ptr(), x.B, x.H, x.W, H, W, int(unit_range),
+                                      _ptr(nonfinite), stream()), "onedc_image_out_checked")
     return out
 
 

@@ -85,7 +85,7 @@ class SD15_1step_codec_stage1:
         with torch.cuda.device(self.device):
             self.feedforward_model = UNet(feedforward_sd, self.device, rank, alpha)
             self.codec_model = IntraNoAR(codec_sd, self.device, prior_f32=bool(_get(self.args, "prior_f32", True)),
-                                         prior_arith=_get(self.args, "prior_arith", "mfma") or "mfma",
+                                         prior_arith=_get(self.args, "prior_arith", "auto") or "auto",
                                          ref_threads=_get(self.args, "ref_threads", None),
                                          ref_profile=_get(self.args, "ref_profile", None))
             self.vae_large = VAEDecoder(vae_sd, self.device, self.vae_attn_patch)
@@ -303,7 +303,12 @@ class SD15_1step_codec_stage1:
         with K.act_format(self.act), torch.no_grad(), torch.cuda.device(self.device):
             res, flags = self._decode_after_entropy(self.codec_model.decode_entropy_z_only(fp=fp, stream=stream),
                                                     unit_range, out=out)
-            self._raise_if_nonfinite(flags)
+            try:
+                self._raise_if_nonfinite(flags)
+            except K.HalfRangeError:
+                if not (self.range_fallback and self.act == "f16"):
+                    raise
+                return self.bf16_twin().decode_z_only_stream(fp=fp, stream=stream, unit_range=unit_range, out=out)
             return res
 
     def decode_z_only(self, indices):
@@ -454,23 +459,36 @@ class DecodePipeline:
         cur = torch.cuda.current_stream(self.dev)
         outs = []
         self.last_done_events = [[p[1] for p in (e if isinstance(e, list) else [e])] for e in results]
-        for entry in results:
+        fallback = self.model.range_fallback and self.model.act == "f16"
+        for bi, entry in enumerate(results):
             parts = entry if isinstance(entry, list) else [entry]
-            tensors, first = [], 0
+            tensors, first, bad = [], 0, []
             for res, ev_done, stream, err, flags_host in parts:
                 if err is not None:
                     raise err
                 if self.model.check_finite or to_host:
                     ev_done.synchronize()                    # the flags (and host pictures) have landed
                     if self.model.check_finite:
-                        bad = [first + b for b in torch.nonzero(flags_host).flatten().tolist()]
-                        if bad:
-                            raise K.HalfRangeError(bad, self.model.act)
+                        bad += [first + b for b in torch.nonzero(flags_host).flatten().tolist()]
                 if not to_host:
                     cur.wait_event(ev_done)
                     res.record_stream(cur)
                 tensors.append(res)
                 first += res.shape[0]
+            if bad and fallback:
+                # f16_range_fallback, as in model.decode(): THIS batch again on the bf16 twin (sequentially: the rare
+                # path); the other batches of the call keep their pictures
+                twin = self.model.bf16_twin()
+                dec = twin.decode_z_only_stream if self.z_only else twin.decode
+                again = dec(stream=batches[bi], unit_range=unit_range, out=out)
+                if to_host:
+                    host = torch.empty(again.shape, dtype=again.dtype, pin_memory=True)
+                    host.copy_(again)
+                    again = host
+                outs.append(again)
+                continue
+            if bad:
+                raise K.HalfRangeError(bad, self.model.act)
             outs.append(tensors[0] if len(tensors) == 1 else torch.cat(tensors, 0))
         return outs
 

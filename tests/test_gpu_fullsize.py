@@ -328,7 +328,7 @@ def test_reference_made_stream_through_the_hip_prior(name, preset):
       * no flips  => the free-running decode returns the reference's symbols and y_hat,
       * any flip  => the decode raises StreamDesyncError (never a silently wrong picture)."""
     g = golden(name)
-    codec = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV)
+    codec = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="mfma")     # (the default, "auto", would go on to the reference arithmetic)
     codec.update(force=True)
     flips, total, y_hat_tf = _teacher_forced_flips(codec, g)
     inside = float(((g["index_planes"] > 0) & (g["index_planes"] < 255)).mean())
@@ -369,7 +369,7 @@ def test_reference_made_stream_bf16_prior_mode_reports_desync():
     """prior_f32=False reproduces the reference's GPU-autocast precision class (bf16 nets): a CPU-made stream then
     cannot decode (tens of percent of the indexes flip) -- it must say so."""
     g = golden("g5_codec_path.npz")
-    codec = IntraNoAR(synth.codec_state_dict(0), DEV, prior_f32=False)
+    codec = IntraNoAR(synth.codec_state_dict(0), DEV, prior_f32=False, prior_arith="mfma")
     codec.update(force=True)
     with pytest.raises(StreamDesyncError):
         codec.decompress([g["stream"].tobytes()], torch.from_numpy(g["indices"]).to(DEV))

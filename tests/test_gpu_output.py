@@ -124,6 +124,7 @@ def test_half_range_overflow_raises_with_the_fix_named(model, tmp_path):
             ev.args = {"decoder_only": True, "decoder_bin_path": str(tmp_path / "a.bin"),
                        "decoder_out_path": str(tmp_path / "a.png"), "batch_size": 16}
             ev.model = model
+            ev.rank, ev.world = 0, 1
             with pytest.raises(K.HalfRangeError):
                 ev.evaluate()
             assert not (tmp_path / "a.png").exists()
@@ -131,6 +132,13 @@ def test_half_range_overflow_raises_with_the_fix_named(model, tmp_path):
             model.range_fallback = True
             try:
                 fb = model.decode(stream=blobs, unit_range=True)
+                # ... and in the throughput mode too: the affected batches go to the twin, map() returns every batch
+                pipe = model.pipeline()
+                try:
+                    fbm = pipe.map([blobs, blobs[:1]], unit_range=True)
+                finally:
+                    pipe.close()
+                assert torch.equal(fbm[0], fb) and torch.equal(fbm[1], fb[:1])
             finally:
                 model.range_fallback = False
             assert model._twin is not None and model._twin.act == "bf16" and bool(torch.isfinite(fb).all())

@@ -491,6 +491,14 @@ def test_cli_harness_encode_decode_and_decoder_only(tmp_path):
                     "--vae_path", str(ckpt / "vae.safetensors"), "--decoder_only",
                     "--decoder_bin_path", str(out / "stream" / "b.bin"), "--decoder_out_path", str(tmp_path / "b2.png")])
     assert np.array_equal(np.asarray(Image.open(tmp_path / "b2.png")), np.asarray(Image.open(out / "recon" / "b.png")))
+    # a DIRECTORY of streams goes through the overlapped pipeline (model.pipeline().map(..., out="u8", to_host=True), PNG
+    # writing on a thread pool): the same pictures, bit for bit, as the one-by-one decodes of the evaluate loop
+    inference.main(["--config_path", str(tmp_path / "cfg.yaml"), "--checkpoint_path", str(ckpt),
+                    "--vae_path", str(ckpt / "vae.safetensors"), "--decoder_only",
+                    "--decoder_bin_path", str(out / "stream"), "--decoder_out_path", str(tmp_path / "dec")])
+    for name in ("a", "b"):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "dec" / f"{name}.png")),
+                              np.asarray(Image.open(out / "recon" / f"{name}.png"))), name
 
 
 def test_z_only_harness_forward(full_model):

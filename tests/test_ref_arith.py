@@ -135,7 +135,7 @@ def test_reference_made_768_streams_decode_in_the_reference_arithmetic(eight_thr
     yb, _ = codec.decompress([g["stream"].tobytes()] * 3, idx.repeat(3, 1, 1))
     assert all(torch.equal(yb.torch_nchw()[i], y_hat.torch_nchw()[0]) for i in range(3))
     # the MFMA prior on the same stream: desynchronises (the reason this path exists)
-    mfma = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV)
+    mfma = IntraNoAR(synth.codec_state_dict(0, preset=preset), DEV, prior_arith="mfma")
     mfma.update(force=True)
     with pytest.raises(StreamDesyncError):
         mfma.decompress([g["stream"].tobytes()], idx)
@@ -222,6 +222,45 @@ def test_model_decodes_container_files_of_both_producers_in_one_batch(eight_thre
     for b, f in enumerate(files):
         alone = model.decode(stream=[f], unit_range=True)
         assert torch.equal(alone[0], batch[b]), b
+
+
+@pytest.mark.gpu
+def test_cli_decodes_a_reference_made_container_with_the_default_config(eight_threads, tmp_path):
+    """`python -m onedc_amd.inference --decoder_only` on a container whose y stream THE REFERENCE wrote (tests/golden/g9: 768x768,
+    trained-like weights, torch-CPU fp32 at 8 threads; wrapped by the reference's own container format, utils.py:95-105), with a
+    config file that names NO prior_arith: the default ("auto") decodes it -- the MFMA prior desynchronises, the reference's
+    arithmetic takes over (codec_module.py:418-454 is what the file was made for) -- to the picture the explicit compatibility
+    mode decodes it to."""
+    import yaml
+    from PIL import Image
+    from safetensors.torch import save_file
+    from onedc_amd import inference
+    from onedc_amd.entropy.utils import encode_i, pack_indices
+    from onedc_amd.model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
+    g = golden("g9_ref_stream_768_trained.npz")
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    save_file(synth.unet_state_dict(0, preset="trained_like"), str(ckpt / "model.safetensors"))
+    save_file(synth.codec_state_dict(0, preset="trained_like"), str(ckpt / "model_1.safetensors"))
+    save_file(synth.vae_state_dict(0, preset="trained_like"), str(ckpt / "vae.safetensors"))
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump({"vae_attn_patch": 16, "conditioning_timestep": 999}))
+    (tmp_path / "ref.bin").write_bytes(encode_i(768, 768, g["stream"].tobytes(), pack_indices(g["indices"].reshape(-1), 14), b"", 0))
+    inference.main(["--config_path", str(tmp_path / "cfg.yaml"), "--checkpoint_path", str(ckpt), "--vae_path", str(ckpt / "vae.safetensors"),
+                    "--decoder_only", "--decoder_bin_path", str(tmp_path / "ref.bin"), "--decoder_out_path", str(tmp_path / "ref.png")])
+    got = np.asarray(Image.open(tmp_path / "ref.png"))
+    assert got.shape == (768, 768, 3)
+    explicit = SD15_1step_codec_stage1({"vae_attn_patch": 16, "prior_arith": "torch_cpu", "ref_threads": 8},
+                                       device="cuda:0").load_synthetic(0, preset="trained_like")
+    explicit.codec_model.update(force=True)
+    want = explicit.decode(fp=str(tmp_path / "ref.bin"), out="u8")[0].cpu().numpy()
+    assert np.array_equal(got, want)
+    # the default really is "auto", and the MFMA prior alone refuses this file
+    from onedc_amd.codec_module import StreamDesyncError
+    assert SD15_1step_codec_stage1({"vae_attn_patch": 16}, device="cuda:0").load_synthetic(0, preset="trained_like").codec_model.prior_arith == "auto"
+    mfma = SD15_1step_codec_stage1({"vae_attn_patch": 16, "prior_arith": "mfma"}, device="cuda:0").load_synthetic(0, preset="trained_like")
+    mfma.codec_model.update(force=True)
+    with pytest.raises(StreamDesyncError):
+        mfma.decode(fp=str(tmp_path / "ref.bin"))
 
 
 @pytest.mark.gpu

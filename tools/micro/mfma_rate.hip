@@ -11,6 +11,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int ITER = 2048, NACC = 16;
 
@@ -39,6 +41,13 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, int seed) {
                 const long la = ((long)a8[1] << 32) | (unsigned)a8[0], lb = ((long)b8[1] << 32) | (unsigned)b8[0];
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, acc[i], 0, 0, 0);
             }
+            if (MODE == 4)   // the k = 16 forms of CDNA1-3 (half the K of the gfx950 forms): do they take half the cycles?
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, s16x4{a16[0], a16[1], a16[2], a16[3]}),
+                                                               __builtin_bit_cast(h16x4, s16x4{b16[0], b16[1], b16[2], b16[3]}),
+                                                               acc[i], 0, 0, 0);
+            if (MODE == 5)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{a16[0], a16[1], a16[2], a16[3]},
+                                                                   s16x4{b16[0], b16[1], b16[2], b16[3]}, acc[i], 0, 0, 0);
             if (MODE == 3)   // block-scaled, both operands e4m3 (cbsz = blgp = 0), scales 2^0 (E8M0 127)
                 acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
@@ -77,6 +86,8 @@ int main() {
     const double h = run<1>("v_mfma_f32_16x16x32_f16", 2.0 * 16 * 16 * 32, out);
     const double f = run<2>("v_mfma_f32_16x16x32_fp8_fp8 (not scaled)", 2.0 * 16 * 16 * 32, out);
     const double m = run<3>("v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3)", 2.0 * 16 * 16 * 128, out);
-    printf("ratios to bf16: f16 %.3f, fp8 %.3f, MXFP8 %.3f\n", h / b, f / b, m / b);
+    const double l = run<4>("v_mfma_f32_16x16x16_f16 (k = 16 form)", 2.0 * 16 * 16 * 16, out);
+    const double lb = run<5>("v_mfma_f32_16x16x16_bf16 (k = 16 form)", 2.0 * 16 * 16 * 16, out);
+    printf("ratios to bf16: f16 %.3f, fp8 %.3f, MXFP8 %.3f, f16 k=16 %.3f, bf16 k=16 %.3f\n", h / b, f / b, m / b, l / b, lb / b);
     return 0;
 }

@@ -31,9 +31,15 @@ def wrapped(x, w, bias, y, **kw):
     r = orig(x, w, bias, y, **kw)
     e1.record()
     cout = kw.get("Cout") or y.C
-    rec.append(((kw.get("KH", 1), x.H, kw.get("Cin") or x.C, cout, kw.get("epi", 0), kw.get("batch", 1),
-                 "res" if kw.get("res") is not None else ""), e0, e1,
-                2.0 * x.B * y.H * y.W * cout * kw.get("KH", 1) ** 2 * (kw.get("Cin") or x.C) * max(1, kw.get("batch", 1))))
+    cin, up = kw.get("Cin") or x.C, kw.get("up", 0)
+    # rows are keyed by the OUTPUT map (a stride-2 or upsampling layer is not the layer of its input size), FLOPs are the
+    # EXECUTED ones: the phase-decomposed upsample conv (up == 2) runs 4 taps per output, not the reference's 9
+    taps = 4 if up == 2 else kw.get("KH", 1) ** 2
+    cin2 = kw["x2"].C if kw.get("x2") is not None else 0
+    tag = ("res" if kw.get("res") is not None else "") + (f" up{up}" if up else "") + (f" +1x1 {cin2}" if cin2 else "") + \
+        (f" s{kw['stride']}" if kw.get("stride", 1) != 1 else "")
+    rec.append(((kw.get("KH", 1), y.H, cin, cout, kw.get("epi", 0), kw.get("batch", 1), tag), e0, e1,
+                2.0 * x.B * y.H * y.W * cout * (taps * cin + cin2) * max(1, kw.get("batch", 1))))
     return r
 
 
@@ -50,5 +56,5 @@ for key, e0, e1, fl in rec:
     d[2] += fl
 tot = sum(v[1] for v in agg.values())
 print(f"conv launches {len(rec)}, {tot:.2f} ms")
-for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
-    print(f"k{key[0]} {key[1]:3d}x{key[1]:<3d} {key[2]:5d}->{key[3]:<5d} epi{key[4]} batch{key[5]:<3d} {key[6]:3s} x{n:3d} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF")
+for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+    print(f"k{key[0]} out {key[1]:3d}x{key[1]:<3d} {key[2]:5d}->{key[3]:<5d} epi{key[4]} batch{key[5]:<3d} {key[6]:14s} x{n:3d} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF executed")
