@@ -518,13 +518,13 @@ def main():
     side = None
     if rank == 0 and world == 1 and not args.no_extras and mode == "decode" and not args.sequential:
         other = "random_init" if args.weights == "trained_like" else "trained_like"
-        m2 = SD15_1step_codec_stage1(model_cfg, device=device).load_state_dicts(*synthetic_weights(other))
+        m2 = SD15_1step_codec_stage1(model_cfg, device=model.device).load_state_dicts(*synthetic_weights(other))
         m2.codec_model.update(force=True)
         blobs2, _ = m2.codec_model.encode_latents(idx, None, noise_seed=2 + rank)
         pipe2 = m2.pipeline(s_streams=args.s_streams, serialise_vae=not args.free_vae)
         try:
-            k2 = max(2, min(args.steps, 8))
-            pipe2.map([blobs2] * 2)
+            k2 = args.steps
+            pipe2.map([blobs2] * max(2, args.warmup))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pipe2.map([blobs2] * k2)
@@ -534,7 +534,7 @@ def main():
             pipe2.close()
         side = {"weights": other, "value": round(B * k2 / dt2, 3), "unit": "images/s", "steps": k2,
                 "ms_per_step": round(dt2 / k2 * 1e3, 3), "stream_bytes_per_image": sum(len(b) for b in blobs2) // B,
-                "how": "same bench, the other synthetic operating point (own model, own pipeline), fewer steps, no per-launch events"}
+                "how": "same bench, the other synthetic operating point (own model, own pipeline), same K steps, no per-launch events"}
         del m2, pipe2, blobs2
         torch.cuda.empty_cache()
 

@@ -129,7 +129,9 @@ enum {
     ONEDC_KERNEL_F32_64X128 = 9,   /* conv_gemm_kernel<Tile<64,128>, f32>: the same for grids of less than two rounds */
     ONEDC_KERNEL_WIN3X3_4W = 10,   /* conv_win4_kernel: the window kernel as 4-wave workgroups, two per CU */
     ONEDC_KERNEL_UPS2X2_4W = 11,   /* conv_win4_kernel<2>: the upsample phases on the same 4-wave machinery */
-    ONEDC_KERNEL_SPLITK_256 = 12   /* conv_gemm256_kernel over K ranges + splitk_reduce_kernel (onedc_conv_params.split_k) */
+    ONEDC_KERNEL_SPLITK_256 = 12,  /* conv_gemm256_kernel over K ranges + splitk_reduce_kernel (onedc_conv_params.split_k) */
+    ONEDC_KERNEL_LIN_64X128 = 13,  /* conv_lin_kernel<Tile<64,128>>: 1x1 layers, 32-channel K-steps, four-stage LDS ring */
+    ONEDC_KERNEL_LIN_128X128 = 14  /* conv_lin_kernel<Tile<128,128>> */
 };
 int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
 const char *onedc_conv_kernel_name(int kernel_id);

@@ -132,7 +132,7 @@ struct ConvPixSrc {
 // XCD) -- measured HBM reads of the 256-tile kernel were 4.6x the input bytes.  With patch16 the tile is a
 // 16 x 16 patch: its nine taps touch one 18 x 18 window (1.27x the patch), and tiles that follow each other
 // on an XCD are neighbouring patches.  Needs OH, OW multiples of 16.
-__device__ __forceinline__ bool conv_is_linear(const onedc_conv_params &p) {      // wave-uniform (kernel arguments only)
+__host__ __device__ __forceinline__ bool conv_is_linear(const onedc_conv_params &p) {      // wave-uniform (kernel arguments only)
     return p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && !p.up && p.IH == p.OH && p.IW == p.OW;
 }
 

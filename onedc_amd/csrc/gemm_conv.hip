@@ -236,6 +236,168 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     }
 }
 
+// ---- 1x1 layers: the same tiles on a deeper pipeline ------------------------------------------------------------------------
+// The UNet's Linear / 1x1 layers (decoder_unet.py:204-293: to_q|k, to_out, GEGLU, ff.net.2, proj_in / proj_out; K = 320 ... 5120)
+// are short-K GEMMs whose time is the L2 -> LDS stream: conv_gemm_kernel above keeps ONE 64-channel K-step in flight and
+// drains it (vmcnt(0)) before every barrier, so a K-step costs a full L2 round trip however little there is to multiply
+// (round 3: 128 x 128 tiles at 370 - 620 TFLOP/s, 9 - 10 TB/s of LDS-DMA against the 17 - 19 TB/s the L2 serves to gathers).
+// Here a K-step is 32 channels -- one MFMA k step; an LDS row is 64 B, a fragment read covers 1 KB of consecutive bytes, no
+// swizzle -- and the ring has FOUR stages: three K-steps are in flight while one multiplies, one counted vmcnt and one barrier
+// per step.  Same LDS footprint (64 KB / 48 KB), same wave tiles, same k order as the 64-channel kernel: the accumulators
+// see the same MFMA sequence, so outputs and epilogue statistics are bit-identical to conv_gemm_kernel's.
+// Input through a buffer descriptor (tail rows read zeros): the dispatcher keeps tensors of 4 GB and more on the old kernel.
+template <class T>
+__global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_params p, int tiles_n, int tiles_m, int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TN = T::TN, TM = T::TM;
+    constexpr int STAGE = (TN + TM) * 64;          // bytes per K-step: 32 channels of every row
+    constexpr int NSTAGE = 4;
+    constexpr int WB = TN / 16, PB = TM / 16;      // 16-row DMA blocks of weights / pixels
+    constexpr int NBLK = WB + PB, NI = NBLK / 4;   // DMA instructions per wave and stage
+    static_assert(NBLK % 4 == 0, "blocks divide over the four waves");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % T::WN, wm = wave / T::WN;
+
+    const int logical = xcd_logical_tile(blockIdx.x, tiles_n * tiles_m);
+    const int n0 = (logical % tiles_n) * TN;
+    const int m0 = (logical / tiles_n) * TM;
+
+    const char *xb = (const char *)p.x + (int64_t)blockIdx.z * p.x_bs * 2;
+    const char *wb = (const char *)p.w + (int64_t)blockIdx.z * p.w_bs * 2;
+    const int K = p.Cin;                            // 1x1: k = input channel
+    const int steps = K >> 5;
+    // lane l of a DMA instruction moves granule (l & 3) of row (l >> 2) of a 16-row block
+    const int drow = lane >> 2, dg = lane & 3;
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wb, (unsigned)((int64_t)tiles_n * TN * K * 2));
+    const int64_t x_total = (int64_t)M * p.x_cs * 2;
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(xb, (unsigned)x_total);           // (< 4 GB: conv_lin_ok)
+    unsigned voff[NI];
+    bool is_w[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int blk = wave + 4 * i;               // wave-uniform
+        is_w[i] = blk < WB;
+        if (blk < WB) {
+            voff[i] = (unsigned)((n0 + blk * 16 + drow) * K * 2) + dg * 16;
+        } else {
+            const int m = m0 + (blk - WB) * 16 + drow;
+            voff[i] = m < M ? (unsigned)(m * p.x_cs + p.x_co) * 2u + dg * 16 : 0xfffffff0u;       // out of range: zeros
+        }
+    }
+    auto issue = [&](int s) {
+        char *dst = smem + (s & (NSTAGE - 1)) * STAGE + lane * 0;
+        const unsigned so = (unsigned)s * 64;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int blk = wave + 4 * i;
+            if (is_w[i]) glds16_buf(w_rsrc, voff[i], so, dst + blk * 1024);
+            else glds16_buf(x_rsrc, voff[i], so, dst + blk * 1024);
+        }
+    };
+    issue(0);
+    if (steps > 1) issue(1);
+    if (steps > 2) issue(2);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[T::FI][T::FJ];
+#pragma unroll
+    for (int i = 0; i < T::FI; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    int fa_off = (wn * T::WTN + frow) * 64 + fq * 16;
+    int fb_off = (TN + wm * T::WTM + frow) * 64 + fq * 16;
+    asm volatile("" : "+v"(fa_off), "+v"(fb_off));
+
+    for (int s = 0; s < steps; ++s) {
+        // K-step s has landed (this wave's part): what may still fly are the NI instructions of each younger step
+        if (s + 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        else if (s + 1 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // ... everywhere; and every wave is past its reads of step s - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < steps) issue(s + 3);            // into the stage of step s - 1
+        const char *cur = smem + (s & (NSTAGE - 1)) * STAGE;
+        a16x8 a[T::FI], b[T::FJ];
+#pragma unroll
+        for (int i = 0; i < T::FI; ++i) a[i] = *(const a16x8 *)(cur + fa_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < T::FJ; ++j) b[j] = *(const a16x8 *)(cur + fb_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < T::FI; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FJ; ++j) acc[i][j] = ONEDC_MFMA16(a[i], b[j], acc[i][j]);
+    }
+
+    // ---- epilogue: as conv_gemm_kernel ------------------------------------------------------------------------------------
+    const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
+    const int cout_store = glu ? p.Cout / 2 : p.Cout;
+    char *yb = (char *)p.y + (int64_t)blockIdx.z * p.y_bs * (p.out_f32 ? 4 : 2);
+    const char *rb = p.res ? (const char *)p.res + (int64_t)blockIdx.z * p.r_bs * 2 : nullptr;
+    const int nw = n0 + wn * T::WTN;
+    float ssum[T::FI], ssq[T::FI], ssum_hi[T::FI], ssq_hi[T::FI];
+    EpiBias bias[T::FI];
+#pragma unroll
+    for (int i = 0; i < T::FI; ++i) {
+        ssum[i] = ssq[i] = ssum_hi[i] = ssq_hi[i] = 0.f;
+        bias[i] = conv_epi_bias(p, glu, nw + i * 16, fq);
+    }
+    auto epilogue = [&](auto mode) {
+        typedef decltype(mode) EM;
+        EpiRes<false> res[T::FI][T::FJ];
+#pragma unroll
+        for (int j = 0; j < T::FJ; ++j) {
+            const int m = m0 + wm * T::WTM + j * 16 + frow;
+            const ConvOutPix op = conv_out_pix(p, m);
+#pragma unroll
+            for (int i = 0; i < T::FI; ++i) {
+                if (glu && (i & 1)) continue;
+                const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_load_res<false, EM>(p, rb, cout_store, e, res[i][j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T::FJ; ++j) {
+            const int m = m0 + wm * T::WTM + j * 16 + frow;
+            const ConvOutPix op = conv_out_pix(p, m);
+#pragma unroll
+            for (int i = 0; i < T::FI; ++i) {
+                if (glu && (i & 1)) continue;
+                const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
+                const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                conv_epi_finish<false, EM>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i],
+                                           ssq[i], ssum_hi[i], ssq_hi[i]);
+            }
+        }
+    };
+    ONEDC_EPI_DISPATCH(p, true, epilogue);
+    if (p.stats) {
+        static_assert(T::WTM == 64, "a wave covers one 64-pixel statistics block");
+#pragma unroll
+        for (int i = 0; i < T::FI; ++i) {
+            if (glu && (i & 1)) continue;
+            const int n_out = (glu ? (nw + i * 16) / 2 : nw + i * 16) + fq * 4;
+            conv_stats_store(p, ssum[i], ssq[i], m0 + wm * T::WTM, n_out, cout_store, lane, M, ssum_hi[i], ssq_hi[i]);
+        }
+    }
+}
+
+template <class T>
+int launch_lin(const onedc_conv_params &p, hipStream_t st) {
+    constexpr int LDS = 4 * (T::TN + T::TM) * 64;
+    static OnedcLdsAttrOnce once;
+    once.ensure({{(const void *)conv_lin_kernel<T>, LDS}});
+    const int M = (int)((int64_t)p.B * p.OH * p.OW);
+    const int tiles_n = (p.Cout + T::TN - 1) / T::TN;
+    const int tiles_m = (M + T::TM - 1) / T::TM;
+    dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
+    hipLaunchKernelGGL((conv_lin_kernel<T>), grid, dim3(256), LDS, st, p, tiles_n, tiles_m, M);
+    ONEDC_LAUNCH_CHECK();
+    return 0;
+}
+
 template <class T, bool F32 = false>
 int launch(const onedc_conv_params &p, hipStream_t st) {
     static OnedcLdsAttrOnce once;
@@ -329,6 +491,13 @@ extern "C" int64_t onedc_conv_splitk_ws_bytes(const onedc_conv_params *pp) {
     return parts ? onedc_conv_splitk_bytes(*pp, parts) : 0;
 }
 
+// conv_lin_kernel: 1x1 / stride 1 layers on 16-bit operands whose input and weights a 32-bit buffer offset reaches
+static bool conv_lin_ok(const onedc_conv_params &p) {
+    const int64_t M = (int64_t)p.B * p.OH * p.OW;
+    return conv_is_linear(p) && !p.in_f32 && !p.gn_ab && !p.x2 && M * p.x_cs * 2 < 0xfff00000ll &&
+           (int64_t)((p.Cout + 127) / 128 * 128) * p.Cin * 2 < 0xfff00000ll && M < 0x7fffffff;
+}
+
 static int conv_choose(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     {
@@ -387,9 +556,12 @@ static int conv_choose(const onedc_conv_params &p) {
     // 64-row tiles: channel counts that leave <= 64 rows in the last 128-row tile, and grids of fewer than 256
     // 128x128 tiles (the 12x12 maps of the UNet: 180 tiles for 256 CUs)
     const int64_t blocks4w = (rows128 / 128) * ((M64 + 127) / 128) * (p.batch > 1 ? p.batch : 1);
+    // 1x1 layers of both 4-wave tile shapes run on the 32-channel / four-stage pipeline (conv_lin_kernel: same tiles, same k
+    // order, same bits); tile 128 keeps the 64-channel kernel (tests, A/B)
+    const bool lin = conv_lin_ok(p) && p.tile != 128;
     if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))
-        return ONEDC_KERNEL_64X128;
-    return ONEDC_KERNEL_128X128;
+        return lin ? ONEDC_KERNEL_LIN_64X128 : ONEDC_KERNEL_64X128;
+    return lin ? ONEDC_KERNEL_LIN_128X128 : ONEDC_KERNEL_128X128;
 }
 
 extern "C" int onedc_conv_gemm_kernel_id(const onedc_conv_params *pp) {
@@ -413,6 +585,8 @@ extern "C" const char *onedc_conv_kernel_name(int id) {
         case ONEDC_KERNEL_WIN3X3_4W: return "win3x3_4w";
         case ONEDC_KERNEL_UPS2X2_4W: return "ups2x2_4w";
         case ONEDC_KERNEL_SPLITK_256: return "splitk_256";
+        case ONEDC_KERNEL_LIN_64X128: return "lin_64x128";
+        case ONEDC_KERNEL_LIN_128X128: return "lin_128x128";
         default: return "?";
     }
 }
@@ -435,6 +609,8 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         case ONEDC_KERNEL_16X256: return launch<Tile<16, 256, 1, 4>>(p, st);
         case ONEDC_KERNEL_64X128: return launch<Tile<64, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_128X128: return launch<Tile<128, 128, 2, 2>>(p, st);
+        case ONEDC_KERNEL_LIN_64X128: return launch_lin<Tile<64, 128, 2, 2>>(p, st);
+        case ONEDC_KERNEL_LIN_128X128: return launch_lin<Tile<128, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_F32_128X128: return launch<Tile<128, 128, 2, 2>, true>(p, st);
         case ONEDC_KERNEL_F32_64X128: return launch<Tile<64, 128, 2, 2>, true>(p, st);
 #ifdef EXP_TILES

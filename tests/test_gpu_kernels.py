@@ -1185,3 +1185,72 @@ def test_conv_win4_second_source_race_screen_and_refusal():
     y.t.fill_(7.0)
     assert K.conv_gemm(from_nchw(h[:1, :, :12, :12].to(DEV)), wp, None, y, KH=3, x2=from_nchw(x2[:1, :, :12, :12].to(DEV)), w2=w2p) is None
     assert float((y.t[:144 * Cout].float() - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,epi,res,stats", [
+    (2, 24, 24, 320, 320, "linear", True, True),       # proj_out: residual + statistics (pairs: 320 channels), 64-row tail tile
+    (1, 20, 20, 320, 2560, "geglu", False, False),     # ff.net.0 (GEGLU pairs), ragged M (400 pixels)
+    (3, 8, 8, 1280, 640, "linear", True, False),       # long K
+    (1, 16, 16, 64, 128, "silu", False, True),         # two K-steps: shorter than the ring
+    (2, 12, 12, 384, 320, "linear", True, False),      # attention out-projection (padded heads), 12 K-steps
+    (1, 9, 7, 96 + 32, 128, "leaky", False, False),    # 63 pixels: one partial tile
+])
+def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, res, stats):
+    """1x1 layers on conv_lin_kernel (32-channel K-steps, four-stage ring; the automatic choice) against F.conv2d and, BIT
+    FOR BIT -- outputs and the GroupNorm statistics of the epilogue -- against conv_gemm_kernel (tile=128): same tiles, same k
+    order.  The layers are the UNet's Linear / 1x1 convs (decoder_unet.py:204-293)."""
+    glu = epi == "geglu"
+    x, w, b = rnd(B, Cin, H, W, seed=441), rnd(Cout, Cin, 1, 1, seed=442, scale=Cin ** -0.5), rnd(Cout, seed=443)
+    cstore = Cout // 2 if glu else Cout
+    r = rnd(B, cstore, H, W, seed=444) if res else None
+    perm = pack.glu_perm(Cout // 2) if glu else None
+    xv, wp = from_nchw(x.to(DEV)), packed(w, perm)
+    bd = (b[perm] if glu else b).to(DEV)
+    rv = from_nchw(r.to(DEV)) if res else None
+    code = {"linear": K.EPI_LINEAR, "geglu": K.EPI_GEGLU, "silu": K.EPI_SILU, "leaky": K.EPI_LEAKY}[epi]
+    outs = []
+    for tile in (0, 128):
+        y = new_view(B, H, W, cstore, DEV, stats=stats)
+        K.conv_gemm(xv, wp, bd, y, KH=1, epi=code, slope=0.1, res=rv, stats=stats, tile=tile)
+        outs.append((y.t[:B * H * W * cstore].clone(), y.stats.t.clone() if (stats and y.stats is not None) else None, y))
+    full = F.conv2d(x, w, b)
+    if glu:
+        a, g = full.chunk(2, 1)
+        ref = a * F.gelu(g)
+    else:
+        ref = {"linear": full, "silu": F.silu(full), "leaky": F.leaky_relu(full, 0.1)}[epi]
+    ref = ref + (r if res else 0)
+    close(outs[0][2].torch_nchw(), ref, what="conv_lin")
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_conv_lin_kernel_is_the_automatic_choice_and_batched():
+    """The dispatcher's answer for the 1x1 layers, and the batched form (blockIdx.z: V^T of the attention layers)."""
+    G, n, Cc = 5, 144, 128
+    q, k = rnd(G, n, Cc, seed=451), rnd(G, n, Cc, seed=452)
+    qd = torch.zeros(G * n + 128, Cc, dtype=K.a16(), device=DEV)
+    kd = torch.zeros(G * n + 128, Cc, dtype=K.a16(), device=DEV)
+    qd[:G * n] = q.view(-1, Cc).to(DEV)
+    kd[:G * n] = k.view(-1, Cc).to(DEV)
+    outs = []
+    for tile in (0, 128):
+        s = torch.empty(G * n * n, dtype=torch.float32, device=DEV)
+        K.conv_gemm(View(qd, 1, 1, n, Cc), kd, None, View(s, 1, 1, n, n), Cin=Cc, Cout=n, batch=G, x_bs=n * Cc,
+                    w_bs=n * Cc, y_bs=n * n, alpha=0.25, tile=tile)
+        outs.append(s)
+    close(outs[0].view(G, n, n), 0.25 * q @ k.transpose(1, 2), rms=1e-4, mx=1e-4, what="batched nt on conv_lin")
+    assert torch.equal(outs[0], outs[1])
+    x = new_view(16, 96, 96, 320, DEV)
+    y = new_view(16, 96, 96, 320, DEV)
+    p = K.ConvParams()
+    p.x, p.w, p.y, p.zeros = x.ptr, x.ptr, y.ptr, K.zeros_page(DEV).data_ptr()
+    p.B, p.IH, p.IW, p.Cin, p.x_cs, p.OH, p.OW, p.Cout, p.y_cs = 16, 96, 96, 320, 320, 96, 96, 320, 320
+    p.KH = p.KW = p.stride = 1
+    p.alpha = 1.0
+    assert K.conv_kernel_name(p) == "lin_64x128"
+    p.Cout = p.y_cs = 2560
+    assert K.conv_kernel_name(p) == "lin_128x128"
+    p.tile = 128
+    assert K.conv_kernel_name(p) == "128x128"

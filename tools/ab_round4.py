@@ -66,6 +66,29 @@ def main():
         fl = 2.0 * B * H * H * Cout * 9 * Cin
         print(f"3x3 {Cin}->{Cout} res={int(res)}: split {t['split'] * 1e3:7.1f} us {fl / t['split'] / 1e9:7.1f} TF   unsplit "
               f"{t['unsplit'] * 1e3:7.1f} us {fl / t['unsplit'] / 1e9:7.1f} TF   ratio {t['split'] / t['unsplit']:.3f}", flush=True)
+    print("== 1x1 layers: conv_lin_kernel (32-channel K-steps, four-stage ring) against conv_gemm_kernel (tile=128)")
+    for H, Cin, Cout, epi, res in ((96, 320, 2560, K.EPI_GEGLU, False), (96, 320, 1024, K.EPI_LINEAR, False), (96, 384, 320, K.EPI_LINEAR, True),
+                                   (96, 1280, 320, K.EPI_LINEAR, True), (96, 320, 320, K.EPI_LINEAR, True), (96, 320, 512, K.EPI_LINEAR, False),
+                                   (48, 640, 5120, K.EPI_GEGLU, False), (48, 2560, 640, K.EPI_LINEAR, True), (48, 768, 640, K.EPI_LINEAR, True),
+                                   (48, 640, 2048, K.EPI_LINEAR, False), (24, 1280, 1280, K.EPI_LINEAR, True), (24, 5120, 1280, K.EPI_LINEAR, True)):
+        B = 16
+        glu = epi == K.EPI_GEGLU
+        x = K.new_view(B, H, H, Cin, DEV)
+        x.t.normal_()
+        cs = Cout // 2 if glu else Cout
+        r = K.new_view(B, H, H, cs, DEV)
+        r.t.normal_()
+        w = pack.pack_matrix(torch.randn(Cout, Cin, generator=g, device=DEV) * Cin ** -0.5, DEV)
+        y = K.new_view(B, H, H, cs, DEV)
+        names = {}
+
+        def run(tile):
+            K.conv_gemm(x, w, None, y, KH=1, epi=epi, res=r if res else None, tile=tile)
+        t = timed({"lin": lambda: run(0), "old": lambda: run(128)}, 40)
+        fl = 2.0 * B * H * H * Cout * Cin
+        print(f"{H}^2 1x1 {Cin}->{Cout} epi{epi} res={int(res)}: new {t['lin'] * 1e3:7.1f} us {fl / t['lin'] / 1e9:7.1f} TF   old "
+              f"{t['old'] * 1e3:7.1f} us {fl / t['old'] / 1e9:7.1f} TF   ratio {t['lin'] / t['old']:.3f}", flush=True)
+        del x, r, y, w
     print("== conv_shortcut as a second source of conv2")
     for B, H, Cin, Cout, Cin2, gn in ((16, 768, 128, 128, 256, True), (16, 384, 256, 256, 512, False), (16, 96, 320, 320, 960, False),
                                       (16, 96, 320, 320, 640, False), (16, 48, 640, 640, 1920, False), (16, 48, 640, 640, 960, False)):

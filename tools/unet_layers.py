@@ -30,6 +30,8 @@ def wrapped(x, w, bias, y, **kw):
     e0.record()
     r = orig(x, w, bias, y, **kw)
     e1.record()
+    if r is None:                      # (a second source the dispatcher refused: nothing was launched)
+        return r
     cout = kw.get("Cout") or y.C
     cin, up = kw.get("Cin") or x.C, kw.get("up", 0)
     # rows are keyed by the OUTPUT map (a stride-2 or upsampling layer is not the layer of its input size), FLOPs are the
