@@ -71,7 +71,9 @@ typedef struct onedc_conv_params {
                                            128 = 4-wave kernels (128x128 / 64x128 / 16x256 tiles),
                                            256 = 8-wave 256x256 tile, 129 = 8-wave 128(ch)x256(px) tile,
                                            130 = 3x3 window kernel (16x16-pixel patches, stride 1, pad 1), 8 waves,
-                                           131 = the same layer on the 4-wave window kernel (two workgroups per CU) */
+                                           131 = the same layer on the 4-wave window kernel (two workgroups per CU),
+                                           132 = as 128 with the epilogue's scattered 8-byte stores instead of line stores,
+                                           133 = 4-wave tiles on conv_lin_kernel whatever K (1x1 layers) */
     int32_t stats_gran;                 /* channels per statistics entry: 4 (quads), or 2 (pairs) for buffers whose
                                            GroupNorm groups are not multiples of 4 channels (320, 960 channels) */
     int32_t patch16;                    /* set by onedc_conv_gemm (callers leave 0): pixel tiles are 16x16 patches */

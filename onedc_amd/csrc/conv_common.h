@@ -299,11 +299,13 @@ __device__ __forceinline__ EpiBias conv_epi_bias(const onedc_conv_params &p, boo
 
 // ssum / ssq: running sum and sum of squares of the four stored values (GroupNorm statistics of the
 // consumer, see conv_stats_store); untouched when the lane stores nothing.
+// to_line (fast 16-bit modes only): the four packed values go to (line0, line1) instead of to memory -- the caller collects a wave's
+// tile in LDS and stores whole lines (conv_line_store below)
 template <bool F32, class M = EpiGeneric>
 __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char *yb, bool glu, int cout_store,
                                                 const f32x4 &accv, const f32x4 &accg, const EpiBias &bias,
                                                 const EpiPos &e, const EpiRes<F32> &r, float &ssum, float &ssq,
-                                                float &ssum_hi, float &ssq_hi) {
+                                                float &ssum_hi, float &ssq_hi, bool to_line, uint32_t &line0, uint32_t &line1) {
     if (!e.store) return;
     float v[4];
     const float bv[4] = {bias.v.x, bias.v.y, bias.v.z, bias.v.w};
@@ -357,6 +359,10 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
 #endif
     if (M::fast) {
         if (F32) *(float4 *)((float *)yb + yo) = make_float4(v[0], v[1], v[2], v[3]);
+        else if (to_line) {
+            line0 = pack_a2(v[0], v[1]);
+            line1 = pack_a2(v[2], v[3]);
+        }
         else *(uint2 *)((a16_t *)yb + yo) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         return;
     }
@@ -380,6 +386,47 @@ __device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char
         } else {
             for (int k = 0; k < 4 && e.n_out + k < cout_store; ++k) yp[k] = f2a(v[k]);
         }
+    }
+}
+
+template <bool F32, class M = EpiGeneric>
+__device__ __forceinline__ void conv_epi_finish(const onedc_conv_params &p, char *yb, bool glu, int cout_store,
+                                                const f32x4 &accv, const f32x4 &accg, const EpiBias &bias,
+                                                const EpiPos &e, const EpiRes<F32> &r, float &ssum, float &ssq,
+                                                float &ssum_hi, float &ssq_hi) {
+    uint32_t u0 = 0, u1 = 0;
+    conv_epi_finish<F32, M>(p, yb, glu, cout_store, accv, accg, bias, e, r, ssum, ssq, ssum_hi, ssq_hi, false, u0, u1);
+}
+
+// ---- line stores of the 4-wave GEMM kernels ------------------------------------------------------------------------------
+// In accumulator layout a lane owns 4 channels of one pixel: a wave's 16 x 16 tile is one 8-byte store per lane, 16 segments
+// of 32 B, and a 64 x 64 wave tile is 16 such instructions -- the store path charges per instruction (DESIGN.md section 7:
+// ~290 cycles each when the four waves of a workgroup finish together), which on the UNet's short-K 1x1 layers is a large
+// part of a workgroup's life.  Here the wave's 16-bit outputs go through LDS once (wave-private region, written in
+// accumulator layout, read back pixel-major) and leave as 16-byte stores: CW stored channels per pixel = CW / 8 lanes per
+// pixel, 64 * CW / 512 instructions per wave (8 for 64 channels, 4 for 32) instead of 16 / 8.  Same values, same bits.
+// slot8: index of the lane's 8-byte group inside the pixel's CW * 2 bytes.
+template <int CW>
+__device__ __forceinline__ void conv_line_put(char *my, int px, int slot8, uint32_t v0, uint32_t v1) {
+    constexpr int LP = CW / 8;                     // 16-byte chunks (lanes) per pixel
+    typedef unsigned line_u32x2 __attribute__((ext_vector_type(2)));
+    *(__attribute__((address_space(3))) line_u32x2 *)((__attribute__((address_space(3))) char *)my + px * (CW * 2) +
+                                                      ((((slot8 >> 1) ^ px) & (LP - 1)) << 4) + (slot8 & 1) * 8) = line_u32x2{v0, v1};
+}
+// the wave's 64 pixels m_wave .. m_wave + 63 (those < M) x CW channels starting at element offset y_off of a pixel
+template <int CW>
+__device__ __forceinline__ void conv_line_store(const char *my, a16_t *yb, int64_t y_cs, int64_t y_off, int m_wave, int M,
+                                                int lane) {
+    constexpr int LP = CW / 8, PPI = 64 / LP;      // pixels per store instruction
+    typedef unsigned line_u32x4 __attribute__((ext_vector_type(4)));
+    const int c = lane & (LP - 1);
+#pragma unroll
+    for (int it = 0; it < LP; ++it) {
+        const int px = it * PPI + lane / LP;
+        const line_u32x4 o = *(const __attribute__((address_space(3))) line_u32x4 *)((const __attribute__((address_space(3))) char *)my +
+                                                                                      px * (CW * 2) + (((c ^ px) & (LP - 1)) << 4));
+        const int m = m_wave + px;
+        if (m < M) *(line_u32x4 *)(yb + (int64_t)m * y_cs + y_off + c * 8) = o;
     }
 }
 

@@ -20,6 +20,27 @@
 
 namespace {
 
+// Line stores of the 4-wave kernels' epilogue (conv_common.h: conv_line_put / conv_line_store), shared by conv_gemm_kernel
+// and conv_lin_kernel.  Taken when the epilogue mode is a fast 16-bit one, the wave tile is 64 pixels wide and every channel
+// of the wave exists and starts on a 16-byte boundary of the output pixel; wave-uniform.  The K loop's LDS is free behind a
+// barrier (the other waves may still be reading fragments of the last step).
+#define ONEDC_LINE_SETUP(F32_)                                                                                         \
+    constexpr int CWL = EM::glu ? T::WTN / 2 : T::WTN;         /* stored channels of a wave */                         \
+    const int n_store0 = EM::glu ? nw / 2 : nw;                                                                        \
+    const bool line = EM::fast && !(F32_) && T::WTM == 64 && CWL >= 16 && nw + T::WTN <= p.Cout &&                     \
+                      ((p.y_cs | (p.y_co + n_store0)) & 7) == 0 && p.tile != 132;                                      \
+    char *const my_line = smem + wave * (64 * CWL * 2);                                                                \
+    if (EM::fast && !(F32_)) __syncthreads();
+#define ONEDC_LINE_PUT()                                                                                               \
+    if constexpr (EM::fast && T::WTM == 64 && (EM::glu ? T::WTN / 2 : T::WTN) >= 16) {                                 \
+        if (line) conv_line_put<CWL>(my_line, j * 16 + frow, (EM::glu ? (i >> 1) : i) * 4 + fq, lv0, lv1);                   \
+    }
+#define ONEDC_LINE_STORE()                                                                                             \
+    if constexpr (EM::fast && T::WTM == 64 && (EM::glu ? T::WTN / 2 : T::WTN) >= 16) {                                 \
+        if (line)                                                                                                      \
+            conv_line_store<CWL>(my_line, (a16_t *)yb, p.y_cs, (int64_t)p.y_co + n_store0, m0 + wm * T::WTM, M, lane); \
+    }
+
 template <int TN_, int TM_, int WN_, int WM_>
 struct Tile {
     static constexpr int TN = TN_, TM = TM_, WN = WN_, WM = WM_;
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
     // pass 1: positions + residual loads of every tile; pass 2: finish + store
     auto epilogue = [&](auto mode) {
         typedef decltype(mode) EM;
+        ONEDC_LINE_SETUP(F32)
         EpiRes<F32> res[T::FI][T::FJ];
 #pragma unroll
         for (int j = 0; j < T::FJ; ++j) {
@@ -219,10 +241,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
                 if (glu && (i & 1)) continue;
                 const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
                 const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                uint32_t lv0 = 0, lv1 = 0;
                 conv_epi_finish<F32, EM>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i],
-                                         ssq[i], ssum_hi[i], ssq_hi[i]);
+                                         ssq[i], ssum_hi[i], ssq_hi[i], line, lv0, lv1);
+                ONEDC_LINE_PUT()
             }
         }
+        ONEDC_LINE_STORE()
     };
     ONEDC_EPI_DISPATCH(p, true, epilogue);
     if (p.stats) {                                 // wave-uniform
@@ -346,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_param
     }
     auto epilogue = [&](auto mode) {
         typedef decltype(mode) EM;
+        ONEDC_LINE_SETUP(false)
         EpiRes<false> res[T::FI][T::FJ];
 #pragma unroll
         for (int j = 0; j < T::FJ; ++j) {
@@ -367,10 +393,13 @@ __global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_param
                 if (glu && (i & 1)) continue;
                 const int i2 = (T::FI >= 2 && i + 1 < T::FI) ? i + 1 : i;
                 const EpiPos e = conv_epi_pos<EM>(p, glu, cout_store, nw + i * 16, fq, op, m < M);
+                uint32_t lv0 = 0, lv1 = 0;
                 conv_epi_finish<false, EM>(p, yb, glu, cout_store, acc[i][j], acc[i2][j], bias[i], e, res[i][j], ssum[i],
-                                           ssq[i], ssum_hi[i], ssq_hi[i]);
+                                           ssq[i], ssum_hi[i], ssq_hi[i], line, lv0, lv1);
+                ONEDC_LINE_PUT()
             }
         }
+        ONEDC_LINE_STORE()
     };
     ONEDC_EPI_DISPATCH(p, true, epilogue);
     if (p.stats) {
@@ -543,13 +572,13 @@ static int conv_choose(const onedc_conv_params &p) {
     // short K (< 16 K-tiles: 1x1 layers up to 960 channels): the 4-wave kernels win, two workgroups per CU hide each
     // other's prologue and epilogue (tools/bench_1x1.py); all three families give identical bits
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);
-    if (p.tile != 128 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 16) || p.tile == 256) &&
+    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 16) || p.tile == 256) &&
         !(p.stats && p.stats_gran == 2))           // the 256x256 kernel only leaves quad statistics
         return ONEDC_KERNEL_256X256;
     // 128 x 256 tiles (8 waves, 3-deep LDS ring): channel counts that are whole 128-row tiles or waste < 20 %
     const int rows128 = (p.Cout + 127) / 128 * 128;
     const int64_t blocks128 = (rows128 / 128) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
-    if (p.tile != 128 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
+    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
         ((blocks128 >= 160 && ktiles >= 16) || p.tile == 129))
         return ONEDC_KERNEL_128X256;
     if (p.Cout <= 16 && !glu) return ONEDC_KERNEL_16X256;
@@ -558,7 +587,9 @@ static int conv_choose(const onedc_conv_params &p) {
     const int64_t blocks4w = (rows128 / 128) * ((M64 + 127) / 128) * (p.batch > 1 ? p.batch : 1);
     // 1x1 layers of both 4-wave tile shapes run on the 32-channel / four-stage pipeline (conv_lin_kernel: same tiles, same k
     // order, same bits); tile 128 keeps the 64-channel kernel (tests, A/B)
-    const bool lin = conv_lin_ok(p) && p.tile != 128;
+    // (measured, tools/ab_round4.py: the deeper ring pays from K = 1280 on -- 5120 -> 1280 at 24x24 139 -> 119 us -- and costs
+    // 4 - 13 % on the short-K layers, whose time is prologue + epilogue, not the K loop)
+    const bool lin = conv_lin_ok(p) && p.tile != 128 && p.tile != 132 && (p.Cin >= 1280 || p.tile == 133);
     if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))
         return lin ? ONEDC_KERNEL_LIN_64X128 : ONEDC_KERNEL_64X128;
     return lin ? ONEDC_KERNEL_LIN_128X128 : ONEDC_KERNEL_128X128;

@@ -1209,7 +1209,7 @@ def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, r
     rv = from_nchw(r.to(DEV)) if res else None
     code = {"linear": K.EPI_LINEAR, "geglu": K.EPI_GEGLU, "silu": K.EPI_SILU, "leaky": K.EPI_LEAKY}[epi]
     outs = []
-    for tile in (0, 128):
+    for tile in (133, 128, 132, 0):           # the ring kernel, the 64-channel kernel, the same without line stores, automatic
         y = new_view(B, H, W, cstore, DEV, stats=stats)
         K.conv_gemm(xv, wp, bd, y, KH=1, epi=code, slope=0.1, res=rv, stats=stats, tile=tile)
         outs.append((y.t[:B * H * W * cstore].clone(), y.stats.t.clone() if (stats and y.stats is not None) else None, y))
@@ -1221,9 +1221,10 @@ def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, r
         ref = {"linear": full, "silu": F.silu(full), "leaky": F.leaky_relu(full, 0.1)}[epi]
     ref = ref + (r if res else 0)
     close(outs[0][2].torch_nchw(), ref, what="conv_lin")
-    assert torch.equal(outs[0][0], outs[1][0])
-    if outs[0][1] is not None:
-        assert torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0])
+        if outs[0][1] is not None:
+            assert torch.equal(outs[0][1], o[1])
 
 
 def test_conv_lin_kernel_is_the_automatic_choice_and_batched():
@@ -1235,22 +1236,26 @@ def test_conv_lin_kernel_is_the_automatic_choice_and_batched():
     qd[:G * n] = q.view(-1, Cc).to(DEV)
     kd[:G * n] = k.view(-1, Cc).to(DEV)
     outs = []
-    for tile in (0, 128):
+    for tile in (133, 128):
         s = torch.empty(G * n * n, dtype=torch.float32, device=DEV)
         K.conv_gemm(View(qd, 1, 1, n, Cc), kd, None, View(s, 1, 1, n, n), Cin=Cc, Cout=n, batch=G, x_bs=n * Cc,
                     w_bs=n * Cc, y_bs=n * n, alpha=0.25, tile=tile)
         outs.append(s)
     close(outs[0].view(G, n, n), 0.25 * q @ k.transpose(1, 2), rms=1e-4, mx=1e-4, what="batched nt on conv_lin")
     assert torch.equal(outs[0], outs[1])
-    x = new_view(16, 96, 96, 320, DEV)
-    y = new_view(16, 96, 96, 320, DEV)
+    # the dispatcher: the ring where a 1x1 layer with K >= 1280 lands on the 4-wave tiles (the UNet's 12x12 level: grids too
+    # small for the 8-wave kernels), the 64-channel kernel for short K (prologue + epilogue bound), tile 128 / 133 force either
+    x = new_view(16, 12, 12, 1280, DEV)
+    y = new_view(16, 12, 12, 1280, DEV)
     p = K.ConvParams()
     p.x, p.w, p.y, p.zeros = x.ptr, x.ptr, y.ptr, K.zeros_page(DEV).data_ptr()
-    p.B, p.IH, p.IW, p.Cin, p.x_cs, p.OH, p.OW, p.Cout, p.y_cs = 16, 96, 96, 320, 320, 96, 96, 320, 320
+    p.B, p.IH, p.IW, p.Cin, p.x_cs, p.OH, p.OW, p.Cout, p.y_cs = 16, 12, 12, 1280, 1280, 12, 12, 1280, 1280
     p.KH = p.KW = p.stride = 1
     p.alpha = 1.0
     assert K.conv_kernel_name(p) == "lin_64x128"
-    p.Cout = p.y_cs = 2560
-    assert K.conv_kernel_name(p) == "lin_128x128"
-    p.tile = 128
-    assert K.conv_kernel_name(p) == "128x128"
+    p.Cin = p.x_cs = 320
+    assert K.conv_kernel_name(p) == "64x128"
+    p.tile = 133
+    assert K.conv_kernel_name(p) == "lin_64x128"
+    p.tile, p.Cin, p.x_cs = 128, 1280, 1280
+    assert K.conv_kernel_name(p) == "64x128"

@@ -66,7 +66,7 @@ def main():
         fl = 2.0 * B * H * H * Cout * 9 * Cin
         print(f"3x3 {Cin}->{Cout} res={int(res)}: split {t['split'] * 1e3:7.1f} us {fl / t['split'] / 1e9:7.1f} TF   unsplit "
               f"{t['unsplit'] * 1e3:7.1f} us {fl / t['unsplit'] / 1e9:7.1f} TF   ratio {t['split'] / t['unsplit']:.3f}", flush=True)
-    print("== 1x1 layers: conv_lin_kernel (32-channel K-steps, four-stage ring) against conv_gemm_kernel (tile=128)")
+    print("== 1x1 layers on the 4-wave tiles: line stores (round 4) and the 32-channel four-stage ring against round 3's kernel")
     for H, Cin, Cout, epi, res in ((96, 320, 2560, K.EPI_GEGLU, False), (96, 320, 1024, K.EPI_LINEAR, False), (96, 384, 320, K.EPI_LINEAR, True),
                                    (96, 1280, 320, K.EPI_LINEAR, True), (96, 320, 320, K.EPI_LINEAR, True), (96, 320, 512, K.EPI_LINEAR, False),
                                    (48, 640, 5120, K.EPI_GEGLU, False), (48, 2560, 640, K.EPI_LINEAR, True), (48, 768, 640, K.EPI_LINEAR, True),
@@ -84,10 +84,11 @@ def main():
 
         def run(tile):
             K.conv_gemm(x, w, None, y, KH=1, epi=epi, res=r if res else None, tile=tile)
-        t = timed({"lin": lambda: run(0), "old": lambda: run(128)}, 40)
+        t = timed({"auto": lambda: run(0), "r3": lambda: run(132), "k64": lambda: run(128), "k32": lambda: run(133)}, 40)
         fl = 2.0 * B * H * H * Cout * Cin
-        print(f"{H}^2 1x1 {Cin}->{Cout} epi{epi} res={int(res)}: new {t['lin'] * 1e3:7.1f} us {fl / t['lin'] / 1e9:7.1f} TF   old "
-              f"{t['old'] * 1e3:7.1f} us {fl / t['old'] / 1e9:7.1f} TF   ratio {t['lin'] / t['old']:.3f}", flush=True)
+        print(f"{H}^2 1x1 {Cin}->{Cout} epi{epi} res={int(res)}: auto {t['auto'] * 1e3:7.1f} us {fl / t['auto'] / 1e9:7.1f} TF | round 3 (scattered "
+              f"stores) {t['r3'] * 1e3:7.1f} us | 64-ch steps + line stores {t['k64'] * 1e3:7.1f} | 32-ch ring + line stores {t['k32'] * 1e3:7.1f} | "
+              f"auto / round 3 {t['auto'] / t['r3']:.3f}", flush=True)
         del x, r, y, w
     print("== conv_shortcut as a second source of conv2")
     for B, H, Cin, Cout, Cin2, gn in ((16, 768, 128, 128, 256, True), (16, 384, 256, 256, 512, False), (16, 96, 320, 320, 960, False),
