@@ -279,6 +279,53 @@ def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, produ
                        f"{S}x{S} picture in {dt:.2f} s on {cores} of {os.cpu_count()} host threads"}, parity)
 
 
+def measure_kernel_clock(fmt, device, seconds=1.5):
+    """Shader clock the chip holds INSIDE the K loop of the dominant kernel (conv_win4_kernel, 128 -> 128 at 768x768, B = 16: its
+    most frequent shape), MI355X_MICROARCH.md 'DVFS give-back' item 6: the diagnostic build of the library (build.build_probe:
+    gemm_conv_win4.hip with -DEXP_W4_TIMELINE; no stamp executes in the product library) stamps s_memtime / s_memrealtime around
+    the loop of every workgroup; clock = delta s_memtime / delta s_memrealtime x 100 MHz, median over the workgroups of the last
+    launch after `seconds` of back-to-back launches on random data.  None when the diagnostic library is not built."""
+    import ctypes
+    from onedc_amd import build, pack
+    from onedc_amd import kernels as K
+    if fmt != "f16" or not os.path.exists(build.PROBE_F16_SO):
+        return None
+    probe = K.attach_signatures(ctypes.CDLL(build.PROBE_F16_SO))
+    base = K.lib(fmt)
+    Bc, H, C = 16, 768, 128
+    g = torch.Generator(device=device).manual_seed(0)
+    with K.act_format(fmt):
+        x = K.new_view(Bc, H, H, C, device)
+        x.t.copy_(torch.randn(x.t.numel(), generator=g, device=device).to(K.a16()))
+        w = pack.pack_matrix(torch.randn(C, 9 * C, generator=g, device=device) * (9 * C) ** -0.5, device)
+        y = K.new_view(Bc, H, H, C, device)
+        blocks = (H // 16) * (H // 16) * Bc
+        dbg = torch.zeros(blocks * 4 * 16, dtype=torch.int64, device=device)
+
+        class _Dbg:                       # the diagnostic kernel writes its stamps where the statistics would go
+            t, gran = dbg, 4
+
+            def mark(self, *a):
+                pass
+        y.stats = _Dbg()
+        K._libs[fmt] = probe
+        try:
+            t_end, n = time.time() + seconds, 0
+            while time.time() < t_end:
+                for _ in range(20):
+                    K.conv_gemm(x, w, None, y, KH=3, tile=131, stats=True)
+                torch.cuda.synchronize()
+                n += 20
+        finally:
+            K._libs[fmt] = base
+    d = dbg.view(blocks, 4, 16).cpu().numpy().astype(np.int64)
+    clk = (d[:, :, 3] - d[:, :, 2]) / np.maximum(d[:, :, 6] - d[:, :, 5], 1) * 0.1          # GHz
+    return {"ghz": round(float(np.median(clk)), 3), "p10": round(float(np.percentile(clk, 10)), 3),
+            "p90": round(float(np.percentile(clk, 90)), 3), "launches": n,
+            "how": "delta s_memtime / delta s_memrealtime around the K loop of every workgroup of conv_win4_kernel (128 -> 128 at "
+                   f"768x768, B = 16) in the diagnostic build of the library, after {seconds} s of back-to-back launches on random data"}
+
+
 def step_stats(marks, pipelined):
     """marks: completion times (ms from the start of the timed region) of the K batches -> interval statistics."""
     if not marks:
@@ -511,6 +558,12 @@ def main():
     rans_t = None
     if rank == 0 and not args.no_extras and mode == "decode":
         rans_t = host_rans_timing(model, blobs[0])
+    clock = None
+    if rank == 0 and not args.no_extras:
+        try:
+            clock = measure_kernel_clock(model.act, model.device)
+        except Exception as ex:                                # noqa: BLE001 -- a diagnostic must not cost the bench line
+            clock = {"ghz": None, "how": f"not measured ({type(ex).__name__}: {ex})"}
 
     # Side line: the same decode at the OTHER synthetic operating point (rounds 1-3 quoted random_init: 124 KB streams).
     # Same kernels, same shapes; what changes is the host rANS share (symbols per stream, escapes) and the operand statistics
@@ -571,7 +624,7 @@ def main():
         # separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) and committed under
         # profiles/; PMC passes serialise every dispatch, so they cannot run inside the timed region.
         traffic = None
-        for name in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if mode == "decode" and os.path.exists(tpath):
                 t = json.load(open(tpath)).get(kernel_symbol)
@@ -579,7 +632,9 @@ def main():
                     traffic = t["hbm_bytes_per_launch"]
                     break
         mfma_util = None
-        upath = os.path.join(ROOT, "profiles", "r3_pmc_mfma.json")
+        upath = os.path.join(ROOT, "profiles", "r4_pmc_mfma.json")
+        if not os.path.exists(upath):
+            upath = os.path.join(ROOT, "profiles", "r3_pmc_mfma.json")
         if mode == "decode" and os.path.exists(upath):
             u = json.load(open(upath)).get(kernel_symbol)
             mfma_util = u and u["mfma_util"]
@@ -652,6 +707,12 @@ def main():
                                "how": "the same K steps in the same barrier / synchronize bracket, the other output hand-off"}
         if device:
             line["device"] = device
+        if clock:
+            line["roofline"]["clock_ghz"] = clock["ghz"]
+            line["roofline"]["clock"] = clock
+            if clock["ghz"]:
+                line["roofline"]["peak_at_clock"] = round(PEAK_MFMA16_TFLOPS * clock["ghz"] / 2.4, 1)
+                line["roofline"]["frac_of_peak_at_clock"] = round(achieved / (PEAK_MFMA16_TFLOPS * clock["ghz"] / 2.4), 4)
         if rans_t:
             line["host_rans"] = rans_t
         if side:

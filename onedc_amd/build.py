@@ -146,6 +146,28 @@ def build_hip(force=False, extra_flags=()):
     return _native.HIP_SO
 
 
+PROBE_F16_SO = os.path.join(_native.CSRC, "libonedc_probe_f16.so")
+
+
+def build_probe(force=False):
+    """The diagnostic twin of libonedc_hip_f16.so: the same objects with gemm_conv_win4.hip compiled -DEXP_W4_TIMELINE (every
+    workgroup of the 4-wave window kernel stamps s_memtime / s_memrealtime around its K loop into the buffer passed as
+    `stats`).  bench.py measures the shader clock the chip holds inside the dominant kernel with it (`roofline.clock_ghz`,
+    MI355X_MICROARCH.md 'DVFS give-back' item 6: a separate build, no stamp executes in the product library).  Never loaded
+    by the product path."""
+    src = os.path.join(_native.CSRC, "gemm_conv_win4.hip")
+    headers = glob.glob(os.path.join(_native.CSRC, "*.h")) + [os.path.join(ROOT, "include", "onedc_hip.h"), os.path.abspath(__file__)]
+    obj = os.path.join(_native.CSRC, "gemm_conv_win4.probe.f16.o")
+    others = [s[:-4] + ".f16.o" for s in hip_sources() if os.path.basename(s) != "gemm_conv_win4.hip"]
+    if force or _stale(obj, [src] + headers):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-result",
+              *FILE_FLAGS.get("gemm_conv_win4.hip", ()), "-DONEDC_ACT_F16", "-DEXP_W4_TIMELINE", "-o", obj, src])
+    if force or _stale(PROBE_F16_SO, [obj] + others):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_F16_SO, obj, *others])
+    print(f"[build] {os.path.relpath(PROBE_F16_SO, ROOT)}: diagnostic build (clock probe)", flush=True)
+    return PROBE_F16_SO
+
+
 def build_oracle():
     _run(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
 
@@ -153,6 +175,7 @@ def build_oracle():
 def build_all(force=False):
     build_coder(force)
     build_hip(force)
+    build_probe(force)
     build_oracle()
 
 

@@ -10,6 +10,8 @@ synthesis 1.0e-3, vae_reduction 3.5e-4, UNet eps 1.5e-3, VAE decoder 1.5e-3, VAE
 end-to-end 67.8 dB), the bf16 bounds the round-1 ones.
 Integer/byte results (symbols, bitstreams, round trips) are checked bit-exactly.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -499,6 +501,25 @@ def test_cli_harness_encode_decode_and_decoder_only(tmp_path):
     for name in ("a", "b"):
         assert np.array_equal(np.asarray(Image.open(tmp_path / "dec" / f"{name}.png")),
                               np.asarray(Image.open(out / "recon" / f"{name}.png"))), name
+    # tools/first_contact.py on the same checkpoint files: strict contract, weight magnitudes, one picture in f16 and bf16
+    # with the stored abs-max of every layer, PSNR between the two, a recommendation (what one runs the day real weights exist)
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("first_contact", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "first_contact.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    rc = fc.main(["--checkpoint_path", str(ckpt), "--vae_path", str(ckpt / "vae.safetensors"), "--config_path", str(tmp_path / "cfg.yaml"),
+                  "--bin", str(out / "stream" / "b.bin"), "--out", str(tmp_path / "report.json")])
+    rep = json.loads((tmp_path / "report.json").read_text())
+    assert rc == 0 and rep["strict_load"] == "ok" and rep["lora_tensors_present"] and rep["weights"]["vae"]["fits_half"]
+    assert rep["decode"]["f16"]["conv_launches"] > 300 and not rep["decode"]["f16"]["nonfinite_pictures"]
+    assert rep["decode"]["f16"]["stages"]["x0"]["finite"] and rep["psnr_f16_vs_bf16_db"] > 35.0
+    assert rep["recommendation"]["act_dtype"] in ("f16", "bf16") and rep["stream"]["bytes"] == (out / "stream" / "b.bin").stat().st_size
+    # a file that breaks the contract is reported, not loaded
+    bad = dict(codec_full)
+    bad.pop("dec.conv_out.weight", None) if "dec.conv_out.weight" in bad else bad.pop(sorted(bad)[0])
+    save_file(bad, str(ckpt / "model_1.safetensors"))
+    assert fc.main(["--checkpoint_path", str(ckpt), "--vae_path", str(ckpt / "vae.safetensors"), "--cpu-only"]) == 1
 
 
 def test_z_only_harness_forward(full_model):
