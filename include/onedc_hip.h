@@ -73,7 +73,9 @@ typedef struct onedc_conv_params {
                                            130 = 3x3 window kernel (16x16-pixel patches, stride 1, pad 1), 8 waves,
                                            131 = the same layer on the 4-wave window kernel (two workgroups per CU),
                                            132 = as 128 with the epilogue's scattered 8-byte stores instead of line stores,
-                                           133 = 4-wave tiles on conv_lin_kernel whatever K (1x1 layers) */
+                                           133 = 4-wave tiles on conv_lin_kernel whatever K (1x1 layers), four-stage ring,
+                                           134 = the same with the three-stage ring on the 128 x 128 tile (three workgroups
+                                                 per CU: the automatic choice for K <= 384) */
     int32_t stats_gran;                 /* channels per statistics entry: 4 (quads), or 2 (pairs) for buffers whose
                                            GroupNorm groups are not multiples of 4 channels (320, 960 channels) */
     int32_t patch16;                    /* set by onedc_conv_gemm (callers leave 0): pixel tiles are 16x16 patches */

@@ -271,12 +271,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
 // per step.  Same LDS footprint (64 KB / 48 KB), same wave tiles, same k order as the 64-channel kernel: the accumulators
 // see the same MFMA sequence, so outputs and epilogue statistics are bit-identical to conv_gemm_kernel's.
 // Input through a buffer descriptor (tail rows read zeros): the dispatcher keeps tensors of 4 GB and more on the old kernel.
-template <class T>
-__global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_params p, int tiles_n, int tiles_m, int M) {
+// NSTAGE 3 (tile 134): 48 KB for the 128 x 128 tile, THREE workgroups per CU (experiment: a third resident workgroup
+// under the prologue and epilogue of the other two).
+template <class T, int NSTAGE = 4>
+__global__ __launch_bounds__(256, NSTAGE == 3 ? 3 : 2) void conv_lin_kernel(const onedc_conv_params p, int tiles_n, int tiles_m, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TN = T::TN, TM = T::TM;
     constexpr int STAGE = (TN + TM) * 64;          // bytes per K-step: 32 channels of every row
-    constexpr int NSTAGE = 4;
     constexpr int WB = TN / 16, PB = TM / 16;      // 16-row DMA blocks of weights / pixels
     constexpr int NBLK = WB + PB, NI = NBLK / 4;   // DMA instructions per wave and stage
     static_assert(NBLK % 4 == 0, "blocks divide over the four waves");
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_param
         }
     }
     auto issue = [&](int s) {
-        char *dst = smem + (s & (NSTAGE - 1)) * STAGE + lane * 0;
+        char *dst = smem + (s % NSTAGE) * STAGE;
         const unsigned so = (unsigned)s * 64;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_param
     };
     issue(0);
     if (steps > 1) issue(1);
-    if (steps > 2) issue(2);
+    if (NSTAGE > 3 && steps > 2) issue(2);
     __builtin_amdgcn_sched_barrier(0);
 
     f32x4 acc[T::FI][T::FJ];
@@ -338,13 +339,13 @@ __global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_param
 
     for (int s = 0; s < steps; ++s) {
         // K-step s has landed (this wave's part): what may still fly are the NI instructions of each younger step
-        if (s + 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        if (NSTAGE > 3 && s + 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
         else if (s + 1 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // ... everywhere; and every wave is past its reads of step s - 1
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 3 < steps) issue(s + 3);            // into the stage of step s - 1
-        const char *cur = smem + (s & (NSTAGE - 1)) * STAGE;
+        if (s + NSTAGE - 1 < steps) issue(s + NSTAGE - 1);            // into the stage of step s - 1
+        const char *cur = smem + (s % NSTAGE) * STAGE;
         a16x8 a[T::FI], b[T::FJ];
 #pragma unroll
         for (int i = 0; i < T::FI; ++i) a[i] = *(const a16x8 *)(cur + fa_off + i * 1024);
@@ -413,16 +414,16 @@ __global__ __launch_bounds__(256, 2) void conv_lin_kernel(const onedc_conv_param
     }
 }
 
-template <class T>
+template <class T, int NSTAGE = 4>
 int launch_lin(const onedc_conv_params &p, hipStream_t st) {
-    constexpr int LDS = 4 * (T::TN + T::TM) * 64;
+    constexpr int LDS = NSTAGE * (T::TN + T::TM) * 64 > 4 * 64 * 64 * 2 ? NSTAGE * (T::TN + T::TM) * 64 : 4 * 64 * 64 * 2;   // (>= the epilogue's line staging)
     static OnedcLdsAttrOnce once;
-    once.ensure({{(const void *)conv_lin_kernel<T>, LDS}});
+    once.ensure({{(const void *)conv_lin_kernel<T, NSTAGE>, LDS}});
     const int M = (int)((int64_t)p.B * p.OH * p.OW);
     const int tiles_n = (p.Cout + T::TN - 1) / T::TN;
     const int tiles_m = (M + T::TM - 1) / T::TM;
     dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
-    hipLaunchKernelGGL((conv_lin_kernel<T>), grid, dim3(256), LDS, st, p, tiles_n, tiles_m, M);
+    hipLaunchKernelGGL((conv_lin_kernel<T, NSTAGE>), grid, dim3(256), LDS, st, p, tiles_n, tiles_m, M);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }
@@ -569,17 +570,21 @@ static int conv_choose(const onedc_conv_params &p) {
     if (p.gn_ab) return -13;                       // only the window kernel normalises on load
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
-    // short K (< 16 K-tiles: 1x1 layers up to 960 channels): the 4-wave kernels win, two workgroups per CU hide each
-    // other's prologue and epilogue (tools/bench_1x1.py); all three families give identical bits
+    // short K (< 32 K-tiles: 1x1 layers up to 1984 channels): the 4-wave kernels win, two workgroups per CU hide each
+    // other's prologue and epilogue (tools/bench_1x1.py; round 4 moved the bound from 16 to 32 K-tiles: the K = 1280 layers
+    // of the 24x24 level run 10 - 22 % faster on four waves -- qk 1280 -> 2560 100 -> 78 us, out-projection 52 -> 46, 1280 ->
+    // 1280 51 -> 43 -- while K = 2560 is level and K = 5120 / the 3x3 layers are 13 - 20 % faster on eight); all three
+    // families give identical bits
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);
-    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= 16) || p.tile == 256) &&
+    constexpr int kLongK = 32;
+    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 134 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= kLongK) || p.tile == 256) &&
         !(p.stats && p.stats_gran == 2))           // the 256x256 kernel only leaves quad statistics
         return ONEDC_KERNEL_256X256;
     // 128 x 256 tiles (8 waves, 3-deep LDS ring): channel counts that are whole 128-row tiles or waste < 20 %
     const int rows128 = (p.Cout + 127) / 128 * 128;
     const int64_t blocks128 = (rows128 / 128) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
-    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
-        ((blocks128 >= 160 && ktiles >= 16) || p.tile == 129))
+    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 134 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
+        ((blocks128 >= 160 && ktiles >= kLongK) || p.tile == 129))
         return ONEDC_KERNEL_128X256;
     if (p.Cout <= 16 && !glu) return ONEDC_KERNEL_16X256;
     // 64-row tiles: channel counts that leave <= 64 rows in the last 128-row tile, and grids of fewer than 256
@@ -587,12 +592,19 @@ static int conv_choose(const onedc_conv_params &p) {
     const int64_t blocks4w = (rows128 / 128) * ((M64 + 127) / 128) * (p.batch > 1 ? p.batch : 1);
     // 1x1 layers of both 4-wave tile shapes run on the 32-channel / four-stage pipeline (conv_lin_kernel: same tiles, same k
     // order, same bits); tile 128 keeps the 64-channel kernel (tests, A/B)
-    // (measured, tools/ab_round4.py: the deeper ring pays from K = 1280 on -- 5120 -> 1280 at 24x24 139 -> 119 us -- and costs
-    // 4 - 13 % on the short-K layers, whose time is prologue + epilogue, not the K loop)
-    const bool lin = conv_lin_ok(p) && p.tile != 128 && p.tile != 132 && (p.Cin >= 1280 || p.tile == 133);
+    // conv_lin_kernel (32-channel K-steps, four-stage ring) is a MEASURED NEGATIVE, kept selectable (tile 133) with its tests:
+    // tools/ab_round4.py / bench_1x1.py, B = 16 -- 4 - 13 % slower than the 64-channel kernel on the short-K layers (their time is
+    // prologue + epilogue, not the K loop), level with the 8-wave kernels where K is long (5120 -> 1280 at 24x24: 119 us
+    // against 139 for the 64-channel 4-wave kernel and 118 for the 128 x 256 tile the dispatcher picks there anyway), slower at
+    // 12x12 (5120 -> 1280: 73 against 55 us).  Never the automatic choice.
+    // ... except its THREE-stage form on the 128 x 128 tile (48 KB: three workgroups per CU instead of two) for K <= 384, the
+    // level-0 Linear layers with wide outputs, whose life is prologue + epilogue and wants one more resident workgroup:
+    // to_q|k 320 -> 1024 at 96x96 211 -> 182 us, GEGLU 320 -> 2560 397 -> 368, to_q 320 -> 512 88 -> 80; level from K = 640 on.
+    const bool lin = conv_lin_ok(p) && (p.tile == 133 || p.tile == 134);
+    const bool lin3 = conv_lin_ok(p) && p.tile == 0 && p.Cin <= 384;
     if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))
         return lin ? ONEDC_KERNEL_LIN_64X128 : ONEDC_KERNEL_64X128;
-    return lin ? ONEDC_KERNEL_LIN_128X128 : ONEDC_KERNEL_128X128;
+    return (lin || lin3) ? ONEDC_KERNEL_LIN_128X128 : ONEDC_KERNEL_128X128;
 }
 
 extern "C" int onedc_conv_gemm_kernel_id(const onedc_conv_params *pp) {
@@ -640,8 +652,10 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         case ONEDC_KERNEL_16X256: return launch<Tile<16, 256, 1, 4>>(p, st);
         case ONEDC_KERNEL_64X128: return launch<Tile<64, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_128X128: return launch<Tile<128, 128, 2, 2>>(p, st);
-        case ONEDC_KERNEL_LIN_64X128: return launch_lin<Tile<64, 128, 2, 2>>(p, st);
-        case ONEDC_KERNEL_LIN_128X128: return launch_lin<Tile<128, 128, 2, 2>>(p, st);
+        case ONEDC_KERNEL_LIN_64X128:
+            return p.tile == 134 ? launch_lin<Tile<64, 128, 2, 2>, 3>(p, st) : launch_lin<Tile<64, 128, 2, 2>>(p, st);
+        case ONEDC_KERNEL_LIN_128X128:
+            return p.tile != 133 ? launch_lin<Tile<128, 128, 2, 2>, 3>(p, st) : launch_lin<Tile<128, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_F32_128X128: return launch<Tile<128, 128, 2, 2>, true>(p, st);
         case ONEDC_KERNEL_F32_64X128: return launch<Tile<64, 128, 2, 2>, true>(p, st);
 #ifdef EXP_TILES

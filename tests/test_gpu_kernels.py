@@ -1196,7 +1196,7 @@ def test_conv_win4_second_source_race_screen_and_refusal():
     (1, 9, 7, 96 + 32, 128, "leaky", False, False),    # 63 pixels: one partial tile
 ])
 def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, res, stats):
-    """1x1 layers on conv_lin_kernel (32-channel K-steps, four-stage ring; the automatic choice) against F.conv2d and, BIT
+    """1x1 layers on conv_lin_kernel (32-channel K-steps, four-stage ring; tile 133) against F.conv2d and, BIT
     FOR BIT -- outputs and the GroupNorm statistics of the epilogue -- against conv_gemm_kernel (tile=128): same tiles, same k
     order.  The layers are the UNet's Linear / 1x1 convs (decoder_unet.py:204-293)."""
     glu = epi == "geglu"
@@ -1209,7 +1209,7 @@ def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, r
     rv = from_nchw(r.to(DEV)) if res else None
     code = {"linear": K.EPI_LINEAR, "geglu": K.EPI_GEGLU, "silu": K.EPI_SILU, "leaky": K.EPI_LEAKY}[epi]
     outs = []
-    for tile in (133, 128, 132, 0):           # the ring kernel, the 64-channel kernel, the same without line stores, automatic
+    for tile in (133, 128, 132, 134, 0):      # the ring kernel, the 64-channel kernel, the same without line stores, 3-stage ring, automatic
         y = new_view(B, H, W, cstore, DEV, stats=stats)
         K.conv_gemm(xv, wp, bd, y, KH=1, epi=code, slope=0.1, res=rv, stats=stats, tile=tile)
         outs.append((y.t[:B * H * W * cstore].clone(), y.stats.t.clone() if (stats and y.stats is not None) else None, y))
@@ -1227,7 +1227,7 @@ def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, r
             assert torch.equal(outs[0][1], o[1])
 
 
-def test_conv_lin_kernel_is_the_automatic_choice_and_batched():
+def test_conv_lin_kernel_batched_and_dispatch():
     """The dispatcher's answer for the 1x1 layers, and the batched form (blockIdx.z: V^T of the attention layers)."""
     G, n, Cc = 5, 144, 128
     q, k = rnd(G, n, Cc, seed=451), rnd(G, n, Cc, seed=452)
@@ -1243,8 +1243,7 @@ def test_conv_lin_kernel_is_the_automatic_choice_and_batched():
         outs.append(s)
     close(outs[0].view(G, n, n), 0.25 * q @ k.transpose(1, 2), rms=1e-4, mx=1e-4, what="batched nt on conv_lin")
     assert torch.equal(outs[0], outs[1])
-    # the dispatcher: the ring where a 1x1 layer with K >= 1280 lands on the 4-wave tiles (the UNet's 12x12 level: grids too
-    # small for the 8-wave kernels), the 64-channel kernel for short K (prologue + epilogue bound), tile 128 / 133 force either
+    # the dispatcher's answers
     x = new_view(16, 12, 12, 1280, DEV)
     y = new_view(16, 12, 12, 1280, DEV)
     p = K.ConvParams()
@@ -1252,10 +1251,19 @@ def test_conv_lin_kernel_is_the_automatic_choice_and_batched():
     p.B, p.IH, p.IW, p.Cin, p.x_cs, p.OH, p.OW, p.Cout, p.y_cs = 16, 12, 12, 1280, 1280, 12, 12, 1280, 1280
     p.KH = p.KW = p.stride = 1
     p.alpha = 1.0
-    assert K.conv_kernel_name(p) == "lin_64x128"
-    p.Cin = p.x_cs = 320
-    assert K.conv_kernel_name(p) == "64x128"
+    assert K.conv_kernel_name(p) == "64x128"            # (the ring is a measured negative: never the automatic choice)
     p.tile = 133
     assert K.conv_kernel_name(p) == "lin_64x128"
-    p.tile, p.Cin, p.x_cs = 128, 1280, 1280
+    p.tile = 128
+    assert K.conv_kernel_name(p) == "64x128"
+    # 24x24 level, K = 1280 (20 K-tiles): four waves since round 4 (the 8-wave tiles from 32 K-tiles on)
+    p.tile, p.IH, p.IW, p.OH, p.OW = 0, 24, 24, 24, 24
+    assert K.conv_kernel_name(p) == "128x128"
+    p.Cin = p.x_cs = 5120
+    assert K.conv_kernel_name(p) == "256x256"
+    # level 0, K = 320, wide output: the three-stage ring (three workgroups per CU); narrow output: the 64-row tile as before
+    p.IH = p.IW = p.OH = p.OW = 96
+    p.Cin, p.x_cs, p.Cout, p.y_cs = 320, 320, 1024, 1024
+    assert K.conv_kernel_name(p) == "lin_128x128"
+    p.Cout = p.y_cs = 320
     assert K.conv_kernel_name(p) == "64x128"

@@ -16,7 +16,15 @@ SH = [("ff-in geglu 320->2560 @96", 96, 320, 2560, 1, K.EPI_GEGLU, False), ("ff-
       ("out 384->320 @96 +res", 96, 384, 320, 1, 0, True), ("ff-out 1280->320 @96 +res", 96, 1280, 320, 1, 0, True),
       ("qkv 640->768 @48", 48, 640, 768, 1, 0, False), ("proj 640->640 @48 +res", 48, 640, 640, 1, 0, True),
       ("3x3 1280->1280 @12 +res", 12, 1280, 1280, 3, 0, True), ("3x3 2560->1280 @12", 12, 2560, 1280, 3, 0, False),
-      ("1x1 1280->1280 @24", 24, 1280, 1280, 1, 0, False), ("3x3 1280->1280 @24 +res", 24, 1280, 1280, 3, 0, True)]
+      ("1x1 1280->1280 @24", 24, 1280, 1280, 1, 0, False), ("3x3 1280->1280 @24 +res", 24, 1280, 1280, 3, 0, True),
+      # round 4: the rest of the UNet's 1x1 shapes (profiles/r4_unet_layers.txt), to check the dispatcher's choice per shape
+      ("qk 320->1024 @96", 96, 320, 1024, 1, 0, False), ("proj 320->320 @96 +res", 96, 320, 320, 1, 0, True),
+      ("qk 640->2048 @48", 48, 640, 2048, 1, 0, False), ("out 768->640 @48 +res", 48, 768, 640, 1, 0, True),
+      ("ff-out 2560->640 @48 +res", 48, 2560, 640, 1, 0, True), ("q 640->1024 @48", 48, 640, 1024, 1, 0, False),
+      ("qk 1280->2560 @24", 24, 1280, 2560, 1, 0, False), ("out 1280->1280 @24 +res", 24, 1280, 1280, 1, 0, True),
+      ("ff-out 5120->1280 @24 +res", 24, 5120, 1280, 1, 0, True), ("3x3 2560->1280 @24", 24, 2560, 1280, 3, 0, False),
+      ("3x3 1280->1280 @24", 24, 1280, 1280, 3, 0, False), ("1x1 1280->1280 @12 +res", 12, 1280, 1280, 1, 0, True),
+      ("ff-in geglu 1280->10240 @12", 12, 1280, 10240, 1, K.EPI_GEGLU, False), ("ff-out 5120->1280 @12 +res", 12, 5120, 1280, 1, 0, True)]
 for name, H, Cin, Cout, k, epi, res in SH:
     B = 16
     x = K.View(torch.randn((B * H * H + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, H, Cin)
