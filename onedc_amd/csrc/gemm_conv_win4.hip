@@ -203,17 +203,28 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         f32x4 ab[2];                                 // (a, b) pairs of four of the lane's 8 channels
         const int cbase = c32 * 32 + ((lane & 3) ^ (((sbits >> k) & 1) << 1)) * 8;
         const int abaddr = W4_LDS + cbase * 8;
+#ifdef EXP_NORM_NONE                                 // (ablation) no normalisation work at all: what GroupNorm on load costs in total
+        (void)addr;
+        (void)abaddr;
+        return;
+#endif
         asm volatile("ds_read_b128 %0, %1" : "=v"(raw) : "v"(addr));
+#ifdef EXP_NORM_NOAB                                 // (ablation) (a, b) from registers instead of 4 LDS reads per block
+        ab[0] = ab[1] = f32x4{1.f, 0.25f, 1.f, 0.25f};
+#else
         asm volatile("ds_read_b128 %0, %1" : "=v"(ab[0]) : "v"(abaddr));
         asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(ab[1]) : "v"(abaddr));
+#endif
         const bool live = woff[k] != x_bytes;
         u32x4_t o;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+#ifndef EXP_NORM_NOAB
             if (h == 1) {                            // second four channels into the same registers
                 asm volatile("ds_read_b128 %0, %1 offset:32" : "+v"(ab[0]) : "v"(abaddr));
                 asm volatile("ds_read_b128 %0, %1 offset:48" : "+v"(ab[1]) : "v"(abaddr));
             }
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw), "+v"(ab[0]), "+v"(ab[1]));
             const f32x4 ab0 = ab[0], ab1 = ab[1];     // (a, b) of channels 4 h .. 4 h + 3
             const uint32_t w0 = h ? raw[2] : raw[0], w1 = h ? raw[3] : raw[1];
