@@ -13,7 +13,7 @@ run bench_line_bf16 env ONEDC_ACT=bf16 python3 bench.py --no-cpu-baseline
 run bench_line_sequential python3 bench.py --sequential --no-cpu-baseline
 run bench_line_zonly python3 bench.py --mode z_only --no-cpu-baseline
 run bench_line_encdec python3 bench.py --mode encode_decode
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r3 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r4 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$root/$out/pmc_$c" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_$c.err" < /dev/null; echo "pmc $c rc=$?" )
 done
@@ -31,4 +31,10 @@ f=$(find "$out/pmc_FETCH_SIZE" -name "*counter_collection.csv" < /dev/null | hea
 w=$(find "$out/pmc_WRITE_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then python3 tools/pmc_traffic.py "$f" "$w" "$out/pmc_traffic.json" "folded on the box" < /dev/null; fi
 rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"
+ls -la "$out" < /dev/null
+# round 4: per-layer tables, the A/B of the round's kernel forms, the tile sweep of the UNet's 1x1 shapes
+timeout 400 python3 tools/unet_layers.py > "$out/unet_layers.txt" 2>&1 < /dev/null
+timeout 400 python3 tools/vae_layers.py > "$out/vae_layers.txt" 2>&1 < /dev/null
+timeout 500 python3 tools/ab_round4.py > "$out/ab_round4.txt" 2>&1 < /dev/null
+timeout 300 python3 tools/bench_1x1.py > "$out/bench_1x1.txt" 2>&1 < /dev/null
 ls -la "$out" < /dev/null

@@ -27,11 +27,14 @@ def wrapped(x, w, bias, y, **kw):
     e0.record()
     r = orig(x, w, bias, y, **kw)
     e1.record()
+    if r is None:                      # (a second source the dispatcher refused: nothing was launched)
+        return r
     cout = kw.get("Cout") or y.C
     taps = 4 if kw.get("up") == 2 else kw.get("KH", 1) ** 2
+    cin2 = kw["x2"].C if kw.get("x2") is not None else 0      # conv_shortcut riding on conv2 (round 4)
     rec.append(((kw.get("KH", 1), y.H, kw.get("Cin") or x.C, cout, kw.get("up", 0), "gn" if kw.get("gn") is not None else "",
-                 "res" if kw.get("res") is not None else ""), e0, e1,
-                2.0 * x.B * y.H * y.W * cout * taps * (kw.get("Cin") or x.C) * max(1, kw.get("batch", 1))))
+                 ("res" if kw.get("res") is not None else "") + (f"+1x1 {cin2}" if cin2 else "")), e0, e1,
+                2.0 * x.B * y.H * y.W * cout * (taps * (kw.get("Cin") or x.C) + cin2) * max(1, kw.get("batch", 1))))
     return r
 
 
@@ -52,4 +55,4 @@ for key, e0, e1, fl in rec:
 tot = sum(v[1] for v in agg.values())
 print(f"VAE decode {t0.elapsed_time(t1):.2f} ms; conv launches {len(rec)}, {tot:.2f} ms")
 for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
-    print(f"k{key[0]} out {key[1]:3d}^2 {key[2]:4d}->{key[3]:<4d} up{key[4]} {key[5]:2s} {key[6]:3s} x{n:3d} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF executed")
+    print(f"k{key[0]} out {key[1]:3d}^2 {key[2]:4d}->{key[3]:<4d} up{key[4]} {key[5]:2s} {key[6]:9s} x{n:3d} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF executed")
