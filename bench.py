@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--prior-16bit", action="store_true",
                     help="prior networks on the 16-bit matrix cores (the reference's GPU-autocast precision class) instead of exact "
                          "f32: a measurement of what the exact-f32 prior costs, not the headline configuration")
+    ap.add_argument("--prior-exact", action="store_true",
+                    help="prior networks on the f32 matrix instructions (prior_f32: exact, the arithmetic of rounds 1-3) instead of "
+                         "split-half operands on the 16-bit matrix cores: what the round-4 form saves")
     ap.add_argument("--prior-arith", choices=["mfma", "torch_cpu", "auto"], default="auto",
                     help="arithmetic of the four-part prior: auto (the product's default: the exact-f32 MFMA path, and the "
                          "reference's CPU arithmetic only for a stream that desynchronises -- none of the bench's own do), mfma "
@@ -393,7 +396,8 @@ def main():
         sds_dev = broadcast_state_dicts(sds, specs, device, rank, world)
     else:                                  # synthetic weights are a pure function of (key, seed): every rank builds its own
         sds = sds_dev = synthetic_weights(args.weights)
-    model_cfg = {"vae_attn_patch": 16, "prior_f32": not args.prior_16bit, "prior_arith": args.prior_arith}
+    model_cfg = {"vae_attn_patch": 16, "prior_f32": False if args.prior_16bit else ("exact" if args.prior_exact else True),
+                 "prior_arith": args.prior_arith}
     if args.prior_arith == "torch_cpu":
         model_cfg.update(ref_threads=8)
     model = SD15_1step_codec_stage1(model_cfg, device=device).load_state_dicts(*sds_dev)
@@ -669,7 +673,9 @@ def main():
                        "setup_s": round(t_setup, 1),
                        "arithmetic": f"{model.act} storage and MFMA operands (synthesis, UNet, VAE), " +
                                      ("16-bit MFMA prior networks (--prior-16bit), exact f32 MFMA (VAE conv_in)" if args.prior_16bit else
-                                      "exact f32 MFMA (prior networks, VAE conv_in)" if args.prior_arith in ("mfma", "auto") else
+                                      "exact f32 MFMA (prior networks, VAE conv_in)" if args.prior_arith in ("mfma", "auto") and args.prior_exact else
+                                      "f32 activations and accumulation with split-half operands (22 bits, exact products) on the 16-bit "
+                                      "matrix cores (prior networks), exact f32 MFMA (VAE conv_in)" if args.prior_arith in ("mfma", "auto") else
                                       f"prior networks in the reference's torch-CPU arithmetic as f32 fma chains on the GPU "
                                       f"(prior_arith={args.prior_arith}, compatibility path), exact f32 MFMA (VAE conv_in)") +
                                      ", f64 (eps -> x0), f32 accumulation everywhere",

@@ -80,7 +80,12 @@ typedef struct onedc_conv_params {
                                            GroupNorm groups are not multiples of 4 channels (320, 960 channels) */
     int32_t patch16;                    /* set by onedc_conv_gemm (callers leave 0): pixel tiles are 16x16 patches */
     int32_t in_f32;                     /* 1: x, w, res are f32 (exact f32 MFMA; Cin multiple of 32): the prior
-                                           networks, whose outputs feed integer decisions, and the VAE's conv_in */
+                                           networks, whose outputs feed integer decisions, and the VAE's conv_in;
+                                           2 (version 0.4): x and res f32 as with 1, w in the split form of
+                                           pack.pack_matrix_split16 -- per row and 32-channel block 32 halves h then 32 halves
+                                           l with w = h + l * 2^-11, channels in the kernel's slot order -- and the products
+                                           on the 16-bit matrix cores (three v_mfma_f32_16x16x32_f16 per block: 22-bit
+                                           operands, exact products, f32 accumulation; |x| < 65504) */
     int64_t x_bs, w_bs, y_bs, r_bs;     /* element strides between batches */
     const float *gn_ab;                 /* NULL, or float2 (a, b) [B][Cin] from onedc_gn_from_stats / onedc_gn_stats: x is the
                                            RAW tensor in front of nn.GroupNorm (+SiLU when gn_silu) and the conv reads
@@ -135,7 +140,9 @@ enum {
     ONEDC_KERNEL_UPS2X2_4W = 11,   /* conv_win4_kernel<2>: the upsample phases on the same 4-wave machinery */
     ONEDC_KERNEL_SPLITK_256 = 12,  /* conv_gemm256_kernel over K ranges + splitk_reduce_kernel (onedc_conv_params.split_k) */
     ONEDC_KERNEL_LIN_64X128 = 13,  /* conv_lin_kernel<Tile<64,128>>: 1x1 layers, 32-channel K-steps, four-stage LDS ring */
-    ONEDC_KERNEL_LIN_128X128 = 14  /* conv_lin_kernel<Tile<128,128>> */
+    ONEDC_KERNEL_LIN_128X128 = 14, /* conv_lin_kernel<Tile<128,128>> */
+    ONEDC_KERNEL_F32S_128X128 = 15,/* conv_gemm_kernel<Tile<128,128>, f32, split>: f32 activations, operands as pairs of halves */
+    ONEDC_KERNEL_F32S_64X128 = 16
 };
 int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
 const char *onedc_conv_kernel_name(int kernel_id);

@@ -151,8 +151,12 @@ class IntraNoAR:
                  prior_f32=True, prior_arith="auto", ref_threads=None, ref_profile=None):
         """prior_f32: run everything that feeds the integer decisions of the entropy coder (hyper
         decoder, prior fusion, the four-part prior's nets: 36 GFLOP of the 8047 per 768x768 picture)
-        in exact f32 on the f32 matrix-core path, like the reference's CPU path; False = bf16 MFMA
-        like the reference under GPU autocast (SURVEY hard part 2).
+        on f32 activations with f32 accumulation, like the reference's CPU path.  True (default, round 4): the products on
+        the 16-bit matrix cores with every operand split into a pair of halves (22 significant bits, exact products:
+        csrc/gemm_conv.hip SPLIT; a sum differs from the f32 fma chain by less than that chain's own rounding; operands must
+        lie inside the half range, which the prior networks do by two orders of magnitude); "exact": the f32 matrix
+        instructions, a fixed-order fp32 fma chain (rounds 1-3; what a stream written by those rounds' encoder needs);
+        False = 16-bit nets like the reference under GPU autocast (SURVEY hard part 2).
         prior_arith: "mfma" (this package's own prior, encoder and decoder side alike) or "torch_cpu": the prior
         networks evaluated in the REFERENCE'S CPU arithmetic -- the fused-multiply-add chains torch-CPU's convolutions are
         made of, calibrated against the local torch (onedc_amd/ref_arith.py) -- so that y streams written by the reference
@@ -170,6 +174,9 @@ class IntraNoAR:
         self.act = K.act()                 # the format the weights below are packed in
         self.N = N = bottleneck_ch
         self.prior_f32 = f32 = bool(prior_f32)
+        self.prior_exact = isinstance(prior_f32, str) and prior_f32.lower() == "exact"
+        from . import layers as _layers
+        _split_before, _layers.PRIOR_SPLIT16 = _layers.PRIOR_SPLIT16, _layers.PRIOR_SPLIT16 and not self.prior_exact
         if prior_arith not in ("mfma", "torch_cpu", "auto"):
             raise ValueError(f"prior_arith must be 'mfma', 'torch_cpu' or 'auto', not {prior_arith!r}")
         self.prior_arith = prior_arith
@@ -191,6 +198,7 @@ class IntraNoAR:
         self.y_spatial_prior_adaptor = [DepthConvBlock4(sd, f"y_spatial_prior_adaptor_{i}", device, f32)
                                         for i in (1, 2, 3)]
         self.y_spatial_prior = [DepthConvBlock4(sd, f"y_spatial_prior.{i}", device, f32) for i in range(3)]
+        _layers.PRIOR_SPLIT16 = _split_before
         self.semantic_adaptor = SemanticAdaptor(sd, device, semantic_ch)
         self.dec = Decoder(sd, device)
         self.z_fsq_levels = list(z_fsq_levels)

@@ -59,9 +59,30 @@ struct Tile {
 // 16-byte fragment chunk feeds four k=4 MFMAs (element e of every lane's chunk is one k-slice, the
 // same permutation on both operands).  Used for the prior networks, whose outputs feed integer
 // decisions (SURVEY hard part 2).
-template <class T, bool F32>
+// SPLIT (with F32; onedc_conv_params.in_f32 == 2): the same f32 activations, f32 accumulation and tiles at the 16-bit matrix
+// rate.  Every operand is written as a PAIR of IEEE halves, v = h + l * 2^-11 (h = half(v), l = half((v - h) * 2^11): 22
+// significant bits, relative representation error <= 2^-23), the weights once by the host (pack.pack_matrix_split16: per
+// 32-channel K-step 64 B of h then 64 B of l, the same 128 bytes an f32 row has), the activations in registers behind the
+// fragment read; the product is three v_mfma_f32_16x16x32_f16 per K-step and tile -- h.h into one accumulator, h.l + l.h
+// into a second that joins scaled by 2^-11 at the end; l.l (2^-22 of the product) is dropped -- instead of eight
+// v_mfma_f32_16x16x4_f32: 48 instead of 256 matrix-pipe cycles.  Each product is exact in f32 (11 x 11 bits), so a sum differs
+// from the f32 fma chain by the operands' 2^-23, which is below the rounding that chain accumulates itself over K >= 128.
+// Fixed k order, no atomics: as deterministic and batch-invariant as the exact form; operands must lie inside the half range
+// (|v| < 65504: the prior networks stay below 600 with random-init weights, 11 with damped ones -- DESIGN.md section 3).
+typedef __attribute__((ext_vector_type(8))) _Float16 split_h8;
+typedef __attribute__((ext_vector_type(2))) _Float16 split_h2;
+__device__ __forceinline__ void split16_pair(float v0, float v1, uint32_t &h, uint32_t &l) {
+    const split_h2 hh = {(_Float16)v0, (_Float16)v1};                       // round to nearest even
+    const float d0 = (v0 - (float)hh[0]) * 2048.f, d1 = (v1 - (float)hh[1]) * 2048.f;   // exact differences
+    const split_h2 ll = {(_Float16)d0, (_Float16)d1};
+    h = __builtin_bit_cast(uint32_t, hh);
+    l = __builtin_bit_cast(uint32_t, ll);
+}
+
+template <class T, bool F32, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_params p, int tiles_n,
                                                            int tiles_m, int M, int Ktot) {
+    static_assert(!SPLIT || F32, "the split form is a form of the f32 path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TN = T::TN, TM = T::TM;
     constexpr int ES = F32 ? 4 : 2;                // bytes per element
@@ -139,10 +160,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
 
     // ---- accumulators ---------------------------------------------------------------------------
     f32x4 acc[T::FI][T::FJ];
+    f32x4 acc_x[SPLIT ? T::FI : 1][SPLIT ? T::FJ : 1];      // SPLIT: the cross terms h.l + l.h, scaled 2^11
 #pragma unroll
     for (int i = 0; i < T::FI; ++i)
 #pragma unroll
-        for (int j = 0; j < T::FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T::FJ; ++j) {
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
     const int frow = lane & 15, fq = lane >> 4;
     int foff[2];                                    // fragment byte offset inside a 16-row group
@@ -168,6 +193,38 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
             }
             issue(s + 1, tap, ci, smem + ((s + 1) & 1) * T::BUF);
         }
+        if constexpr (SPLIT) {
+            // one MFMA k step per 32-channel K-step.  Slot 8 fq + j of the k dimension is channel 4 fq + j (j < 4) or
+            // 16 + 4 fq + j - 4: what a lane's two f32 chunks (fq, 4 + fq) hold -- the host packs the weight halves in
+            // that order, so chunk fq of the row is the lane's h fragment and chunk 4 + fq its l fragment
+            split_h8 ah[T::FI], al[T::FI], bh[T::FJ], bl[T::FJ];
+#pragma unroll
+            for (int i = 0; i < T::FI; ++i) {
+                ah[i] = *(const split_h8 *)(cur + a_base + i * 2048 + foff[0]);
+                al[i] = *(const split_h8 *)(cur + a_base + i * 2048 + foff[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < T::FJ; ++j) {
+                const f32x4 v0 = *(const f32x4 *)(cur + b_base + j * 2048 + foff[0]);
+                const f32x4 v1 = *(const f32x4 *)(cur + b_base + j * 2048 + foff[1]);
+                uint32_t h[4], l[4];
+                split16_pair(v0[0], v0[1], h[0], l[0]);
+                split16_pair(v0[2], v0[3], h[1], l[1]);
+                split16_pair(v1[0], v1[1], h[2], l[2]);
+                split16_pair(v1[2], v1[3], h[3], l[3]);
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+                bh[j] = __builtin_bit_cast(split_h8, u32x4_{h[0], h[1], h[2], h[3]});
+                bl[j] = __builtin_bit_cast(split_h8, u32x4_{l[0], l[1], l[2], l[3]});
+            }
+#pragma unroll
+            for (int i = 0; i < T::FI; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FJ; ++j) {
+                    acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+                    acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if constexpr (F32) {
@@ -202,6 +259,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
         }
     }
 
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < T::FI; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = __builtin_fmaf(acc_x[i][j][e], 1.f / 2048.f, acc[i][j][e]);
+    }
     // ---- epilogue: lane holds channels 4*fq..4*fq+3 of pixel (lane & 15) of every 16x16 tile --------
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     const int cout_store = glu ? p.Cout / 2 : p.Cout;
@@ -428,10 +493,10 @@ int launch_lin(const onedc_conv_params &p, hipStream_t st) {
     return 0;
 }
 
-template <class T, bool F32 = false>
+template <class T, bool F32 = false, bool SPLIT = false>
 int launch(const onedc_conv_params &p, hipStream_t st) {
     static OnedcLdsAttrOnce once;
-    once.ensure({{(const void *)conv_gemm_kernel<T, F32>, 2 * T::BUF}});
+    once.ensure({{(const void *)conv_gemm_kernel<T, F32, SPLIT>, 2 * T::BUF}});
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
     if (M64 > 0x7fffffff) return -1;
     const int M = (int)M64;
@@ -439,7 +504,7 @@ int launch(const onedc_conv_params &p, hipStream_t st) {
     const int tiles_m = (M + T::TM - 1) / T::TM;
     const int Ktot = p.KH * p.KW * p.Cin;
     dim3 grid(tiles_n * tiles_m, 1, p.batch > 1 ? p.batch : 1);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, F32>), grid, dim3(256), 2 * T::BUF, st, p, tiles_n, tiles_m, M, Ktot);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, F32, SPLIT>), grid, dim3(256), 2 * T::BUF, st, p, tiles_n, tiles_m, M, Ktot);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }
@@ -551,7 +616,9 @@ static int conv_choose(const onedc_conv_params &p) {
         // 64-row tile (twice the workgroups, half the work each; same k order, same bits): 256->256 at 48x48, B = 16:
         // 64 -> 45 us (tools/bench_f32.py)
         const int64_t blocks = ((p.Cout + 127) / 128) * ((M64 + 127) / 128) * (p.batch > 1 ? p.batch : 1);
-        return (blocks < 1024 && (p.Cout % 64) == 0 && p.tile != 128) ? ONEDC_KERNEL_F32_64X128 : ONEDC_KERNEL_F32_128X128;
+        const bool small = blocks < 1024 && (p.Cout % 64) == 0 && p.tile != 128;
+        if (p.in_f32 == 2) return small ? ONEDC_KERNEL_F32S_64X128 : ONEDC_KERNEL_F32S_128X128;
+        return small ? ONEDC_KERNEL_F32_64X128 : ONEDC_KERNEL_F32_128X128;
     }
     // 3x3 window kernel (16x16-pixel patches x 128 channels, every input pixel staged once per 64-channel chunk):
     // 5-27 % faster than the 128x256 / 256x256 kernels on every 3x3 layer it can take (tools/bench_conv.py)
@@ -625,6 +692,8 @@ extern "C" const char *onedc_conv_kernel_name(int id) {
         case ONEDC_KERNEL_128X128: return "128x128";
         case ONEDC_KERNEL_F32_128X128: return "f32_128x128";
         case ONEDC_KERNEL_F32_64X128: return "f32_64x128";
+        case ONEDC_KERNEL_F32S_128X128: return "f32s_128x128";
+        case ONEDC_KERNEL_F32S_64X128: return "f32s_64x128";
         case ONEDC_KERNEL_WIN3X3_4W: return "win3x3_4w";
         case ONEDC_KERNEL_UPS2X2_4W: return "ups2x2_4w";
         case ONEDC_KERNEL_SPLITK_256: return "splitk_256";
@@ -658,6 +727,8 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
             return p.tile != 133 ? launch_lin<Tile<128, 128, 2, 2>, 3>(p, st) : launch_lin<Tile<128, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_F32_128X128: return launch<Tile<128, 128, 2, 2>, true>(p, st);
         case ONEDC_KERNEL_F32_64X128: return launch<Tile<64, 128, 2, 2>, true>(p, st);
+        case ONEDC_KERNEL_F32S_128X128: return launch<Tile<128, 128, 2, 2>, true, true>(p, st);
+        case ONEDC_KERNEL_F32S_64X128: return launch<Tile<64, 128, 2, 2>, true, true>(p, st);
 #ifdef EXP_TILES
         case 1000: return launch<Tile<128, 64, 4, 1>>(p, st);      // 48 KB: three workgroups per CU
         case 1001: return launch<Tile<64, 64, 4, 1>>(p, st);       // 32 KB: five

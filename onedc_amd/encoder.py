@@ -56,7 +56,7 @@ class VAEEncoder:
         # conv_in (3x3, 3 -> 128) on the exact-f32 matrix-core path: input channels zero-padded 3 -> 32
         wci = torch.zeros(128, 32, 3, 3)
         wci[:, :3] = sd["encoder.conv_in.weight"].float()
-        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["encoder.conv_in.bias"], f32=True, flop_scale=3 / 32)
+        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["encoder.conv_in.bias"], f32=True, exact=True, flop_scale=3 / 32)
         self.down = []
         for i in range(4):
             blk = {"res": [ResnetBlock2D(sd, f"encoder.down_blocks.{i}.resnets.{j}", device, 1e-6) for j in range(2)]}

@@ -353,15 +353,15 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
     p.KH = p.KW = KH
     p.stride, p.pad, p.up = stride, (KH // 2 if pad is None else pad), up
     p.epi, p.out_f32, p.pixel_shuffle = epi, int(y.f32), pixel_shuffle
-    p.in_f32 = int(x.f32)
+    p.in_f32 = 2 if (x.f32 and w.dtype == torch.float16) else int(x.f32)       # f16 "weights" of an f32 layer: the split form
     p.out_bf16 = int(bool(out_bf16))
     p.tile = tile
     if stats and y.stats is not None and not pixel_shuffle and batch <= 1 and y.co % 4 == 0 and y.C % 4 == 0:
         p.stats = y.stats.t.data_ptr()       # the epilogue leaves GroupNorm partial sums for the consumer
         p.stats_gran = y.stats.gran
         y.stats.mark(y.co, y.C)
-    if x.f32 and (w.dtype != torch.float32 or (res is not None and not res.f32)):
-        raise KernelError("f32 conv_gemm needs f32 weights and residual")
+    if x.f32 and (w.dtype not in (torch.float32, torch.float16) or (res is not None and not res.f32)):
+        raise KernelError("f32 conv_gemm needs f32 (or split-half) weights and an f32 residual")
     p.alpha, p.slope = alpha, slope
     p.batch, p.x_bs, p.w_bs, p.y_bs, p.r_bs = batch, x_bs, w_bs, y_bs, r_bs
     p.split_k = SPLIT_K

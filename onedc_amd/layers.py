@@ -66,13 +66,16 @@ class Workspace:
 
 USE_UPSAMPLE_PHASES = True    # tests switch it off to compare with the plain fused-upsample path
 FUSE_SHORTCUT = __import__("os").environ.get("ONEDC_FUSE_SHORTCUT", "1") != "0"   # ResnetBlock2D.conv_shortcut inside conv2's launch
+# f32 layers built while this is True compute on split operands (pairs of halves, 22 bits) at the 16-bit matrix rate; False: the
+# exact f32 matrix instructions (a fixed-order fp32 fma chain).  codec_module.IntraNoAR sets it from `prior_f32` while it builds.
+PRIOR_SPLIT16 = __import__("os").environ.get("ONEDC_PRIOR_SPLIT16", "1") != "0"
 
 
 class Conv:
     """nn.Conv2d / nn.Linear as one implicit-GEMM launch."""
 
     def __init__(self, sd, name, device, *, perm=None, glu=False, shuffle=False, weight=None, bias=None,
-                 flop_scale=1.0, f32=False, upsample=False):
+                 flop_scale=1.0, f32=False, upsample=False, exact=False):
         self.flop_scale = flop_scale          # < 1 when rows/cols are zero padding (padded heads)
         self.f32 = f32                        # exact-f32 path: f32 weights, activations, output
         w = sd[f"{name}.weight"] if weight is None else weight
@@ -84,7 +87,13 @@ class Conv:
             perm = pack.glu_perm(self.cout // 2)
         elif shuffle:
             perm = pack.shuffle_perm(self.cout)
-        self.w = pack.pack_matrix(m, device, perm, torch.float32 if f32 else K.a16())
+        # f32 layers (the prior side): PRIOR_SPLIT16 -> weights as pairs of halves, products on the 16-bit matrix cores with
+        # f32 activations and accumulation (onedc_conv_params.in_f32 == 2); exact=True keeps the f32 matrix instructions
+        self.split16 = bool(f32 and PRIOR_SPLIT16 and not exact and self.cin % 32 == 0)
+        if self.split16:
+            self.w = pack.pack_matrix_split16(m, device, perm)
+        else:
+            self.w = pack.pack_matrix(m, device, perm, torch.float32 if f32 else K.a16())
         self.b = pack.f32(b, device, perm)
         self.glu, self.shuffle = glu, shuffle
         # conv behind a nearest x2 upsample: also keep the four 2x2 phase convolutions (2.25x fewer MACs); used

@@ -84,7 +84,7 @@ class SD15_1step_codec_stage1:
         alpha = _get(lc, "lora_alpha", 8.0)
         with torch.cuda.device(self.device):
             self.feedforward_model = UNet(feedforward_sd, self.device, rank, alpha)
-            self.codec_model = IntraNoAR(codec_sd, self.device, prior_f32=bool(_get(self.args, "prior_f32", True)),
+            self.codec_model = IntraNoAR(codec_sd, self.device, prior_f32=_get(self.args, "prior_f32", True),
                                          prior_arith=_get(self.args, "prior_arith", "auto") or "auto",
                                          ref_threads=_get(self.args, "ref_threads", None),
                                          ref_profile=_get(self.args, "ref_profile", None))

@@ -49,6 +49,31 @@ def pack_matrix(w2d, device, row_perm=None, dtype=None):
     return _pad_rows(w2d.contiguous()).to(dtype).to(device).contiguous()
 
 
+SPLIT16_SCALE = 2048.0          # 2^11: the low half of a split operand is stored times this (csrc/gemm_conv.hip, SPLIT)
+
+
+def split16_slot_order():
+    """Channel held by slot s (0..31) of a 32-channel K-step in the split form: the lane group fq = s // 8 of the matrix
+    instruction reads the f32 chunks fq and 4 + fq of the activation row, i.e. channels 4 fq .. 4 fq + 3 and 16 + 4 fq .."""
+    return torch.tensor([(4 * (s // 8) + s % 8) if s % 8 < 4 else (16 + 4 * (s // 8) + s % 8 - 4) for s in range(32)])
+
+
+def pack_matrix_split16(w2d, device, row_perm=None):
+    """[rows][K] f32 (K % 32 == 0) -> the split form of onedc_conv_params.in_f32 == 2: every weight as a pair of IEEE halves
+    w = h + l * 2^-11 (h = half(w), l = half((w - h) * 2^11): 22 significant bits), per row and 32-channel block 32 halves h
+    followed by 32 halves l, channels in the kernel's slot order -- the same 128 bytes per block an f32 row has.
+    Returns a float16 tensor [rows padded to 128][2 K]."""
+    if row_perm is not None:
+        w2d = w2d[row_perm]
+    w = _pad_rows(w2d.contiguous().float())
+    rows, K = w.shape
+    assert K % 32 == 0, K
+    blocks = w.view(rows, K // 32, 32)[:, :, split16_slot_order()]
+    h = blocks.to(torch.float16)
+    l = ((blocks - h.float()) * SPLIT16_SCALE).to(torch.float16)
+    return torch.cat([h, l], dim=2).reshape(rows, 2 * K).to(device).contiguous()
+
+
 def conv_matrix(w):
     """(Cout, Cin, KH, KW) or (Cout, Cin) -> [Cout][KH*KW*Cin] with k = (ky, kx, cin)."""
     if w.dim() == 2:

@@ -45,7 +45,7 @@ class VAEDecoder:
         # conv_in (3x3, 4 -> 512) on the exact-f32 matrix-core path: input channels zero-padded 4 -> 32
         wci = torch.zeros(512, 32, 3, 3)
         wci[:, :4] = sd["decoder.conv_in.weight"].float()
-        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["decoder.conv_in.bias"] * s, f32=True, flop_scale=4 / 32)
+        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["decoder.conv_in.bias"] * s, f32=True, exact=True, flop_scale=4 / 32)     # (x0 may exceed the half range: exact f32)
         self.mid_res = [ResnetBlock2D(sd, f"decoder.mid_block.resnets.{j}", device, 1e-6, s) for j in range(2)]
         self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6 * s * s)
         self.attn = SingleHeadAttention(sd, (f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{a}.to_out.0"), device, 512)

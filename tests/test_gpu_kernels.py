@@ -1267,3 +1267,67 @@ def test_conv_lin_kernel_batched_and_dispatch():
     assert K.conv_kernel_name(p) == "lin_128x128"
     p.Cout = p.y_cs = 320
     assert K.conv_kernel_name(p) == "64x128"
+
+
+# ---- round 4: the f32 path on split operands (pairs of halves, 16-bit matrix rate) ---------------------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,scale", [
+    (2, 12, 12, 128, 128, 1, 1.0),
+    (1, 9, 7, 96, 256, 3, 1.0),           # Cin = 3 x 32, odd spatial size
+    (3, 8, 8, 256, 512, 1, 1.0),
+    (2, 16, 16, 256, 256, 1, 300.0),      # activations in the hundreds (the random-init prior reaches 540)
+    (2, 16, 16, 256, 256, 1, 1e-4),       # ... and tiny ones (low halves in the subnormal range)
+])
+def test_conv_gemm_f32_split16(B, H, W, Cin, Cout, k, scale):
+    """onedc_conv_params.in_f32 == 2: f32 activations, weights and activations as pairs of halves (22 bits), three f16 MFMAs
+    per 32 channels, f32 accumulation -- against an fp64 convolution at the tolerance of the exact-f32 kernel, against that
+    kernel itself, bit-identical between the two tile shapes and between a picture alone and inside a batch."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, W, generator=g) * scale
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5
+    b = torch.randn(Cout, generator=g) * scale
+    r = torch.randn(B, Cout, H, W, generator=g) * scale
+    xv, rv = from_nchw(x.to(DEV), torch.float32), from_nchw(r.to(DEV), torch.float32)
+    ws = pack.pack_matrix_split16(pack.conv_matrix(w), DEV)
+    wf = pack.pack_matrix(pack.conv_matrix(w), DEV, None, torch.float32)
+    outs = {}
+    for name, wt, tile in (("split", ws, 0), ("split128", ws, 128), ("exact", wf, 0)):
+        y = new_view(B, H, W, Cout, DEV, torch.float32)
+        K.conv_gemm(xv, wt, b.to(DEV), y, KH=k, epi=K.EPI_LEAKY, slope=0.01, res=rv, tile=tile)
+        outs[name] = y.torch_nchw()
+    ref = F.leaky_relu(_f64_conv(x, w, b, padding=k // 2), 0.01) + r.double()
+    close(outs["split"], ref, rms=2e-6, mx=2e-6, what="split f32 conv")
+    close(outs["split"], outs["exact"], rms=1e-6, mx=2e-6, what="split vs exact f32 conv")
+    assert torch.equal(outs["split"], outs["split128"])
+    y1 = new_view(1, H, W, Cout, DEV, torch.float32)
+    K.conv_gemm(from_nchw(x[-1:].to(DEV), torch.float32), ws, b.to(DEV), y1, KH=k, epi=K.EPI_LEAKY, slope=0.01,
+                res=from_nchw(r[-1:].to(DEV), torch.float32))
+    assert torch.equal(y1.torch_nchw(), outs["split"][-1:])
+
+
+def test_conv_gemm_f32_split16_glu_shuffle_and_accuracy_against_the_exact_kernel():
+    g = torch.Generator().manual_seed(32)
+    B, H, W, C = 2, 6, 10, 128
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(4 * C, C, 1, 1, generator=g) * C ** -0.5
+    b = torch.randn(4 * C, generator=g)
+    xv = from_nchw(x.to(DEV), torch.float32)
+    perm = pack.glu_perm(2 * C)
+    y = new_view(B, H, W, 2 * C, DEV, torch.float32)
+    K.conv_gemm(xv, pack.pack_matrix_split16(pack.conv_matrix(w), DEV, perm), b[perm].to(DEV), y, KH=1, epi=K.EPI_GLU_LEAKY)
+    t = _f64_conv(x, w, b)
+    close(y.torch_nchw(), F.leaky_relu(t[:, :2 * C], 0.1) + F.leaky_relu(t[:, 2 * C:], 0.01), rms=2e-6, mx=2e-6, what="split glu")
+    perm = pack.shuffle_perm(4 * C)
+    y = new_view(B, 2 * H, 2 * W, C, DEV, torch.float32)
+    K.conv_gemm(xv, pack.pack_matrix_split16(pack.conv_matrix(w), DEV, perm), b[perm].to(DEV), y, KH=1, pixel_shuffle=1)
+    close(y.torch_nchw(), F.pixel_shuffle(t, 2), rms=2e-6, mx=2e-6, what="split pixel shuffle")
+    # error of the two f32 forms against fp64 on a long sum: the split form is not the worse one by more than a factor 2
+    xl = torch.randn(1, 512, 16, 16, generator=g)
+    wl = torch.randn(256, 512, 1, 1, generator=g) / 512 ** 0.5
+    ref = _f64_conv(xl, wl, None)
+    errs = {}
+    for name, wt in (("split", pack.pack_matrix_split16(pack.conv_matrix(wl), DEV)), ("exact", pack.pack_matrix(pack.conv_matrix(wl), DEV, None, torch.float32))):
+        yl = new_view(1, 16, 16, 256, DEV, torch.float32)
+        K.conv_gemm(from_nchw(xl.to(DEV), torch.float32), wt, None, yl, KH=1)
+        errs[name] = float((yl.torch_nchw().double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"[split16] rel. RMS error against fp64, K = 512: split {errs['split']:.2e}, exact f32 chain {errs['exact']:.2e}")
+    assert errs["split"] <= max(2 * errs["exact"], 3e-7)

