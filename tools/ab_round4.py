@@ -90,6 +90,30 @@ def main():
               f"stores) {t['r3'] * 1e3:7.1f} us | 64-ch steps + line stores {t['k64'] * 1e3:7.1f} | 32-ch ring + line stores {t['k32'] * 1e3:7.1f} | 3-stage ring, 3 WG/CU {t['k32x3'] * 1e3:7.1f} | "
               f"auto / round 3 {t['auto'] / t['r3']:.3f}", flush=True)
         del x, r, y, w
+    print("== prior-side GEMMs (f32 activations, 48x48, B = 16): exact f32 MFMA against split-half operands, 64-row and 128-row tiles")
+    for Cin, Cout, epi, res in ((256, 256, K.EPI_LEAKY, False), (256, 256, K.EPI_LINEAR, True), (256, 1024, K.EPI_GLU_LEAKY, False),
+                                (512, 256, K.EPI_LINEAR, True), (128, 128, K.EPI_LEAKY, False), (128, 512, K.EPI_GLU_LEAKY, False),
+                                (256, 128, K.EPI_LINEAR, False)):
+        B, H = 16, 48
+        glu = epi == K.EPI_GLU_LEAKY
+        x = K.new_view(B, H, H, Cin, DEV, torch.float32)
+        x.t.normal_()
+        cs = Cout // 2 if glu else Cout
+        r = K.new_view(B, H, H, cs, DEV, torch.float32)
+        r.t.normal_()
+        wm = torch.randn(Cout, Cin, generator=g, device=DEV) * Cin ** -0.5
+        perm = pack.glu_perm(Cout // 2).to(DEV) if glu else None
+        wf = pack.pack_matrix(wm, DEV, perm, torch.float32)
+        ws = pack.pack_matrix_split16(wm, DEV, perm)
+        y = K.new_view(B, H, H, cs, DEV, torch.float32)
+
+        def run(wt, tile):
+            K.conv_gemm(x, wt, None, y, KH=1, epi=epi, res=r if res else None, tile=tile)
+        t = timed({"exact": lambda: run(wf, 0), "exact128": lambda: run(wf, 128), "split": lambda: run(ws, 0), "split128": lambda: run(ws, 128)}, 40)
+        fl = 2.0 * B * H * H * Cout * Cin
+        print(f"1x1 {Cin}->{Cout} epi{epi} res={int(res)}: exact {t['exact'] * 1e3:6.1f} us (128-row {t['exact128'] * 1e3:6.1f}) | split auto "
+              f"{t['split'] * 1e3:6.1f} us {fl / t['split'] / 1e9:6.1f} TF | split 128-row {t['split128'] * 1e3:6.1f} us | split / exact {t['split'] / t['exact']:.3f}", flush=True)
+        del x, r, y, wf, ws
     print("== conv_shortcut as a second source of conv2")
     for B, H, Cin, Cout, Cin2, gn in ((16, 768, 128, 128, 256, True), (16, 384, 256, 256, 512, False), (16, 96, 320, 320, 960, False),
                                       (16, 96, 320, 320, 640, False), (16, 48, 640, 640, 1920, False), (16, 48, 640, 640, 960, False)):
