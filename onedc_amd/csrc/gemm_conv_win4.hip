@@ -659,8 +659,11 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 // Layers of the window kernel (onedc_conv_win_ok) whose epilogue is the fast linear one on whole 64-channel wave tiles;
 // with gn_ab, room for the image's (a, b) pairs behind the ring while two workgroups still fit a CU.
 bool onedc_conv_win4_ok(const onedc_conv_params &p) {
+    // (second source: 32-bit byte offsets inside one image of x2, like the window's own -- a bigger image, e.g. 256 channels
+    // at 3072 x 3072, is refused here and the caller runs the shortcut as its own launch)
     if (p.x2 && (!p.w2 || p.Cin2 < 32 || (p.Cin2 & 31) || ((p.x2_cs | p.x2_co) & 7) || p.stride != 1 ||
-                 (int64_t)((p.Cout + 127) / 128 * 128) * p.Cin2 * 2 > 0x7fffffffll))
+                 (int64_t)((p.Cout + 127) / 128 * 128) * p.Cin2 * 2 > 0x7fffffffll ||
+                 (int64_t)p.OH * p.OW * p.x2_cs * 2 >= 0xfffff000ll))
         return false;
     return !p.up && conv_epi_fast_ok(p, false) && p.epi == ONEDC_EPI_LINEAR && (p.Cout & 63) == 0 &&
            ((p.y_cs | p.y_co) & 7) == 0 && (!p.res || ((p.r_cs | p.r_co) & 3) == 0) &&

@@ -8,7 +8,10 @@
 namespace {
 
 constexpr int GN_GROUPS = 32;
-constexpr int GN_PPC = 1024;  // pixels per partial-sum chunk
+// pixels per partial-sum chunk: a function of the map size ONLY (never of B: an image's sums are added in the same order alone
+// and inside a batch).  Round 4: small maps get small chunks -- the UNet's 12x12 level was ONE block per image whose threads walked
+// 144 pixels one dependent load after the other (51 us per launch, 27 launches per decode); now 9 blocks per image.
+__host__ __device__ constexpr int gn_ppc(int HW) { return HW <= 1024 ? 16 : (HW <= 16384 ? 128 : 1024); }
 
 __device__ __forceinline__ void unpack8(const uint4 &v, float *f) {
     f[0] = a2f((a16_t)(v.x & 0xffff)); f[1] = a2f((a16_t)(v.x >> 16));
@@ -20,7 +23,7 @@ __device__ __forceinline__ uint4 pack8(const float *f) {
     return make_uint4(pack_a2(f[0], f[1]), pack_a2(f[2], f[3]), pack_a2(f[4], f[5]), pack_a2(f[6], f[7]));
 }
 
-// stage 1: block (chunk, b) sums x and x^2 per group over GN_PPC pixels.
+// stage 1: block (chunk, b) sums x and x^2 per group over gn_ppc(HW) pixels.
 // threads = CC * PL with CC = C/8 channel chunks and PL pixel lanes.
 __global__ void gn_partial_kernel(const a16_t *__restrict__ x, float *__restrict__ part, int HW, int C,
                                   int cs, int co, int CC, int PL, int nchunk) {
@@ -28,8 +31,8 @@ __global__ void gn_partial_kernel(const a16_t *__restrict__ x, float *__restrict
     const int t = threadIdx.x;
     const int cc = t % CC, pl = t / CC;
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int p0 = chunk * GN_PPC;
-    const int p1 = min(p0 + GN_PPC, HW);
+    const int p0 = chunk * gn_ppc(HW);
+    const int p1 = min(p0 + gn_ppc(HW), HW);
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
@@ -305,7 +308,7 @@ __global__ void softmax_rows_any_kernel(const float *__restrict__ s, a16_t *__re
 
 extern "C" {
 
-int onedc_gn_chunks(int HW) { return (HW + GN_PPC - 1) / GN_PPC; }
+int onedc_gn_chunks(int HW) { return (HW + gn_ppc(HW) - 1) / gn_ppc(HW); }
 
 int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *partial, float *ab, int B,
                    int HW, int C, int x_cs, int x_co, float eps, void *stream) {
