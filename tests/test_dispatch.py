@@ -55,9 +55,53 @@ def test_window_layers_go_to_the_4wave_kernel_where_its_epilogue_applies(fmt):
 def test_layers_no_window_kernel_takes():
     assert name(params(H=24, W=24, Cin=1280, Cout=1280, B=16)) == "256x256"          # map is not whole 16x16 patches
     assert name(params(H=12, W=12, Cin=1280, Cout=1280, B=16)) == "64x128"           # 2304 pixels: a small grid
-    assert name(params(k=1, H=96, W=96, Cin=320, Cout=2560, B=16)) == "128x128"      # short K: the 4-wave kernels
+    assert name(params(k=1, H=96, W=96, Cin=320, Cout=2560, B=16)) == "lin_128x128"  # K <= 384, wide output: three-stage ring, 3 workgroups per CU
+    assert name(params(k=1, H=96, W=96, Cin=320, Cout=320, B=16)) == "64x128"        # ... narrow output: the 64-row tile
+    assert name(params(k=1, H=48, W=48, Cin=640, Cout=5120, B=16)) == "128x128"      # short K: the 4-wave kernels
+    assert name(params(k=1, H=24, W=24, Cin=1280, Cout=1280, B=16)) == "128x128"     # 20 K-tiles: four waves since round 4
+    assert name(params(k=1, H=24, W=24, Cin=5120, Cout=1280, B=16)) == "256x256"     # 80 K-tiles: eight
+    assert name(params(k=1, H=96, W=96, Cin=320, Cout=2560, B=16, tile=133)) == "lin_128x128"
+    assert name(params(k=1, H=96, W=96, Cin=320, Cout=2560, B=16, tile=128)) == "128x128"
     assert name(params(k=1, H=48, W=48, Cin=256, Cout=256, B=16, in_f32=1, out_f32=1)).startswith("f32_")
+    assert name(params(k=1, H=48, W=48, Cin=256, Cout=256, B=16, in_f32=2, out_f32=1)).startswith("f32s_")   # split-half operands
     assert name(params(Cout=3)) == "16x256"                                           # conv_out-like
+
+
+def test_split_k_is_a_function_of_the_layer_shape():
+    """3x3 layers on maps of <= 256 pixels with >= 160 K-tiles (the UNet's 12x12 level) are split into five K ranges whatever
+    the batch size, when the caller brings the scratch the dispatcher asks for; never by B, never without scratch."""
+    lib = K.lib()
+    for B in (1, 2, 16):
+        p = params(H=12, W=12, Cin=1280, Cout=1280, B=B)
+        need = lib.onedc_conv_splitk_ws_bytes(C.byref(p))
+        assert need == 5 * B * 144 * 1280 * 4
+        assert name(p) == "64x128"                                                    # no scratch: the unsplit kernels
+        p.ws, p.ws_bytes = C.cast(C.create_string_buffer(64), C.c_void_p), need
+        assert name(p) == "splitk_256"
+        p.split_k = 1
+        assert name(p) == "64x128"
+    assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(H=24, W=24, Cin=1280, Cout=1280, B=16))) == 0     # 576 pixels per image
+    assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(H=12, W=12, Cin=320, Cout=1280, B=16))) == 0       # 45 K-tiles
+    assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(k=1, H=12, W=12, Cin=5120, Cout=1280, B=16))) == 0  # 1x1
+
+
+def test_second_source_question():
+    """conv_shortcut as a second source: taken where the layer runs on the 4-wave window kernel, refused elsewhere (the caller
+    then launches the shortcut itself)."""
+    lib = K.lib()
+    dummy = C.cast(C.create_string_buffer(64), C.c_void_p)
+
+    def with_x2(p, Cin2=256, cs=None):
+        p.x2, p.w2, p.Cin2, p.x2_cs, p.x2_co = dummy, dummy, Cin2, cs or Cin2, 0
+        return p
+    assert lib.onedc_conv_win_takes_x2(C.byref(with_x2(params()))) == 1
+    assert name(with_x2(params())) == "win3x3_4w"
+    assert lib.onedc_conv_win_takes_x2(C.byref(with_x2(params(gn=True)))) == 1                 # GroupNorm on load too
+    assert lib.onedc_conv_win_takes_x2(C.byref(with_x2(params(H=12, W=12)))) == 0              # not whole patches
+    assert lib.onedc_conv_win_takes_x2(C.byref(with_x2(params(epi=K.EPI_SILU)))) == 0          # 8-wave kernel's layer
+    assert lib.onedc_conv_win_takes_x2(C.byref(with_x2(params(), Cin2=48))) == 0               # not whole 32-channel chunks
+    assert lib.onedc_conv_win_takes_x2(C.byref(with_x2(params(B=1, H=3072, W=3072), Cin2=256))) == 0   # 4.8 GB per image of x2
+    assert name(with_x2(params(H=12, W=12))) == -16
 
 
 def test_window_kernels_refuse_images_beyond_their_32bit_window_offsets():
