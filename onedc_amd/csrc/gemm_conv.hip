@@ -644,13 +644,13 @@ static int conv_choose(const onedc_conv_params &p) {
     // families give identical bits
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);
     constexpr int kLongK = 32;
-    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 134 && p.tile != 136 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= kLongK) || p.tile == 256) &&
+    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 134 && (p.Cout % 256) == 0 && ((blocks256 >= 160 && ktiles >= kLongK) || p.tile == 256) &&
         !(p.stats && p.stats_gran == 2))           // the 256x256 kernel only leaves quad statistics
         return ONEDC_KERNEL_256X256;
     // 128 x 256 tiles (8 waves, 3-deep LDS ring): channel counts that are whole 128-row tiles or waste < 20 %
     const int rows128 = (p.Cout + 127) / 128 * 128;
     const int64_t blocks128 = (rows128 / 128) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
-    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 134 && p.tile != 136 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
+    if (p.tile != 128 && p.tile != 132 && p.tile != 133 && p.tile != 134 && p.tile != 256 && !(p.Cout <= 16 && !glu) && rows128 * 5 <= p.Cout * 6 &&
         ((blocks128 >= 160 && ktiles >= kLongK) || p.tile == 129))
         return ONEDC_KERNEL_128X256;
     if (p.Cout <= 16 && !glu) return ONEDC_KERNEL_16X256;
@@ -667,7 +667,7 @@ static int conv_choose(const onedc_conv_params &p) {
     // ... except its THREE-stage form on the 128 x 128 tile (48 KB: three workgroups per CU instead of two) for K <= 384, the
     // level-0 Linear layers with wide outputs, whose life is prologue + epilogue and wants one more resident workgroup:
     // to_q|k 320 -> 1024 at 96x96 211 -> 182 us, GEGLU 320 -> 2560 397 -> 368, to_q 320 -> 512 88 -> 80; level from K = 640 on.
-    const bool lin = conv_lin_ok(p) && (p.tile == 133 || p.tile == 134 || (p.tile == 136 && p.Cout == 320));
+    const bool lin = conv_lin_ok(p) && (p.tile == 133 || p.tile == 134);
     const bool lin3 = conv_lin_ok(p) && p.tile == 0 && p.Cin <= 384;
     if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))
         return lin ? ONEDC_KERNEL_LIN_64X128 : ONEDC_KERNEL_64X128;
@@ -722,7 +722,6 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
         case ONEDC_KERNEL_64X128: return launch<Tile<64, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_128X128: return launch<Tile<128, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_LIN_64X128:
-            if (p.tile == 136) return launch_lin<Tile<320, 64, 4, 1>, 3>(p, st);       // (experiment) all 320 channels in one workgroup
             return p.tile == 134 ? launch_lin<Tile<64, 128, 2, 2>, 3>(p, st) : launch_lin<Tile<64, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_LIN_128X128:
             return p.tile != 133 ? launch_lin<Tile<128, 128, 2, 2>, 3>(p, st) : launch_lin<Tile<128, 128, 2, 2>>(p, st);

@@ -84,12 +84,7 @@ def main():
 
         def run(tile):
             K.conv_gemm(x, w, None, y, KH=1, epi=epi, res=r if res else None, tile=tile)
-        variants = {"auto": lambda: run(0), "r3": lambda: run(132), "k64": lambda: run(128), "k32": lambda: run(133), "k32x3": lambda: run(134)}
-        if Cout == 320:
-            variants["t320"] = lambda: run(136)
-        t = timed(variants, 40)
-        if Cout == 320:
-            print(f"    (experiment) all 320 channels in one workgroup, 320 x 64 tile: {t['t320'] * 1e3:7.1f} us")
+        t = timed({"auto": lambda: run(0), "r3": lambda: run(132), "k64": lambda: run(128), "k32": lambda: run(133), "k32x3": lambda: run(134)}, 40)
         fl = 2.0 * B * H * H * Cout * Cin
         print(f"{H}^2 1x1 {Cin}->{Cout} epi{epi} res={int(res)}: auto {t['auto'] * 1e3:7.1f} us {fl / t['auto'] / 1e9:7.1f} TF | round 3 (scattered "
               f"stores) {t['r3'] * 1e3:7.1f} us | 64-ch steps + line stores {t['k64'] * 1e3:7.1f} | 32-ch ring + line stores {t['k32'] * 1e3:7.1f} | 3-stage ring, 3 WG/CU {t['k32x3'] * 1e3:7.1f} | "
