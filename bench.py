@@ -692,8 +692,12 @@ def main():
                          "algorithmic_bytes_per_launch": round(dom_bytes / launches),
                          "mfma_util_pmc": mfma_util,      # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024), profiles/r3_pmc_mfma.json
                          "kernel": kernel_symbol,
+                         # per family: TFLOP/s against the MFMA peak AND algorithmic bytes per second against the 6.3 TB/s a streaming
+                         # kernel reaches (MI355X_MICROARCH.md): the short-K Linear layers are bound by the second, not the first
                          "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms_per_step": round(v[1] / all_steps * 1e3, 2),
-                                           "launches_per_step": v[2] // all_steps} for k, v in sorted(by_all.items())},
+                                           "launches_per_step": v[2] // all_steps, "algorithmic_tb_per_s": round(v[3] / v[1] / 1e12, 2),
+                                           "frac_of_mfma_peak": round(v[0] / v[1] / 1e12 / PEAK_MFMA16_TFLOPS, 3),
+                                           "frac_of_hbm_stream": round(v[3] / v[1] / 6.3e12, 3)} for k, v in sorted(by_all.items())},
                          "by_kernel_from": by_from + ("; the timed region carries events on the dominant family only"
                                                       if prof_warm else ""),
                          "launches_per_step": launches // args.steps,
