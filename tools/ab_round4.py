@@ -104,16 +104,16 @@ def main():
         wm = torch.randn(Cout, Cin, generator=g, device=DEV) * Cin ** -0.5
         perm = pack.glu_perm(Cout // 2).to(DEV) if glu else None
         wf = pack.pack_matrix(wm, DEV, perm, torch.float32)
-        ws = pack.pack_matrix_split16(wm, DEV, perm)
+        wsp = pack.pack_matrix_split16(wm, DEV, perm)
         y = K.new_view(B, H, H, cs, DEV, torch.float32)
 
         def run(wt, tile):
             K.conv_gemm(x, wt, None, y, KH=1, epi=epi, res=r if res else None, tile=tile)
-        t = timed({"exact": lambda: run(wf, 0), "exact128": lambda: run(wf, 128), "split": lambda: run(ws, 0), "split128": lambda: run(ws, 128)}, 40)
+        t = timed({"exact": lambda: run(wf, 0), "exact128": lambda: run(wf, 128), "split": lambda: run(wsp, 0), "split128": lambda: run(wsp, 128)}, 40)
         fl = 2.0 * B * H * H * Cout * Cin
         print(f"1x1 {Cin}->{Cout} epi{epi} res={int(res)}: exact {t['exact'] * 1e3:6.1f} us (128-row {t['exact128'] * 1e3:6.1f}) | split auto "
               f"{t['split'] * 1e3:6.1f} us {fl / t['split'] / 1e9:6.1f} TF | split 128-row {t['split128'] * 1e3:6.1f} us | split / exact {t['split'] / t['exact']:.3f}", flush=True)
-        del x, r, y, wf, ws
+        del x, r, y, wf, wsp
     print("== conv_shortcut as a second source of conv2")
     for B, H, Cin, Cout, Cin2, gn in ((16, 768, 128, 128, 256, True), (16, 384, 256, 256, 512, False), (16, 96, 320, 320, 960, False),
                                       (16, 96, 320, 320, 640, False), (16, 48, 640, 640, 1920, False), (16, 48, 640, 640, 960, False)):

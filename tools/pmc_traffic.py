@@ -10,13 +10,20 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(conv_gemm_kernel)<.*Tile<(\d+), (\d+).*?>, (true|false)>", name)
+    # conv_gemm_kernel<Tile<TM, TN, ..>, F32, SPLIT>: 16-bit / exact f32 / split-half operands are three different kernels
+    m = re.search(r"(conv_gemm_kernel)<.*Tile<(\d+), (\d+).*?>, (true|false)(?:, (true|false))?>", name)
     if m:
-        return f"conv_gemm_kernel<{m.group(2)}x{m.group(3)}>" + (" f32" if m.group(4) == "true" else "")
-    m = re.search(r"conv_win4_kernel<(\d), \d>", name)
-    if m:                                            # MODE 2 = the upsample phases: their own row (4/9 of the taps, x4 outputs)
+        return (f"conv_gemm_kernel<{m.group(2)}x{m.group(3)}>"
+                + (" f32s" if m.group(5) == "true" else " f32" if m.group(4) == "true" else ""))
+    m = re.search(r"(conv_lin_kernel)<.*Tile<(\d+), (\d+).*?>, (\d)>", name)
+    if m:
+        return f"conv_lin_kernel<{m.group(2)}x{m.group(3)}, {m.group(4)} stages>"
+    # conv_win4_kernel<MODE, ST, X2>: MODE 2 = the upsample phases, their own row (4/9 of the taps, x4 outputs); MODE 0 / 1 with
+    # or without a second source are the family bench.py's roofline object is about
+    m = re.search(r"conv_win4_kernel<(\d), \d(?:, (?:true|false))?>", name)
+    if m:
         return "conv_win4_kernel" + ("<ups>" if m.group(1) == "2" else "")
-    m = re.search(r"(conv_win_kernel)<(true|false)>", name)
+    m = re.search(r"(conv_win_kernel)<(true|false)(?:, (?:true|false))?>", name)
     if m:
         return "conv_win_kernel" + ("<up>" if m.group(2) == "true" else "")
     m = re.search(r"::(\w+?)(_kernel)?[<(]", name)

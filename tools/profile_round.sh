@@ -25,11 +25,11 @@ rm -rf "$out/seqprof"
 [ -x tools/micro/mfma_rate ] && timeout 120 tools/micro/mfma_rate > "$out/mfma_rate.txt" 2>&1 < /dev/null
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$root/$out/pmc_mfma" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_mfma.err" < /dev/null; echo "pmc mfma rc=$?" )
 m=$(find "$out/pmc_mfma" -name "*counter_collection.csv" < /dev/null | head -1)
-if [ -n "$m" ]; then ( cd tools && python3 pmc_mfma.py "$root/$m" "$root/$out/pmc_mfma.json" "folded on the box" < /dev/null ); fi
+if [ -n "$m" ]; then ( cd tools && python3 pmc_mfma.py "$root/$m" "$root/$out/pmc_mfma.json" "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, tools/profile_round.sh) over python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential; util = busy cycles of all SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs). Folded by tools/pmc_mfma.py on the box." < /dev/null ); fi
 rm -rf "$out/pmc_mfma"
 f=$(find "$out/pmc_FETCH_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
 w=$(find "$out/pmc_WRITE_SIZE" -name "*counter_collection.csv" < /dev/null | head -1)
-if [ -n "$f" ] && [ -n "$w" ]; then python3 tools/pmc_traffic.py "$f" "$w" "$out/pmc_traffic.json" "folded on the box" < /dev/null; fi
+if [ -n "$f" ] && [ -n "$w" ]; then python3 tools/pmc_traffic.py "$f" "$w" "$out/pmc_traffic.json" "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, tools/profile_round.sh) over python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential (stream setup + one decode of 16 768x768 pictures), f16 activations. Counter unit KiB. hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced / LDS-DMA reads on gfx950; WRITE_SIZE exact. Per launch = sum over the run / launches in the run; conv_win4_kernel = MODE 0 and 1 with or without a second source (the launches bench.py's roofline object is about), conv_win4_kernel<ups> = MODE 2. Folded by tools/pmc_traffic.py on the box." < /dev/null; fi
 rm -rf "$out/prof" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"
 ls -la "$out" < /dev/null
 # round 4: per-layer tables, the A/B of the round's kernel forms, the tile sweep of the UNet's 1x1 shapes
