@@ -564,8 +564,8 @@ static bool conv_win_wanted(const onedc_conv_params &p) {
            rows128w * 5 <= p.Cout * 6;
 }
 
-// Split-K (gemm_conv256.hip): 3x3 layers on maps of at most 256 pixels with whole 256-channel tiles and >= 160 K-tiles -- the
-// UNet's 12x12 level.  Decided by the layer's SHAPE alone (not by B: determinism rule of the path), five K ranges
+// Split-K (gemm_conv256.hip): 3x3 layers on maps of at most 256 pixels with whole 256-channel tiles and >= 96 K-tiles -- the
+// UNet's 12x12 level and the codec's 768-channel layers at the same resolution.  Decided by the layer's SHAPE alone (not by B: determinism rule of the path), five K ranges
 // (1280 -> 1280: 36 K-tiles each, 2560 -> 1280: 72; 45 x 5 = 225 workgroups per batch of 16).  0: not split.
 static int conv_splitk_parts(const onedc_conv_params &p) {
     if (p.split_k == 1 || p.in_f32 || p.batch > 1 || p.stats || p.gn_ab || p.x2 || p.pixel_shuffle || p.out_bf16 || p.up ||
@@ -574,8 +574,10 @@ static int conv_splitk_parts(const onedc_conv_params &p) {
         ((p.y_cs | p.y_co) & 3) || (p.res && ((p.r_cs | p.r_co) & 3)))
         return 0;
     const int ktiles = p.KH * p.KW * (p.Cin >> 6);
-    const int parts = p.split_k > 1 ? p.split_k : 5;
-    if (ktiles < 160 && p.split_k <= 1) return 0;
+    // from 96 K-tiles on in four ranges: the codec's 768 -> 768 layers at 1/64 resolution (SemanticAdaptor / synthesis, 108
+    // K-tiles, 27 tiles of 256 x 256 per batch of 16: 130 us on 216 tiles of the 4-wave kernel)
+    const int parts = p.split_k > 1 ? p.split_k : ktiles >= 160 ? 5 : 4;
+    if (ktiles < 96 && p.split_k <= 1) return 0;
     if (ktiles < 4 * parts) return 0;
     return parts;
 }

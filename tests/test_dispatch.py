@@ -68,8 +68,8 @@ def test_layers_no_window_kernel_takes():
 
 
 def test_split_k_is_a_function_of_the_layer_shape():
-    """3x3 layers on maps of <= 256 pixels with >= 160 K-tiles (the UNet's 12x12 level) are split into five K ranges whatever
-    the batch size, when the caller brings the scratch the dispatcher asks for; never by B, never without scratch."""
+    """3x3 layers on maps of <= 256 pixels with >= 160 K-tiles (the UNet's 12x12 level) are split into five K ranges (four from 96
+    K-tiles on: the codec's 768-channel layers) whatever the batch size, when the caller brings the scratch the dispatcher asks for; never by B, never without scratch."""
     lib = K.lib()
     for B in (1, 2, 16):
         p = params(H=12, W=12, Cin=1280, Cout=1280, B=B)
@@ -80,6 +80,8 @@ def test_split_k_is_a_function_of_the_layer_shape():
         assert name(p) == "splitk_256"
         p.split_k = 1
         assert name(p) == "64x128"
+    assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(H=12, W=12, Cin=768, Cout=768, B=16))) == 4 * 16 * 144 * 768 * 4   # 108 K-tiles
+    assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(H=12, W=12, Cin=512, Cout=768, B=16))) == 0       # 72 K-tiles
     assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(H=24, W=24, Cin=1280, Cout=1280, B=16))) == 0     # 576 pixels per image
     assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(H=12, W=12, Cin=320, Cout=1280, B=16))) == 0       # 45 K-tiles
     assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(k=1, H=12, W=12, Cin=5120, Cout=1280, B=16))) == 0  # 1x1

@@ -1072,7 +1072,7 @@ def test_group_norm_pair_statistics_320_and_960_channels(tile):
 
 
 # ---- round 4: split-K for the 12x12 level, conv_shortcut as a second source of the window kernel ------------------------
-@pytest.mark.parametrize("Cin,Cout,res", [(1280, 1280, True), (2560, 1280, False), (1280, 256, True)])
+@pytest.mark.parametrize("Cin,Cout,res", [(1280, 1280, True), (2560, 1280, False), (1280, 256, True), (768, 768, True)])
 def test_conv_splitk_small_maps(Cin, Cout, res):
     """3x3 layers of the UNet's 12x12 level (decoder_unet.py:204-293) on the split-K form: against F.conv2d, against the
     unsplit kernels, the same bits on every launch, and a picture alone == inside a batch (the number of parts follows
@@ -1120,6 +1120,8 @@ def test_conv_splitk_dispatch_is_by_shape():
     for B in (1, 2, 16):
         name, need = kid(B, 12, 1280, 1280, 3)
         assert name == "splitk_256" and need == 5 * B * 144 * 1280 * 4
+    name, need = kid(16, 12, 768, 768, 3)                                      # the codec's 768-channel layers: four ranges
+    assert name == "splitk_256" and need == 4 * 16 * 144 * 768 * 4
     assert kid(16, 12, 1280, 1280, 3, ws=False)[0] != "splitk_256"            # no scratch: the unsplit kernels
     assert kid(16, 12, 1280, 1280, 1)[1] == 0 and kid(16, 24, 1280, 1280, 3)[1] == 0 and kid(16, 12, 320, 1280, 3)[1] == 0
 
