@@ -42,10 +42,22 @@ class VAEDecoder:
         # post_quant_conv (1x1, 4->4) and conv_in (3x3, 4->512): tiny-channel direct kernels in f32
         self.pq_w = sd["post_quant_conv.weight"].permute(0, 2, 3, 1).reshape(4, -1).float().contiguous().to(device)
         self.pq_b = sd["post_quant_conv.bias"].float().contiguous().to(device)
-        # conv_in (3x3, 4 -> 512) on the exact-f32 matrix-core path: input channels zero-padded 4 -> 32
+        # conv_in (3x3, 4 -> 512), input channels zero-padded 4 -> 32, f32 activations.  Round 4: on split-half operands (the 16-bit
+        # matrix rate with f32-grade sums, layers.Conv / DESIGN.md section 3) instead of the f32 matrix instructions (0.46 -> 0.25 ms
+        # per batch).  Its operands must lie inside the half range, and x0 of a random-init model reaches 1e6 and more, so the
+        # latent travels multiplied by 2^-10 (post_quant_conv's input scale and bias below) and conv_in's weights by 2^10: powers of
+        # two, the products and sums are the same numbers.  What that costs: a latent component below 0.06 keeps an ABSOLUTE
+        # precision of 3e-8 instead of 22 bits; a latent beyond 6.7e7 becomes inf and is reported like any other non-finite
+        # picture; weights of 64 and more (never seen in a VAE) keep the f32 instructions, as does ONEDC_PRIOR_SPLIT16=0.
+        self.latent_prescale = 2.0 ** -10
         wci = torch.zeros(512, 32, 3, 3)
-        wci[:, :4] = sd["decoder.conv_in.weight"].float()
-        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["decoder.conv_in.bias"] * s, f32=True, exact=True, flop_scale=4 / 32)     # (x0 may exceed the half range: exact f32)
+        wci[:, :4] = sd["decoder.conv_in.weight"].float() / self.latent_prescale
+        fits = bool(wci.abs().max() < 6.0e4)
+        if not fits:
+            self.latent_prescale = 1.0
+            wci[:, :4] = sd["decoder.conv_in.weight"].float()
+        self.pq_b = (self.pq_b * self.latent_prescale).contiguous()
+        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["decoder.conv_in.bias"] * s, f32=True, exact=not fits, flop_scale=4 / 32)
         self.mid_res = [ResnetBlock2D(sd, f"decoder.mid_block.resnets.{j}", device, 1e-6, s) for j in range(2)]
         self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6 * s * s)
         self.attn = SingleHeadAttention(sd, (f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{a}.to_out.0"), device, 512)
@@ -97,7 +109,7 @@ class VAEDecoder:
         ws, dev = self.ws, self.device
         zbuf = torch.zeros((latents.B * latents.H * latents.W + K.SLACK_ROWS) * 32, dtype=torch.float32, device=dev)
         z = View(zbuf, latents.B, latents.H, latents.W, 32)
-        K.direct_conv(latents, self.pq_w, self.pq_b, z.slice(0, 4), K=1, in_scale=1.0 / self.scaling_factor)
+        K.direct_conv(latents, self.pq_w, self.pq_b, z.slice(0, 4), K=1, in_scale=self.latent_prescale / self.scaling_factor)
         h = self.conv_in(z, new_view(latents.B, latents.H, latents.W, 512, dev), stats=True, alpha=self.stream_scale)
         h = self.mid_res[0](h, ws)
         h = self._windowed_attention(h)
