@@ -53,10 +53,13 @@ class VAEEncoder:
         self.device, self.attn_patch, self.scaling_factor = device, attn_patch, scaling_factor
         self.act = K.act()
         self.ws = Workspace(device)
-        # conv_in (3x3, 3 -> 128) on the exact-f32 matrix-core path: input channels zero-padded 3 -> 32
+        # conv_in (3x3, 3 -> 128), input channels zero-padded 3 -> 32, f32 picture in [-1, 1] (reflect-padded): on split-half
+        # operands (the 16-bit matrix rate with f32-grade sums: layers.Conv) -- the picture is inside the half
+        # range by construction; weights of 6e4 and more (never seen) keep the f32 instructions, as does ONEDC_PRIOR_SPLIT16=0
         wci = torch.zeros(128, 32, 3, 3)
         wci[:, :3] = sd["encoder.conv_in.weight"].float()
-        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["encoder.conv_in.bias"], f32=True, exact=True, flop_scale=3 / 32)
+        self.conv_in = Conv({}, "", device, weight=wci, bias=sd["encoder.conv_in.bias"], f32=True,
+                            exact=bool(wci.abs().max() >= 6.0e4), flop_scale=3 / 32)
         self.down = []
         for i in range(4):
             blk = {"res": [ResnetBlock2D(sd, f"encoder.down_blocks.{i}.resnets.{j}", device, 1e-6) for j in range(2)]}
