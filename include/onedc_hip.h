@@ -160,7 +160,8 @@ int onedc_direct_conv(const onedc_direct_conv_params *p, void *stream);
  * it applied while the input is staged: AutoencoderKL decoder.conv_norm_out + SiLU + conv_out (128 -> 3 at picture
  * resolution; src/models/sd15_onedc_codec_stage1/model_sd15_with_codec_stage1.py:184-188).  x bf16 NHWC view; w the
  * layer's packed bf16 matrix [rows >= Cout][9*Cin] (same packing as onedc_conv_gemm); gn_ab NULL or float2 [B][Cin]
- * from onedc_gn_stats / onedc_gn_from_stats; y f32 (y_f32) or bf16.  H, W % 16 == 0, Cin % 32 == 0. */
+ * from onedc_gn_stats / onedc_gn_from_stats; y f32 (y_f32) or bf16.  H, W % 16 == 0, Cin % 32 == 0 (-1 otherwise);
+ * H * W * x_cs < 2^31 (-2: the caller runs the scale/shift pass and onedc_conv_gemm instead). */
 int onedc_conv3x3_few_out(const void *x, const void *w, const float *bias, const float *gn_ab, void *y, int B, int H,
                           int W, int Cin, int x_cs, int x_co, int Cout, int y_cs, int y_co, int y_f32, int gn_silu,
                           void *stream);

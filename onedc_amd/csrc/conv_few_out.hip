@@ -277,6 +277,7 @@ extern "C" int onedc_conv3x3_few_out(const void *x, const void *w, const float *
                                      int gn_silu, void *stream) {
     if (!x || !w || !y || B < 1 || Cout < 1 || Cout > 4 || (H & 15) || (W & 15) || (Cin & 31) || ((x_cs | x_co) & 7))
         return -1;
+    if ((int64_t)H * W * x_cs >= 0x7fffffffll) return -2;        // pixel offsets inside a picture are 32-bit
     const dim3 grid((H >> 4) * (W >> 4), B);
     const int Ktot = 9 * Cin;
     // the matrix-core form (round 4) wherever its weights fit beside the two windows; ONEDC_FEW_OUT_VALU=1 keeps the

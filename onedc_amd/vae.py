@@ -119,7 +119,7 @@ class VAEDecoder:
                 h = r(h, ws)
             if blk["up"] is not None:
                 h = blk["up"](h, up=1, stats=True)
-        if h.H % 16 == 0 and h.W % 16 == 0 and h.C % 32 == 0 and K.USE_GN_FUSION:
+        if h.H % 16 == 0 and h.W % 16 == 0 and h.C % 32 == 0 and K.USE_GN_FUSION and h.H * h.W * h.cs < 2 ** 31 - 1:
             # conv_norm_out + SiLU + conv_out in one pass over the 128-channel picture-resolution tensor
             y = new_view(h.B, h.H, h.W, 3, dev, torch.float32)
             return K.conv3x3_few_out(h, self.conv_out.w, self.conv_out.b, y,
