@@ -11,7 +11,7 @@ from onedc_amd.model_sd15_with_codec_stage1 import SD15_1step_codec_stage1
 
 model = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0)
 model.codec_model.update(force=True)
-for (H, W, B) in [(512, 768, 3), (1024, 1024, 2), (256, 256, 5), (704, 576, 2), (1280, 768, 2)]:
+for (H, W, B) in [(512, 768, 3), (1024, 1024, 2), (256, 256, 5), (704, 576, 2), (1280, 768, 2), (1408, 2048, 2), (2048, 2048, 1)]:   # (the last two: the CLIC 2K class)
     rng = np.random.default_rng(H + W)
     idx = torch.from_numpy(rng.integers(0, 16384, (B, H // 64, W // 64)).astype(np.int32)).cuda()
     blobs, _ = model.codec_model.encode_latents(idx, None, noise_seed=3)
