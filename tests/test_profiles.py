@@ -88,3 +88,21 @@ def test_kernel_statistics_name_kernels_of_this_tree():
         assert ours > 95.0, ours                           # the device time is this package's own kernels
     # the record the bench line's roofline is about leads the sequential profile
     assert "conv_win4_kernel" in _stats("sequential_kernel_stats")[0]["Name"]
+
+
+def _family_avg_us(rows):
+    tot = calls = 0.0
+    for r in rows:
+        if "conv_win4_kernel<0" in r["Name"] or "conv_win4_kernel<1" in r["Name"]:      # plain / GroupNorm on load, with or without x2
+            tot += float(r["TotalDurationNs"])
+            calls += int(r["Calls"])
+    return tot / calls / 1e3
+
+
+def test_live_launch_durations_agree_with_the_profiler():
+    """the average launch duration bench.py measures live with HIP events must agree with rocprofv3's for the same
+    command -- the pipelined run under the profiler, and the kernel alone (the bench's isolated pass against the sequential profile)."""
+    under = _line("bench_line_under_profiler")["roofline"]
+    assert under["avg_launch_us"] == pytest.approx(_family_avg_us(_stats("bench_default_kernel_stats")), rel=5e-2)
+    alone = _line("bench_line")["roofline"]["isolated"]["avg_launch_us"]
+    assert alone == pytest.approx(_family_avg_us(_stats("sequential_kernel_stats")), rel=5e-2)
