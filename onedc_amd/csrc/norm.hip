@@ -97,6 +97,53 @@ __global__ void gn_finalize_kernel(const float *__restrict__ part, const float *
     }
 }
 
+// Small maps (HW <= 256: the 12 x 12 level of the UNet and of the codec, whose 144 pixels are not whole 64-pixel blocks, so no
+// producer leaves partial sums for them): stages 1 and 2 in ONE launch.  Block (group, image); thread t takes the group's
+// 16-byte units t, t + 256, ... (unit = 8 channels of one pixel) in fp64, then the fixed-shape tree of gn_from_stats_kernel.
+// Round 4: 27 GroupNorms of a decode run here (tools/gn_pass_census.py); two dependent launches of ~15 + 7 us became one.
+__global__ void gn_small_kernel(const a16_t *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                float2 *__restrict__ ab, int HW, int C, int cs, int co, float eps) {
+    __shared__ double red[2][256];
+    const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int cpg = C / GN_GROUPS, upp = cpg >> 3;            // 16-byte units per pixel of this group
+    const a16_t *base = x + ((int64_t)b * HW) * cs + co + g * cpg;
+    double ss = 0.0, qq = 0.0;
+    const int n = HW * upp;
+    for (int u = t; u < n; u += 256) {
+        const int p = u / upp, k = u - p * upp;
+        float f[8];
+        unpack8(*(const uint4 *)(base + (int64_t)p * cs + k * 8), f);
+        float s8 = 0.f, q8 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s8 += f[e];
+            q8 = __builtin_fmaf(f[e], f[e], q8);
+        }
+        ss += (double)s8;
+        qq += (double)q8;
+    }
+    red[0][t] = ss;
+    red[1][t] = qq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            red[0][t] += red[0][t + o];
+            red[1][t] += red[1][t + o];
+        }
+        __syncthreads();
+    }
+    const double cnt = (double)HW * cpg;
+    const double mean = red[0][0] / cnt;
+    double var = red[1][0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (t < cpg) {
+        const int c = g * cpg + t;
+        const float a = rstd * gamma[c];
+        ab[(int64_t)b * C + c] = make_float2(a, beta[c] - (float)mean * a);
+    }
+}
+
 // stage 2 when the producing conv left partial sums (onedc_conv_params.stats): block (group, image)
 // folds the group's quads over the image's 64-pixel blocks.  Fixed order: thread t sums entries
 // t, t+256, ... in fp64, then a fixed-shape tree over the 256 threads.
@@ -314,6 +361,12 @@ int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *
                    int HW, int C, int x_cs, int x_co, float eps, void *stream) {
     if (!x || !gamma || !beta || !partial || !ab) return -1;
     if (C % 32 || C % 8 || (x_cs & 7) || (x_co & 7) || C > 4096) return -2;
+    if (HW <= 256 && (C / GN_GROUPS) % 8 == 0 && C / GN_GROUPS <= 256) {       // small maps: one launch (a function of the shape only)
+        hipLaunchKernelGGL(gn_small_kernel, dim3(GN_GROUPS, B), dim3(256), 0, as_stream(stream), (const a16_t *)x, gamma, beta,
+                           (float2 *)ab, HW, C, x_cs, x_co, eps);
+        ONEDC_LAUNCH_CHECK();
+        return 0;
+    }
     const int CC = C / 8;
     const int PL = CC >= 256 ? 1 : 256 / CC;
     const int threads = CC * PL;

@@ -157,7 +157,8 @@ class _WS:
 
 
 @pytest.mark.parametrize("B,C,H,W,silu", [(2, 128, 40, 36, True), (1, 320, 9, 9, False), (2, 1920, 6, 6, True),
-                                          (1, 2560, 4, 4, True), (3, 512, 16, 16, False)])
+                                          (1, 2560, 4, 4, True), (3, 512, 16, 16, False), (2, 1280, 12, 12, True),
+                                          (2, 768, 12, 12, False)])       # (the last four: the single-launch statistics of small maps)
 def test_group_norm(B, C, H, W, silu):
     x, g, b = rnd(B, C, H, W, seed=26) * 2 + 0.5, rnd(C, seed=27), rnd(C, seed=28)
     x = x.to(torch.bfloat16).float()
@@ -165,6 +166,10 @@ def test_group_norm(B, C, H, W, silu):
     K.group_norm(from_nchw(x.to(DEV)), g.to(DEV), b.to(DEV), y, 1e-6, silu, _WS())
     ref = F.group_norm(x, 32, g, b, 1e-6)
     close(y.torch_nchw(), F.silu(ref) if silu else ref, what="group_norm")
+    if B > 1:                                                                  # a picture alone == inside the batch (bits)
+        y1 = new_view(1, H, W, C, DEV)
+        K.group_norm(from_nchw(x[B - 1:].to(DEV)), g.to(DEV), b.to(DEV), y1, 1e-6, silu, _WS())
+        assert torch.equal(y1.t[:H * W * C], y.t[(B - 1) * H * W * C:B * H * W * C])
 
 
 def test_group_norm_large_map_many_chunks():
