@@ -181,7 +181,8 @@ int onedc_dwconv3x3_f32(const float *x, const float *w, const float *bias, float
  * (decoder_unet.py:19-26), diffusers ResnetBlock2D / Transformer2D.norm / Attention.group_norm.
  * "Image" is whatever the caller makes it: for the VAE mid-block attention, whose statistics are
  * per 16x16 window (vae/autoencoders_patch_attn.py:22-28), the windows are the batch.
- * partial: f32 workspace of B * onedc_gn_chunks(HW) * 64 floats. */
+ * partial: f32 workspace of B * onedc_gn_chunks(HW) * 64 floats (not touched for maps of at most 256 pixels whose groups are
+ * whole 8-channel units: those are reduced in one launch). */
 int onedc_gn_chunks(int HW);
 int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *partial, float *ab, int B,
                    int HW, int C, int x_cs, int x_co, float eps, void *stream);
