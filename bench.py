@@ -282,6 +282,19 @@ def cpu_baseline_encode_decode(model, image, noise, threads, sds, enc_sds, produ
                        f"{S}x{S} picture in {dt:.2f} s on {cores} of {os.cpu_count()} host threads"}, parity)
 
 
+def sustained_mfma_on_random_data(fmt):
+    """TFLOP/s of v_mfma_f32_16x16x32_{f16,bf16} on random operands as recorded in profiles/r4_mfma_power.txt, or None."""
+    path = os.path.join(ROOT, "profiles", "r4_mfma_power.txt")
+    try:
+        with open(path) as f:
+            for l in f:
+                if l.startswith(f"{fmt}, random") and l.rstrip().endswith("TFLOP/s"):
+                    return float(l.split()[-2])
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def measure_kernel_clock(fmt, device, seconds=1.5):
     """Shader clock the chip holds INSIDE the K loop of the dominant kernel (conv_win4_kernel, 128 -> 128 at 768x768, B = 16: its
     most frequent shape), MI355X_MICROARCH.md 'DVFS give-back' item 6: the diagnostic build of the library (build.build_probe:
@@ -723,6 +736,13 @@ def main():
             if clock["ghz"]:
                 line["roofline"]["peak_at_clock"] = round(PEAK_MFMA16_TFLOPS * clock["ghz"] / 2.4, 1)
                 line["roofline"]["frac_of_peak_at_clock"] = round(achieved / (PEAK_MFMA16_TFLOPS * clock["ghz"] / 2.4), 4)
+        # what the 16-bit MFMA instruction SUSTAINS on random-mantissa operands on this chip (power-limited: tools/micro/mfma_power,
+        # measured offline, profiles/r4_mfma_power.txt) -- context for `frac`, which stays priced against the guide's 2.5 PF
+        sustained = sustained_mfma_on_random_data(model.act)
+        if sustained:
+            line["roofline"]["sustained_on_random_data"] = {
+                "tflops": sustained, "frac": round(achieved / sustained, 4),
+                "from": "profiles/r4_mfma_power.txt (register-only loop of the same MFMA instruction on random operands, 0.5 s)"}
         if rans_t:
             line["host_rans"] = rans_t
         if side:
