@@ -14,6 +14,7 @@ itself (SD-VAE encoder + UNet2DModel, third-party bodies) is not built yet.
 import os
 
 import numpy as np
+from types import SimpleNamespace
 import torch
 
 from . import kernels as K
@@ -175,8 +176,6 @@ class IntraNoAR:
         self.N = N = bottleneck_ch
         self.prior_f32 = f32 = bool(prior_f32)
         self.prior_exact = isinstance(prior_f32, str) and prior_f32.lower() == "exact"
-        from . import layers as _layers
-        _split_before, _layers.PRIOR_SPLIT16 = _layers.PRIOR_SPLIT16, _layers.PRIOR_SPLIT16 and not self.prior_exact
         if prior_arith not in ("mfma", "torch_cpu", "auto"):
             raise ValueError(f"prior_arith must be 'mfma', 'torch_cpu' or 'auto', not {prior_arith!r}")
         self.prior_arith = prior_arith
@@ -186,19 +185,16 @@ class IntraNoAR:
             ref_profile = intel_profile(int(ref_profile[6:])) if ref_profile.startswith("intel:") else load_profile(ref_profile)
         self.ref_profile = ref_profile            # known native-path structures of the writer (ref_arith.Calibration), or None
         self.ref_prior = None                     # the reference-arithmetic prior in use (None: the MFMA prior)
+        self.last_auto_arith = None               # "auto": which arithmetic decoded the last call (mfma / mfma_exact / torch_cpu:<threads>)
         self._ref_priors = {}                     # per calibrated thread count
         import threading
         self._auto_lock = threading.RLock()       # "auto" switches self.ref_prior while it retries: one decode at a time
         self._ref_sd = sd if prior_arith != "mfma" else None
         if prior_arith == "torch_cpu":
             self.ref_prior = self._reference_prior(ref_threads)
-        self.hyper_dec = HyperDecoder(sd, device, f32=f32)
-        self.y_prior_fusion = [DepthConvBlock4(sd, f"y_prior_fusion.{i}", device, f32) for i in range(2)]
-        self.y_spatial_prior_reduction = Conv(sd, "y_spatial_prior_reduction", device, f32=f32)
-        self.y_spatial_prior_adaptor = [DepthConvBlock4(sd, f"y_spatial_prior_adaptor_{i}", device, f32)
-                                        for i in (1, 2, 3)]
-        self.y_spatial_prior = [DepthConvBlock4(sd, f"y_spatial_prior.{i}", device, f32) for i in range(3)]
-        _layers.PRIOR_SPLIT16 = _split_before
+        self._prior_nets_default = self._build_prior_nets(sd, f32, self.prior_exact)
+        self._prior_nets_exact = self._prior_nets_default if (self.prior_exact or not f32) else None   # built on first use ("auto")
+        self._use_prior_nets(self._prior_nets_default)
         self.semantic_adaptor = SemanticAdaptor(sd, device, semantic_ch)
         self.dec = Decoder(sd, device)
         self.z_fsq_levels = list(z_fsq_levels)
@@ -216,6 +212,37 @@ class IntraNoAR:
         self.entropy_coder = None
         self._tables = None
         self._pinned_bufs = {}
+
+    @K.in_own_format
+    def _build_prior_nets(self, sd, f32, exact):
+        """The networks that feed the entropy coder's integer decisions (hyper decoder, prior fusion, the four-part prior's
+        nets) in one arithmetic: f32 activations on split-half operands (exact=False, the default since round 4) or on the f32
+        matrix instructions (exact=True: rounds 1-3's arithmetic, what a stream written by those rounds' encoder needs)."""
+        from . import layers as _layers
+        split_before = _layers.PRIOR_SPLIT16
+        _layers.PRIOR_SPLIT16 = split_before and not exact
+        try:
+            dev = self.device
+            return SimpleNamespace(
+                hyper_dec=HyperDecoder(sd, dev, f32=f32),
+                y_prior_fusion=[DepthConvBlock4(sd, f"y_prior_fusion.{i}", dev, f32) for i in range(2)],
+                y_spatial_prior_reduction=Conv(sd, "y_spatial_prior_reduction", dev, f32=f32),
+                y_spatial_prior_adaptor=[DepthConvBlock4(sd, f"y_spatial_prior_adaptor_{i}", dev, f32) for i in (1, 2, 3)],
+                y_spatial_prior=[DepthConvBlock4(sd, f"y_spatial_prior.{i}", dev, f32) for i in range(3)])
+        finally:
+            _layers.PRIOR_SPLIT16 = split_before
+
+    def _use_prior_nets(self, nets):
+        self.hyper_dec, self.y_prior_fusion = nets.hyper_dec, nets.y_prior_fusion
+        self.y_spatial_prior_reduction = nets.y_spatial_prior_reduction
+        self.y_spatial_prior_adaptor, self.y_spatial_prior = nets.y_spatial_prior_adaptor, nets.y_spatial_prior
+
+    def _exact_prior_nets(self):
+        """The exact-f32 twin of the prior networks ("auto": second attempt for a stream that desynchronises under the
+        split-half form -- a stream written by a round-1-3 encoder of this package, or with prior_f32: exact)."""
+        if self._prior_nets_exact is None:
+            self._prior_nets_exact = self._build_prior_nets(self._ref_sd, True, True)
+        return self._prior_nets_exact
 
     # reference CompressionModel.update (compression_model.py:169-171)
     @K.in_own_format
@@ -291,7 +318,12 @@ class IntraNoAR:
         # the MFMA prior, then the reference's arithmetic calibrated for the configuration classes a writer may have used: the
         # stated / current thread count, 8 (2-8 threads are one class on pictures above ~0.16 MP), 1 (the reference harness's own
         # setting, src/inference.py:29: torch's native gemm path), 16 (oneDNN blocks 1x1 differently from 16 threads on)
+        # Second attempt (round 5): this package's OTHER MFMA arithmetic -- a model on split-half operands (the default since
+        # round 4) tries the exact-f32 matrix instructions, which is what a .bin written by rounds 1-3 of this package (or with
+        # prior_f32: exact) needs; the container records no arithmetic, so the order of the attempts is the only selector.
         attempts = [None]
+        if self.prior_f32 and not self.prior_exact:
+            attempts.append("exact")
         for t in (self.ref_threads or cur, 8, 1, 16):
             if t not in attempts:
                 attempts.append(t)
@@ -300,10 +332,15 @@ class IntraNoAR:
             try:
                 # (building / calibrating the reference prior for a thread count can itself fail -- no candidate structure
                 # matches this host's torch -- and must not end the attempts: the next class may still decode the stream)
-                self.ref_prior = None if threads is None else self._reference_prior(threads)
+                if threads == "exact":
+                    self._use_prior_nets(self._exact_prior_nets())
+                else:
+                    self.ref_prior = None if threads is None else self._reference_prior(threads)
                 if trace is not None:
                     del trace[:]
-                return self._decompress_once(streams_y, indices, trace)
+                out = self._decompress_once(streams_y, indices, trace)
+                self.last_auto_arith = "mfma" if threads is None else "mfma_exact" if threads == "exact" else f"torch_cpu:{threads}"
+                return out
             except StreamDesyncError as e:
                 first_error = first_error or e
             except (ReferenceArithmeticUnavailable, AssertionError):         # nothing more to try in that class
@@ -311,6 +348,7 @@ class IntraNoAR:
                     raise
             finally:
                 self.ref_prior = None
+                self._use_prior_nets(self._prior_nets_default)
         if len(streams_y) > 1 and trace is None:
             return self._decompress_one_by_one(streams_y, indices, first_error)
         raise first_error

@@ -109,8 +109,22 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 #endif
     int pt, n0, img, pin, y0, x0;
     auto decode_tile = [&](int lg) {
+#ifdef EXP_W4_NSLOW
+        // (experiment, round 5) channel tile SLOW inside groups of EXP_W4_NSLOW patches: the workgroups resident on an XCD
+        // then stream ONE channel tile's weights at a time (1.2 MB at Cin = 512 instead of 4.7 MB next to a 4 MB L2);
+        // the window of a patch is fetched again per channel tile by construction
+        {
+            const int P = tiles_pi * p.B, G = EXP_W4_NSLOW;
+            const int g = lg / (G * tiles_n), rem = lg - g * G * tiles_n;
+            const int gl = P - g * G < G ? P - g * G : G;
+            const int nn = rem / gl;
+            pt = g * G + rem - nn * gl;
+            n0 = nn * 128;
+        }
+#else
         pt = dv_n.div(lg);
         n0 = (lg - pt * tiles_n) * 128;
+#endif
         img = dv_pi.div(pt);
         pin = pt - img * tiles_pi;
         int ty, tx;

@@ -75,15 +75,32 @@ def rank_world():
 
 
 def run_token():
-    """What the ranks of ONE launch share and another launch does not: the launcher's run id, else the parent's pid."""
-    return os.environ.get("ONEDC_RUN_ID") or f"{os.environ.get('TORCHELASTIC_RUN_ID', '')}-ppid{os.getppid()}"
+    """What the ranks of ONE launch attempt share and another launch (or a restarted attempt of this one) does not.
+    torchrun / accelerate give every rank of every node the same MASTER_ADDR:MASTER_PORT and TORCHELASTIC_RUN_ID, and count
+    restarts in TORCHELASTIC_RESTART_COUNT (a restarted attempt must not accept the failed attempt's marker / done files); the
+    parent's pid -- equal only among the ranks of one node -- is the fallback for launchers that set none of them."""
+    env = os.environ
+    if env.get("ONEDC_RUN_ID"):
+        return env["ONEDC_RUN_ID"]
+    if env.get("MASTER_ADDR") and env.get("MASTER_PORT"):
+        return (f"{env['MASTER_ADDR']}:{env['MASTER_PORT']}-{env.get('TORCHELASTIC_RUN_ID', '')}"
+                f"-restart{env.get('TORCHELASTIC_RESTART_COUNT', '0')}")
+    return f"{env.get('TORCHELASTIC_RUN_ID', '')}-ppid{os.getppid()}"
 
 
-def wait_for(predicate, what, timeout=1800.0, poll=0.05):
-    """File-system rendezvous: poll until predicate() is true."""
+class RankFailed(RuntimeError):
+    """Another rank of this launch left a .failed<r> file: it raised, and waiting for it would only time out."""
+
+
+def wait_for(predicate, what, timeout=1800.0, poll=0.05, abort=None):
+    """File-system rendezvous: poll until predicate() is true; abort() (optional) is polled beside it and returns a
+    message when the wait has become pointless (a rank of this launch failed)."""
     import time
     t0 = time.monotonic()
     while not predicate():
+        why = abort() if abort else None
+        if why:
+            raise RankFailed(f"rank {rank_world()[0]}: stopped waiting for {what}: {why}")
         if time.monotonic() - t0 > timeout:
             raise TimeoutError(f"rank {rank_world()[0]}: waited {timeout:.0f} s for {what}")
         time.sleep(poll)
@@ -218,22 +235,47 @@ def evaluate_sharded(out, src, rank, world, one_picture, write_table):
     marker, token = os.path.join(out, ".onedc_run"), run_token()
     part_file = lambda r: os.path.join(out, f".detail_part{r}.csv")      # noqa: E731
     done_file = lambda r: os.path.join(out, f".done{r}")                 # noqa: E731
+    failed_file = lambda r: os.path.join(out, f".failed{r}")             # noqa: E731
+
+    def someone_failed():
+        for r in range(world):
+            if r != rank and _read(failed_file(r)) == token:
+                return f"rank {r} failed (see its traceback)"
+        return None
     if rank == 0:
-        prepare_output_dir(out)
+        # whatever an earlier attempt left behind goes FIRST (a stale marker would let rank 1 start while this rank is still
+        # deleting the directory; stale done / part files would be merged): the marker, then the rest with the directory
+        if os.path.exists(marker):
+            os.remove(marker)
+        try:
+            prepare_output_dir(out)
+        except BaseException:                    # (a refused directory: tell the waiting ranks, if there is a place to say it)
+            if os.path.isdir(out):
+                with open(failed_file(0), "w") as f:
+                    f.write(token)
+            raise
         with open(marker, "w") as f:
             f.write(token)
     else:
-        wait_for(lambda: _read(marker) == token, f"rank 0 to prepare {out!r}")
-    names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
-    for idx in dataparallel.shard(len(names), rank, world):
-        name = os.path.splitext(names[idx])[0]
-        row = pd.DataFrame(one_picture(idx, name, os.path.join(src, names[idx])), index=[idx])
-        row.to_csv(part_file(rank), mode="a", header=not os.path.exists(part_file(rank)))
+        wait_for(lambda: _read(marker) == token, f"rank 0 to prepare {out!r}", abort=someone_failed)
+    try:
+        names = sorted(f for f in os.listdir(src) if f.endswith((".jpg", ".png")))
+        for idx in dataparallel.shard(len(names), rank, world):
+            name = os.path.splitext(names[idx])[0]
+            row = pd.DataFrame(one_picture(idx, name, os.path.join(src, names[idx])), index=[idx])
+            row.to_csv(part_file(rank), mode="a", header=not os.path.exists(part_file(rank)))
+    except BaseException:
+        try:                                     # the other ranks (rank 0's merge above all) stop waiting at once
+            with open(failed_file(rank), "w") as f:
+                f.write(token)
+        except OSError:
+            pass
+        raise
     with open(done_file(rank), "w") as f:
         f.write(token)
     if rank != 0:
         return None
-    wait_for(lambda: all(_read(done_file(r)) == token for r in range(world)), "the other ranks to finish")
+    wait_for(lambda: all(_read(done_file(r)) == token for r in range(world)), "the other ranks to finish", abort=someone_failed)
     parts = [pd.read_csv(part_file(r), index_col=0) for r in range(world) if os.path.exists(part_file(r))]
     detail = pd.concat(parts).sort_index() if parts else pd.DataFrame()
     write_table(detail, os.path.join(out, "detail_bpp_caption.xlsx"))

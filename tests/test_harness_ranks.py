@@ -23,12 +23,14 @@ def make_pictures(folder, n):
         Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(folder, f"pic{i:02d}.png"))
 
 
-def launch(out, src, rank=None, world=None, run_id="t", extra=()):
+def launch(out, src, rank=None, world=None, run_id="t", extra=(), mode=None):
     env = dict(os.environ)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HARNESS_MODE"):
         env.pop(k, None)
     if rank is not None:
         env.update(RANK=str(rank), WORLD_SIZE=str(world), ONEDC_RUN_ID=run_id)
+    if mode:
+        env["HARNESS_MODE"] = mode
     return subprocess.Popen([sys.executable, RUNNER, out, src, *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
 
@@ -71,3 +73,67 @@ def test_rows_of_finished_pictures_survive_a_failure(tmp_path):
     part = pd.read_csv(os.path.join(out, ".detail_part0.csv"), index_col=0)
     assert list(part["image_name"]) == ["pic00", "pic01", "pic02"]
     assert sorted(os.listdir(os.path.join(out, "recon"))) == ["pic00.png", "pic01.png", "pic02.png"]
+
+
+def test_a_failing_rank_stops_rank_0_at_once(tmp_path):
+    """a crashed non-zero rank made rank 0 wait 30 minutes for its done file.  Now the failing rank leaves
+    .failed<r> and rank 0's merge wait raises RankFailed within a poll interval."""
+    import time
+    src = str(tmp_path / "pictures")
+    make_pictures(src, 6)
+    out = str(tmp_path / "out")
+    t0 = time.monotonic()
+    procs = [launch(out, src, 1, 2, extra=("1",)), launch(out, src, 0, 2)]
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode != 0
+    assert time.monotonic() - t0 < 60
+    assert b"RankFailed" in e and b"rank 1 failed" in e              # (rank 0's stderr)
+    assert os.path.exists(os.path.join(out, ".failed1"))
+    # the next attempt (another token: a restart counts in TORCHELASTIC_RESTART_COUNT) is not confused by what the failed one left
+    finish([launch(out, src, r, 2, run_id="t2") for r in (1, 0)])
+    assert sorted(os.listdir(out)) == ["detail_bpp_caption.xlsx", "recon", "stream", "summary_bpp.xlsx"]
+
+
+def test_run_token_comes_from_the_launchers_rendezvous(monkeypatch):
+    from onedc_amd import inference
+    for k in ("ONEDC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"):
+        monkeypatch.delenv(k, raising=False)
+    assert inference.run_token().endswith(f"ppid{os.getppid()}")                # no launcher: the parent's pid
+    monkeypatch.setenv("MASTER_ADDR", "10.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job7")
+    a = inference.run_token()
+    assert "ppid" not in a and "10.0.0.1:29500" in a and "job7" in a           # the same on every node of the launch
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert inference.run_token() != a                                            # a restarted attempt is another run
+    monkeypatch.setenv("ONEDC_RUN_ID", "mine")
+    assert inference.run_token() == "mine"
+
+
+def make_containers(folder, n):
+    from onedc_amd.entropy.utils import encode_i, write_to_file
+    os.makedirs(folder)
+    rng = np.random.default_rng(1)
+    for i in range(n):
+        h, w = (64, 128) if i % 4 else (128, 128)                    # two padded sizes: batches never mix them
+        n_idx = (h // 64) * (w // 64)
+        blob = encode_i(h - (i % 3), w, rng.bytes(20 + i), rng.bytes((14 * n_idx + 7) // 8), b"", 0)
+        write_to_file(blob, os.path.join(folder, f"s{i:02d}.bin"))
+
+
+def test_two_ranks_share_a_pipelined_directory_decode(tmp_path):
+    """`--decoder_only` with a directory: decode_folder_pipelined(model, src, dst, B, rank, world) deals the BATCHES round-robin
+    (reference src/inference.py:82: accelerator.prepare(img_dataloader)).  Two processes: disjoint file sets, union equal to
+    the single-process output, byte for byte."""
+    src = str(tmp_path / "streams")
+    make_containers(src, 11)
+    single, multi = str(tmp_path / "single"), str(tmp_path / "multi")
+    finish([launch(single, src, mode="decode_folder")])
+    finish([launch(multi, src, r, 2, mode="decode_folder") for r in (1, 0)])
+    a, b = sorted(os.listdir(single)), sorted(os.listdir(multi))
+    assert a == b == [f"s{i:02d}.png" for i in range(11)]
+    assert not filecmp.cmpfiles(single, multi, a, shallow=False)[1] and not filecmp.cmpfiles(single, multi, a, shallow=False)[2]
+    logs = [open(tmp_path / f"log_multi_rank{r}.txt").read().split() for r in (0, 1)]
+    one = open(tmp_path / "log_single_rank0.txt").read().split()
+    assert logs[0] and logs[1] and sorted(logs[0] + logs[1]) == sorted(one)      # every batch decoded once, by one rank
