@@ -106,7 +106,11 @@ typedef struct onedc_conv_params {
                                            23 040 k) are cut into n contiguous ranges, one workgroup per (tile, range)
                                            leaves f32 partial sums in ws, onedc_splitk_reduce adds them in range order
                                            (fixed order, no atomics) and applies the epilogue.  Ask onedc_conv_splitk_ws_bytes
-                                           for the scratch size (0: this layer is not split) */
+                                           for the scratch size (0: this layer is not split).  ABI 5: a layer that qualifies
+                                           and finds ws NULL or smaller than that size is REFUSED with -15 -- it is never run
+                                           unsplit behind the caller's back (the unsplit kernel adds in another order, so a
+                                           fixed-size scratch would make a picture's bits depend on the batch it sits in);
+                                           a caller without scratch sets split_k = 1 */
     const void *x2;                     /* NULL, or the input of a 1x1 convolution that is accumulated into the same output
                                            tile behind the 3x3 taps: y = alpha * (conv3x3(x) + conv1x1(x2)) + bias + res --
                                            diffusers ResnetBlock2D.conv_shortcut riding on conv2 (called from
@@ -142,7 +146,9 @@ enum {
     ONEDC_KERNEL_LIN_64X128 = 13,  /* conv_lin_kernel<Tile<64,128>>: 1x1 layers, 32-channel K-steps, four-stage LDS ring */
     ONEDC_KERNEL_LIN_128X128 = 14, /* conv_lin_kernel<Tile<128,128>> */
     ONEDC_KERNEL_F32S_128X128 = 15,/* conv_gemm_kernel<Tile<128,128>, f32, split>: f32 activations, operands as pairs of halves */
-    ONEDC_KERNEL_F32S_64X128 = 16
+    ONEDC_KERNEL_F32S_64X128 = 16,
+    ONEDC_KERNEL_LIN_128X256 = 17  /* conv_lin_kernel<Tile<128,256,1,4>, 3 stages>: 128 channels x 256 pixels on four waves (wave tile
+                                      128 x 64), 72 KB: two workgroups per CU; 25 % fewer L2 -> LDS bytes per flop than 128 x 128 */
 };
 int onedc_conv_gemm_kernel_id(const onedc_conv_params *p);
 const char *onedc_conv_kernel_name(int kernel_id);
@@ -332,6 +338,15 @@ int onedc_timestep_embedding(const float *t, float *emb, int n, int dim, void *s
 int onedc_add(const void *a, const void *b, void *y, int64_t n, void *stream);
 
 const char *onedc_hip_version(void);
+/* ABI number of this header: bumped whenever a signature, a struct field's meaning or an entry point's behaviour changes in a
+ * way an older caller could not notice at link time (symbol-compatible breaks).  History: 2 = library 0.2; 3 = 0.3
+ * (onedc_image_out gained `nonfinite` in front of `stream` UNDER THE OLD NAME); 4 = 0.4 (onedc_image_out back to its 0.2
+ * signature, the 0.3 form renamed onedc_image_out_checked; fields appended to onedc_conv_params); 5 = round 5 (a split-K
+ * layer without scratch is refused with -15 instead of run unsplit; onedc_hip_abi_version itself).  A host checks
+ * onedc_hip_abi_version() == ONEDC_HIP_ABI_VERSION once after dlopen: a host compiled against ABI 3 that calls
+ * onedc_image_out of a 4+ library would pass its flag pointer where the stream is read. */
+#define ONEDC_HIP_ABI_VERSION 5
+int onedc_hip_abi_version(void);
 /* identity (sha256 prefix) of the kernel sources, headers and compiler flags this library was built from; the Python loader
  * refuses a library whose id differs from the sources beside it (set ONEDC_ALLOW_STALE_LIB=1 for experiment builds) */
 const char *onedc_hip_build_id(void);

@@ -467,7 +467,8 @@ inline int grid_for(int64_t n, int per = 256) { return (int)min((int64_t)16384, 
 
 extern "C" {
 
-const char *onedc_hip_version(void) { return "onedc-hip 0.4 (gfx950, " ONEDC_ACT_NAME " activations)"; }
+const char *onedc_hip_version(void) { return "onedc-hip 0.5 (gfx950, " ONEDC_ACT_NAME " activations)"; }
+int onedc_hip_abi_version(void) { return ONEDC_HIP_ABI_VERSION; }
 // identity of the sources this library was compiled from (onedc_amd/build.py: hip_source_id); the loader compares it with the
 // sources next to it, so a stale .so is an error instead of a wrong answer
 #ifndef ONEDC_BUILD_ID

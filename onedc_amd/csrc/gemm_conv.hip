@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const onedc_conv_para
 // NSTAGE 3 (tile 134): 48 KB for the 128 x 128 tile, THREE workgroups per CU (experiment: a third resident workgroup
 // under the prologue and epilogue of the other two).
 template <class T, int NSTAGE = 4>
-__global__ __launch_bounds__(256, (NSTAGE == 3 && T::TN <= 128) ? 3 : 2) void conv_lin_kernel(const onedc_conv_params p, int tiles_n, int tiles_m, int M) {
+__global__ __launch_bounds__(256, (NSTAGE == 3 && T::TN * T::TM <= 128 * 128) ? 3 : 2) void conv_lin_kernel(const onedc_conv_params p, int tiles_n, int tiles_m, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TN = T::TN, TM = T::TM;
     constexpr int STAGE = (TN + TM) * 64;          // bytes per K-step: 32 channels of every row
@@ -598,13 +598,17 @@ static bool conv_lin_ok(const onedc_conv_params &p) {
 static int conv_choose(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     {
+        // a layer whose SHAPE says split-K runs split or not at all: falling back to the unsplit kernel when the caller's
+        // scratch is missing or too small for this batch would make the sums depend on B (the unsplit kernel adds in another
+        // order) -- the one thing the path promises never to do.  split_k = 1 is the way to ask for the unsplit form.
         const int parts = conv_splitk_parts(p);
-        if (parts && p.ws && p.ws_bytes >= onedc_conv_splitk_bytes(p, parts)) return ONEDC_KERNEL_SPLITK_256;
+        if (parts) return (p.ws && p.ws_bytes >= onedc_conv_splitk_bytes(p, parts)) ? ONEDC_KERNEL_SPLITK_256 : -15;
     }
     // up == 2: x2 upsample + 3x3 decomposed into four 2x2 phase convolutions; w is the phase-packed matrix
     if (p.up == 2) {
         if (!onedc_conv_ups_ok(p)) return -12;
         if (p.tile != 130 && onedc_conv_ups4_ok(p)) return ONEDC_KERNEL_UPS2X2_4W;
+        if (p.out_bf16) return -12;                // (the 8-wave phase kernel stores the build's own format only)
         return p.tile == 131 ? -11 : ONEDC_KERNEL_UPS2X2;
     }
     const int64_t M64 = (int64_t)p.B * p.OH * p.OW;
@@ -637,6 +641,7 @@ static int conv_choose(const onedc_conv_params &p) {
     if (p.x2) return -16;
     if (p.tile == 130 || p.tile == 131) return -11;
     if (p.gn_ab) return -13;                       // only the window kernel normalises on load
+    if (p.tile == 136) return (conv_lin_ok(p) && (p.Cout % 128) == 0) ? ONEDC_KERNEL_LIN_128X256 : -11;
     // 256 x 256 tiles, 8-phase schedule: full 256-row channel tiles and enough pixel tiles to fill the chip
     const int64_t blocks256 = (p.Cout / 256) * ((M64 + 255) / 256) * (p.batch > 1 ? p.batch : 1);
     // short K (< 32 K-tiles: 1x1 layers up to 1984 channels): the 4-wave kernels win, two workgroups per CU hide each
@@ -669,6 +674,13 @@ static int conv_choose(const onedc_conv_params &p) {
     // ... except its THREE-stage form on the 128 x 128 tile (48 KB: three workgroups per CU instead of two) for K <= 384, the
     // level-0 Linear layers with wide outputs, whose life is prologue + epilogue and wants one more resident workgroup:
     // to_q|k 320 -> 1024 at 96x96 211 -> 182 us, GEGLU 320 -> 2560 397 -> 368, to_q 320 -> 512 88 -> 80; level from K = 640 on.
+    // Round 5: the gated Linear layers (GEGLU of the UNet's feed-forward blocks, the codec's ConvFFN3 pairs) on the 128 x 256 tile
+    // of the same kernel (wave tile 128 channels x 64 pixels, three 24 KB stages, two workgroups per CU): their life is the L2 ->
+    // LDS stream of a wide N against a short K plus an arithmetic epilogue, and this tile moves 25 % fewer bytes per flop than
+    // 128 x 128.  tools/bench_1x1.py 136, B = 16: 320 -> 2560 at 96x96 444 -> 382 us, 640 -> 5120 at 48x48 345 -> 328, 1280 -> 10240
+    // at 24x24 311 -> 286; the plain projections are level or slower on it (to_q|k 320 -> 1024: 174 -> 206 us: they want the third
+    // resident workgroup instead).  Same k order, same bits.  By layer shape and epilogue only.
+    if (glu && p.tile == 0 && conv_lin_ok(p) && (p.Cout % 128) == 0 && ktiles < kLongK) return ONEDC_KERNEL_LIN_128X256;
     const bool lin = conv_lin_ok(p) && (p.tile == 133 || p.tile == 134);
     const bool lin3 = conv_lin_ok(p) && p.tile == 0 && p.Cin <= 384;
     if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))
@@ -701,6 +713,7 @@ extern "C" const char *onedc_conv_kernel_name(int id) {
         case ONEDC_KERNEL_SPLITK_256: return "splitk_256";
         case ONEDC_KERNEL_LIN_64X128: return "lin_64x128";
         case ONEDC_KERNEL_LIN_128X128: return "lin_128x128";
+        case ONEDC_KERNEL_LIN_128X256: return "lin_128x256";
         default: return "?";
     }
 }
@@ -727,6 +740,7 @@ extern "C" int onedc_conv_gemm(const onedc_conv_params *pp, void *stream) {
             return p.tile == 134 ? launch_lin<Tile<64, 128, 2, 2>, 3>(p, st) : launch_lin<Tile<64, 128, 2, 2>>(p, st);
         case ONEDC_KERNEL_LIN_128X128:
             return p.tile != 133 ? launch_lin<Tile<128, 128, 2, 2>, 3>(p, st) : launch_lin<Tile<128, 128, 2, 2>>(p, st);
+        case ONEDC_KERNEL_LIN_128X256: return launch_lin<Tile<128, 256, 1, 4>, 3>(p, st);
         case ONEDC_KERNEL_F32_128X128: return launch<Tile<128, 128, 2, 2>, true>(p, st);
         case ONEDC_KERNEL_F32_64X128: return launch<Tile<64, 128, 2, 2>, true>(p, st);
         case ONEDC_KERNEL_F32S_128X128: return launch<Tile<128, 128, 2, 2>, true, true>(p, st);

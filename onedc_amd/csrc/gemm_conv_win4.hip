@@ -617,8 +617,12 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
                     q_hi[r >> 2][i] = __builtin_elementwise_fma(hi, hi, q_hi[r >> 2][i]);
                 }
                 const int s8 = i * 4 + fq;
+                // (upsample phases only: onedc_conv_params.out_bf16 stores bf16 whatever the build's format -- round 5: the VAE's
+                // 768 x 768 block may run in bf16 inside an f16 model, and its input is this kernel's output)
+                const bool as_bf16 = UPS && p.out_bf16;
                 *(__attribute__((address_space(3))) u32x2_t *)(my + px * 128 + (((s8 >> 1) ^ (px & 7)) << 4) + (s8 & 1) * 8) =
-                    u32x2_t{pack_a2(lo[0], lo[1]), pack_a2(hi[0], hi[1])};
+                    as_bf16 ? u32x2_t{pack_bf16_2(lo[0], lo[1]), pack_bf16_2(hi[0], hi[1])}
+                            : u32x2_t{pack_a2(lo[0], lo[1]), pack_a2(hi[0], hi[1])};
             }
             if (r == 1 || r == 3) {
                 load_res_row(r + 3);

@@ -188,15 +188,17 @@ __global__ void gn_from_stats_kernel(const float2 *__restrict__ stats, const flo
 // y = act(x * a + bb).  Block (pixel chunk, image); thread = (channel chunk of 8, pixel lane): the
 // thread's 8 (a, bb) pairs are loaded once and stay in registers while it walks its pixels, so the
 // loop is one 16-byte load, 8 fma (+ 8 exp / rcp for SiLU) and one 16-byte store, no index division.
-constexpr int SSA_PPC = 256;  // pixels per block
+// ppc: pixels per block, 256 on the big maps; round 5: fewer on maps that would give less than two blocks per CU -- 24x24 and
+// 12x12 maps of a batch of 16 were 48 / 16 blocks of serial 256-pixel walks: 56 us for 47 MB (0.8 TB/s), 28 us for 12 MB
+constexpr int SSA_PPC = 256;
 __global__ void scale_shift_act_kernel(const a16_t *__restrict__ x, const float2 *__restrict__ ab,
                                        a16_t *__restrict__ y, int HW, int C, int CC, int PL, int x_cs, int x_co,
-                                       int y_cs, int y_co, int silu) {
+                                       int y_cs, int y_co, int silu, int ppc) {
     const int t = threadIdx.x;
     const int cc = t % CC, pl = t / CC;
     const int b = blockIdx.y;
-    const int p0 = blockIdx.x * SSA_PPC;
-    const int p1 = min(p0 + SSA_PPC, HW);
+    const int p0 = blockIdx.x * ppc;
+    const int p1 = min(p0 + ppc, HW);
     float a[8], bb[8];
     const float4 *abp = (const float4 *)(ab + (int64_t)b * C + cc * 8);
 #pragma unroll
@@ -400,9 +402,11 @@ int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW
     const int PL = CC >= 256 ? 1 : 256 / CC;
     const int threads = CC * PL;
     if (threads > 1024) return -3;
-    hipLaunchKernelGGL(scale_shift_act_kernel, dim3((HW + SSA_PPC - 1) / SSA_PPC, B), dim3(threads), 0,
+    int ppc = SSA_PPC;                // by map size and batch only; elementwise: the values do not depend on the split
+    while (ppc > 8 && ppc > PL && (int64_t)((HW + ppc - 1) / ppc) * B < 512) ppc >>= 1;
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3((HW + ppc - 1) / ppc, B), dim3(threads), 0,
                        as_stream(stream), (const a16_t *)x, (const float2 *)ab, (a16_t *)y, HW, C, CC, PL, x_cs,
-                       x_co, y_cs, y_co, silu);
+                       x_co, y_cs, y_co, silu, ppc);
     ONEDC_LAUNCH_CHECK();
     return 0;
 }

@@ -134,6 +134,7 @@ SIGNATURES = {
     "onedc_ref_prior_indexes": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "onedc_add": (_I, [_P, _P, _P, _L, _P]),
     "onedc_hip_version": (C.c_char_p, []),
+    "onedc_hip_abi_version": (_I, []),
     "onedc_hip_act_format": (C.c_char_p, []),
     "onedc_hip_build_id": (C.c_char_p, []),
 }
@@ -150,12 +151,18 @@ def attach_signatures(l):
     return l
 
 
+ABI_VERSION = 5        # ONEDC_HIP_ABI_VERSION of include/onedc_hip.h this binding was written against (tests/test_abi.py compares)
+
+
 def lib(fmt=None):
     fmt = fmt or act()
     l = _libs.get(fmt)
     if l is None:
         l = attach_signatures(_native.hip(fmt))
         check_library_format(fmt, l.onedc_hip_act_format(), l.onedc_hip_version())
+        if l.onedc_hip_abi_version() != ABI_VERSION:          # a symbol-compatible break is worse than a link error
+            raise _native.NativeLibraryError(f"the kernel library speaks ABI {l.onedc_hip_abi_version()} ({l.onedc_hip_version().decode()}), "
+                                             f"this binding ABI {ABI_VERSION}")
         path = _native.HIP_SO if fmt == "bf16" else _native.HIP_F16_SO
         if not os.environ.get("ONEDC_HIP_SO" if fmt == "bf16" else "ONEDC_HIP_F16_SO"):    # (experiment builds: no id check)
             _native.check_build_id(path, l.onedc_hip_build_id().decode(), "hip")

@@ -117,7 +117,7 @@ class Conv:
         return self
 
     def __call__(self, x, y=None, *, epi=EPI_LINEAR, slope=0.01, res=None, stride=1, up=0, out_f32=False,
-                 alpha=1.0, stats=False, pad=None, gn=None, x2=None, w2=None, bias=None):
+                 alpha=1.0, stats=False, pad=None, gn=None, x2=None, w2=None, bias=None, out_bf16=False):
         """stats: the output feeds a GroupNorm -- leave its partial sums in the epilogue.
         gn = (GroupNorm layer, workspace, silu): the conv reads that norm of x (fused into the operand staging
         where the kernel can, kernels.conv_gemm).
@@ -139,7 +139,8 @@ class Conv:
             if self.shuffle:
                 c //= 4
                 oh, ow = 2 * oh, 2 * ow
-            y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else K.a16())
+            y = new_view(x.B, oh, ow, c, x.t.device, torch.float32 if (out_f32 or self.f32) else
+                         torch.bfloat16 if out_bf16 else K.a16())
         if stats:
             y.want_stats()
         if self.mxfp8:
@@ -154,7 +155,9 @@ class Conv:
                 x.W % 16 == 0 and not y.f32 and y.cs % 8 == 0 and y.co % 8 == 0 and
                 epi in (EPI_LINEAR, EPI_LEAKY, EPI_SILU)):
             return K.conv_gemm(x, self.w_ups, self.b, y, KH=3, up=2, epi=epi, slope=slope, alpha=alpha, Cin=self.cin,
-                               Cout=self.cout, stats=stats)
+                               Cout=self.cout, stats=stats, out_bf16=out_bf16)
+        if out_bf16 and K.act() != "bf16":
+            raise K.KernelError("out_bf16 on a conv that does not run as upsample phases (only that kernel stores the other format)")
         if gn is not None:
             gn = (gn[0].g, gn[0].b, gn[0].eps, gn[2], gn[1])
         return K.conv_gemm(x, self.w, self.b if bias is None else bias, y, KH=self.k, stride=stride, up=up, epi=epi,

@@ -83,12 +83,16 @@ class SD15_1step_codec_stage1:
         rank = _get(lc, "lora_rank", 64)
         alpha = _get(lc, "lora_alpha", 8.0)
         with torch.cuda.device(self.device):
-            self.feedforward_model = UNet(feedforward_sd, self.device, rank, alpha)
+            # unet_act: the UNet alone in another 16-bit format (round 5 experiment: "bf16" inside an f16 model -- the chip
+            # holds a higher clock on 8-bit mantissas; tests/devtools/error_budget.py: a bf16 UNet alone sits 60.7 dB from the
+            # oracle where the whole bf16 model sits 49.7)
+            with K.act_format(_get(self.args, "unet_act", None) or self.act):
+                self.feedforward_model = UNet(feedforward_sd, self.device, rank, alpha)
             self.codec_model = IntraNoAR(codec_sd, self.device, prior_f32=_get(self.args, "prior_f32", True),
                                          prior_arith=_get(self.args, "prior_arith", "auto") or "auto",
                                          ref_threads=_get(self.args, "ref_threads", None),
                                          ref_profile=_get(self.args, "ref_profile", None))
-            self.vae_large = VAEDecoder(vae_sd, self.device, self.vae_attn_patch)
+            self.vae_large = VAEDecoder(vae_sd, self.device, self.vae_attn_patch, up3_act=_get(self.args, "vae_up3_act", None))
         return self
 
     def load(self, checkpoint_path, vae_path=None):
@@ -226,6 +230,9 @@ class SD15_1step_codec_stage1:
         vae_gate: optional context manager entered around the VAE decoder's launches (DecodePipeline serialises the VAE
         stages of its streams with it)."""
         ctx = y_semantic                                            # 'b c h w -> b (h w) c' is the NHWC layout itself
+        if self.feedforward_model.act != self.act:                  # (experiment: the UNet in the other 16-bit format)
+            dt = torch.float16 if self.feedforward_model.act == "f16" else torch.bfloat16
+            h_detail_hat, ctx = (View(v.t.to(dt), v.B, v.H, v.W, v.C, v.cs, v.co) for v in (h_detail_hat, ctx))
         eps, reduced = self.feedforward_model(h_detail_hat, self.conditioning_timestep, ctx)
         x0 = new_view(eps.B, eps.H, eps.W, 4, self.device, torch.float32)
         n = eps.B * eps.H * eps.W * 4

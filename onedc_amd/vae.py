@@ -18,7 +18,7 @@ F16_STREAM_SCALE = 2.0 ** -6
 
 
 class VAEDecoder:
-    def __init__(self, sd, device, attn_patch=16, scaling_factor=0.18215, stream_scale=None):
+    def __init__(self, sd, device, attn_patch=16, scaling_factor=0.18215, stream_scale=None, up3_act=None):
         """stream_scale: the decoder's residual stream (everything between conv_in and conv_norm_out) is stored times
         this power of two.  With IEEE-half activations the default 2^-6 moves the stream's headroom from 65504 to 4.2e6
         (SD-VAE decoder activations reach the thousands; with random-init weights and their huge x0, 2e4) at no cost:
@@ -62,15 +62,23 @@ class VAEDecoder:
         self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6 * s * s)
         self.attn = SingleHeadAttention(sd, (f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{a}.to_out.0"), device, 512)
         self.attn.scale_output(s)
+        # up3_act (round 5): the 16-bit format of the LAST up block (three resnets at picture resolution) + conv_norm_out +
+        # conv_out, "bf16" inside an f16 decoder: what those layers round meets no further GroupNorm-and-amplify stage (the
+        # MXFP8 experiment of round 3 found this block alone inside the 0.01 dB budget even at 3 mantissa bits), and the chip
+        # holds a 3 - 6 % higher clock on 8-bit mantissas in exactly these MFMA-bound launches.  The upsampler in front of
+        # it stores bf16 (onedc_conv_params.out_bf16).  None: the decoder's own format throughout.
+        self.up3_act = up3_act if (up3_act and up3_act != self.act) else None
         self.up = []
         for i, (cin, cout) in enumerate(arch.VAE_UP):
-            blk = {"res": [ResnetBlock2D(sd, f"decoder.up_blocks.{i}.resnets.{j}", device, 1e-6, s) for j in range(3)]}
+            with K.act_format(self.up3_act if (i == 3 and self.up3_act) else self.act):
+                blk = {"res": [ResnetBlock2D(sd, f"decoder.up_blocks.{i}.resnets.{j}", device, 1e-6, s) for j in range(3)]}
             blk["up"] = Conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", device, upsample=True) if i < 3 else None
             if blk["up"] is not None:
                 blk["up"].b = (blk["up"].b * s).contiguous()       # a linear map of the stream: only its bias scales
             self.up.append(blk)
-        self.norm_out = GroupNorm(sd, "decoder.conv_norm_out", device, 1e-6 * s * s)
-        self.conv_out = Conv(sd, "decoder.conv_out", device)
+        with K.act_format(self.up3_act or self.act):
+            self.norm_out = GroupNorm(sd, "decoder.conv_norm_out", device, 1e-6 * s * s)
+            self.conv_out = Conv(sd, "decoder.conv_out", device)
 
     MXFP8_GROUPS = ("mid", "up0", "up1", "up2", "up3")
 
@@ -114,11 +122,22 @@ class VAEDecoder:
         h = self.mid_res[0](h, ws)
         h = self._windowed_attention(h)
         h = self.mid_res[1](h, ws)
-        for blk in self.up:
+        for i, blk in enumerate(self.up):
+            if i == 3 and self.up3_act:
+                if h.t.dtype != (torch.bfloat16 if self.up3_act == "bf16" else torch.float16):
+                    raise K.KernelError("vae_up3_act: the upsampler in front of the last block did not run as upsample phases "
+                                        "(picture size not whole 16x16 patches at 1/2 resolution); use the default format")
+                with K.act_format(self.up3_act):
+                    for r in blk["res"]:
+                        h = r(h, ws)
+                    return self._tail(h, ws, dev)
             for r in blk["res"]:
                 h = r(h, ws)
             if blk["up"] is not None:
-                h = blk["up"](h, up=1, stats=True)
+                h = blk["up"](h, up=1, stats=True, out_bf16=bool(i == 2 and self.up3_act == "bf16"))
+        return self._tail(h, ws, dev)
+
+    def _tail(self, h, ws, dev):
         if h.H % 16 == 0 and h.W % 16 == 0 and h.C % 32 == 0 and K.USE_GN_FUSION and h.H * h.W * h.cs < 2 ** 31 - 1:
             # conv_norm_out + SiLU + conv_out in one pass over the 128-channel picture-resolution tensor
             y = new_view(h.B, h.H, h.W, 3, dev, torch.float32)

@@ -44,6 +44,19 @@ def test_hip_library_exports_header_symbols():
         assert lib.onedc_hip_act_format() == fmt
     assert set(names) == set(kernels.HIP_SYMBOLS)
     assert kernels.lib("bf16") is not kernels.lib("f16")
+    # the ABI number of the header, of the binding and of both libraries is one number (a symbol-compatible break -- ADVICE
+    # round 4: onedc_image_out's 0.3 -> 0.4 change -- shows up as a refused library, not as a stream pointer read from a flag slot)
+    header = open(os.path.join(ROOT, "include", "onedc_hip.h")).read()
+    abi = int(re.search(r"#define\s+ONEDC_HIP_ABI_VERSION\s+(\d+)", header).group(1))
+    assert abi == kernels.ABI_VERSION == kernels.lib("bf16").onedc_hip_abi_version() == kernels.lib("f16").onedc_hip_abi_version()
+
+
+def test_library_of_another_abi_is_refused(monkeypatch):
+    build.build_hip()
+    monkeypatch.setattr(kernels, "_libs", {})
+    monkeypatch.setattr(kernels, "ABI_VERSION", kernels.ABI_VERSION + 1)
+    with pytest.raises(_native.NativeLibraryError, match="ABI"):
+        kernels.lib("f16")
 
 
 def test_library_of_the_other_format_is_refused(monkeypatch):

@@ -54,8 +54,17 @@ def test_window_layers_go_to_the_4wave_kernel_where_its_epilogue_applies(fmt):
 
 def test_layers_no_window_kernel_takes():
     assert name(params(H=24, W=24, Cin=1280, Cout=1280, B=16)) == "256x256"          # map is not whole 16x16 patches
-    assert name(params(H=12, W=12, Cin=1280, Cout=1280, B=16)) == "64x128"           # 2304 pixels: a small grid
+    p12 = params(H=12, W=12, Cin=1280, Cout=1280, B=16)
+    assert name(p12) == -15                                                          # a split-K shape without scratch is refused (ABI 5)
+    p12.split_k = 1
+    assert name(p12) == "64x128"                                                     # 2304 pixels: a small grid
     assert name(params(k=1, H=96, W=96, Cin=320, Cout=2560, B=16)) == "lin_128x128"  # K <= 384, wide output: three-stage ring, 3 workgroups per CU
+    # round 5: gated layers (fewer than 32 K-tiles) on the 128 x 256 tile of the ring kernel, by shape and epilogue only
+    for B in (1, 16):
+        assert name(params(k=1, H=96, W=96, Cin=320, Cout=2560, B=B, epi=K.EPI_GEGLU)) == "lin_128x256"
+        assert name(params(k=1, H=24, W=24, Cin=1280, Cout=10240, B=B, epi=K.EPI_GEGLU)) == "lin_128x256"
+    assert name(params(k=1, H=24, W=24, Cin=5120, Cout=1280, B=16, epi=K.EPI_GEGLU)) == "256x256"      # long K stays on eight waves
+    assert name(params(k=1, H=96, W=96, Cin=320, Cout=320, B=16, tile=136)) == -11                       # forced where it cannot run
     assert name(params(k=1, H=96, W=96, Cin=320, Cout=320, B=16)) == "64x128"        # ... narrow output: the 64-row tile
     assert name(params(k=1, H=48, W=48, Cin=640, Cout=5120, B=16)) == "128x128"      # short K: the 4-wave kernels
     assert name(params(k=1, H=24, W=24, Cin=1280, Cout=1280, B=16)) == "128x128"     # 20 K-tiles: four waves since round 4
@@ -69,14 +78,18 @@ def test_layers_no_window_kernel_takes():
 
 def test_split_k_is_a_function_of_the_layer_shape():
     """3x3 layers on maps of <= 256 pixels with >= 160 K-tiles (the UNet's 12x12 level) are split into five K ranges (four from 96
-    K-tiles on: the codec's 768-channel layers) whatever the batch size, when the caller brings the scratch the dispatcher asks for; never by B, never without scratch."""
+    K-tiles on: the codec's 768-channel layers) whatever the batch size.  A caller that brings no scratch (or too little for this
+    batch) is REFUSED with -15 since ABI 5 -- never served by the unsplit kernel, whose sums round differently (a
+    fixed-size scratch would have made a picture's bits depend on the batch); split_k = 1 asks for the unsplit form."""
     lib = K.lib()
     for B in (1, 2, 16):
         p = params(H=12, W=12, Cin=1280, Cout=1280, B=B)
         need = lib.onedc_conv_splitk_ws_bytes(C.byref(p))
         assert need == 5 * B * 144 * 1280 * 4
-        assert name(p) == "64x128"                                                    # no scratch: the unsplit kernels
-        p.ws, p.ws_bytes = C.cast(C.create_string_buffer(64), C.c_void_p), need
+        assert lib.onedc_conv_gemm_kernel_id(C.byref(p)) == -15                       # no scratch: refused, not run unsplit
+        p.ws, p.ws_bytes = C.cast(C.create_string_buffer(64), C.c_void_p), need - 1
+        assert lib.onedc_conv_gemm_kernel_id(C.byref(p)) == -15                       # too small for this batch: the same
+        p.ws_bytes = need
         assert name(p) == "splitk_256"
         p.split_k = 1
         assert name(p) == "64x128"

@@ -1201,6 +1201,9 @@ def test_conv_win4_second_source_race_screen_and_refusal():
     (1, 16, 16, 64, 128, "silu", False, True),         # two K-steps: shorter than the ring
     (2, 12, 12, 384, 320, "linear", True, False),      # attention out-projection (padded heads), 12 K-steps
     (1, 9, 7, 96 + 32, 128, "leaky", False, False),    # 63 pixels: one partial tile
+    (2, 24, 24, 640, 5120, "geglu", False, False),     # round 5: the gated layers run on the 128 x 256 tile (automatic)
+    (1, 12, 12, 1280, 1024, "geglu", False, False),    # ... K = 1280, a map smaller than one pixel tile
+    (1, 16, 20, 320, 256, "linear", True, True),       # ... and the same tile forced (136) on a plain layer with statistics
 ])
 def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, res, stats):
     """1x1 layers on conv_lin_kernel (32-channel K-steps, four-stage ring; tile 133) against F.conv2d and, BIT
@@ -1216,7 +1219,8 @@ def test_conv_lin_kernel_equals_the_64_channel_kernel(B, H, W, Cin, Cout, epi, r
     rv = from_nchw(r.to(DEV)) if res else None
     code = {"linear": K.EPI_LINEAR, "geglu": K.EPI_GEGLU, "silu": K.EPI_SILU, "leaky": K.EPI_LEAKY}[epi]
     outs = []
-    for tile in (133, 128, 132, 134, 0):      # the ring kernel, the 64-channel kernel, the same without line stores, 3-stage ring, automatic
+    # the ring kernel, the 64-channel kernel, the same without line stores, 3-stage ring, automatic, the 128 x 256 tile (round 5)
+    for tile in (133, 128, 132, 134, 0) + ((136,) if Cout % 128 == 0 else ()):
         y = new_view(B, H, W, cstore, DEV, stats=stats)
         K.conv_gemm(xv, wp, bd, y, KH=1, epi=code, slope=0.1, res=rv, stats=stats, tile=tile)
         outs.append((y.t[:B * H * W * cstore].clone(), y.stats.t.clone() if (stats and y.stats is not None) else None, y))
@@ -1274,6 +1278,9 @@ def test_conv_lin_kernel_batched_and_dispatch():
     assert K.conv_kernel_name(p) == "lin_128x128"
     p.Cout = p.y_cs = 320
     assert K.conv_kernel_name(p) == "64x128"
+    # round 5: gated layers (GEGLU) with fewer than 32 K-tiles take the 128 x 256 tile of the ring kernel
+    p.Cout, p.y_cs, p.epi = 2560, 1280, K.EPI_GEGLU
+    assert K.conv_kernel_name(p) == "lin_128x256"
 
 
 # ---- round 4: the f32 path on split operands (pairs of halves, 16-bit matrix rate) ---------------------------------------
