@@ -456,6 +456,18 @@ def side_lines(args, model, model_cfg, synthetic_weights, idx, blobs, sds, rank)
     if model.act == "f16":
         guarded("bf16", bf16)
 
+    # (4b) the per-stage format switch of round 5: the VAE's last up block + conv_out in bf16 inside the f16 model (off by default:
+    # it spends |dPSNR| 0.0034 / 0.0053 dB of the 0.01 dB budget, tests/devtools/mixed_precision.py)
+    def vae_up3_bf16():
+        cfg = dict(model_cfg, vae_up3_act="bf16")
+        m2 = SD15_1step_codec_stage1(cfg, device=model.device).load_state_dicts(*synthetic_weights(args.weights))
+        m2.codec_model.update(force=True)
+        dt = timed_pipeline(m2, blobs, k)
+        return entry(B, k, dt, "the headline's streams on a model with vae_up3_act: bf16 (the VAE's 768x768 block in bf16, everything else "
+                     "f16); accuracy: DESIGN.md section 5 (|dPSNR| 0.0034 / 0.0053 dB at 25 / 27 dB, budget 0.01)", dtype="f16, VAE up3 bf16")
+    if model.act == "f16":
+        guarded("vae_up3_bf16", vae_up3_bf16)
+
     # (5) BASELINE configs[4] at its per-GPU size: encode + decode of 8 pictures of 512x512, sequential calls
     def encode_decode():
         S2, B2 = MODE_DEFAULTS["encode_decode"]

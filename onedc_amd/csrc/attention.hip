@@ -312,24 +312,30 @@ __device__ __forceinline__ void fa_glds16(const char *src, char *lds_dst) {
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__restrict__ Q,
+// FA64_QT query column tiles (16 queries each) per wave, FA64_OCC workgroups per CU.  4 / 2 is the product; 3 / 3 (48 queries per
+// wave, 168 registers, three waves per SIMD) is round 5's experiment: -DFA64_QT=3 -DFA64_OCC=3 (tools/exp_build.sh)
+#ifndef FA64_QT
+#define FA64_QT 4
+#define FA64_OCC 2
+#endif
+__global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t *__restrict__ Q,
                                                               const a16_t *__restrict__ K,
                                                               const a16_t *__restrict__ VT,
                                                               a16_t *__restrict__ O, int H, int Nq, int Nk,
                                                               int Nk_pad, float scale_log2e, int d_real, int q_rs, int k_rs,
                                                               int64_t vt_bs) {
-    constexpr int DQ = 64, DV = 48, QT = 4;
+    constexpr int DQ = 64, DV = 48, QT = FA64_QT, QW = 64 * QT;      // QW: queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     // all query blocks of one (image, head) run on ONE XCD, back to back: its K / V^T (2 MB at 9216 keys)
     // stay in that XCD's L2 instead of being pulled through all eight
-    const int nqb = (Nq + 255) >> 8;
+    const int nqb = (Nq + QW - 1) / QW;
     const int logical = fa_xcd_logical(blockIdx.x, gridDim.x);
     const int bh = logical / nqb;
     const int h = bh % H, b = bh / H;
-    const int q0 = (logical - bh * nqb) * 256 + wave * 64;
+    const int q0 = (logical - bh * nqb) * QW + wave * 16 * QT;
 
     // Q fragments (B operand): lane (g, r) holds Q[q0 + 16 t + r][32 ks + 8 g .. + 7], pre-multiplied by
     // scale * log2(e): the S product then lands in the exp2 domain and needs no per-element multiply
@@ -528,7 +534,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn64_kernel(const a16_t *__res
                     o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][st], o[d][t], 0, 0, 0);
             }
         if constexpr (TRACK) {
-            const float wmax = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
+            float wmax = tmax[0];
+#pragma unroll
+            for (int t = 1; t < QT; ++t) wmax = fmaxf(wmax, tmax[t]);
             if (__any(wmax > FA64_THR)) {           // wave-uniform, rare
 #pragma unroll
                 for (int t = 0; t < QT; ++t) (void)move_ref(t, fmaxf(tmax[t], 0.f), true);
@@ -969,7 +977,7 @@ extern "C" int onedc_flash_attn_strided(const void *q, const void *k, const void
     if (DQ == 64 && DV == 48 && Nk >= 64) {
         static OnedcLdsAttrOnce once;
         once.ensure({{(const void *)flash_attn64_kernel, FA64_NST * FA64_STAGE}});
-        hipLaunchKernelGGL(flash_attn64_kernel, dim3(((Nq + 255) / 256) * H * B), block, FA64_NST * FA64_STAGE, st,
+        hipLaunchKernelGGL(flash_attn64_kernel, dim3(((Nq + 64 * FA64_QT - 1) / (64 * FA64_QT)) * H * B), block, FA64_NST * FA64_STAGE, st,
                            (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
                            40, q_rs, k_rs, vt_bs);
     } else if (DQ == 128 && DV == 96 && Nk >= 64) {

@@ -680,7 +680,9 @@ static int conv_choose(const onedc_conv_params &p) {
     // 128 x 128.  tools/bench_1x1.py 136, B = 16: 320 -> 2560 at 96x96 444 -> 382 us, 640 -> 5120 at 48x48 345 -> 328, 1280 -> 10240
     // at 24x24 311 -> 286; the plain projections are level or slower on it (to_q|k 320 -> 1024: 174 -> 206 us: they want the third
     // resident workgroup instead).  Same k order, same bits.  By layer shape and epilogue only.
+#ifndef EXP_R5_BASELINE                             // (A/B build: round 5's dispatch and launch changes off, tools/r5_ab_bench.sh)
     if (glu && p.tile == 0 && conv_lin_ok(p) && (p.Cout % 128) == 0 && ktiles < kLongK) return ONEDC_KERNEL_LIN_128X256;
+#endif
     const bool lin = conv_lin_ok(p) && (p.tile == 133 || p.tile == 134);
     const bool lin3 = conv_lin_ok(p) && p.tile == 0 && p.Cin <= 384;
     if (((p.Cout % 128) != 0 && (p.Cout % 128) <= 64) || (blocks4w < 256 && (p.Cout % 64) == 0 && p.Cout >= 128))

@@ -403,7 +403,9 @@ int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW
     const int threads = CC * PL;
     if (threads > 1024) return -3;
     int ppc = SSA_PPC;                // by map size and batch only; elementwise: the values do not depend on the split
+#ifndef EXP_R5_BASELINE
     while (ppc > 8 && ppc > PL && (int64_t)((HW + ppc - 1) / ppc) * B < 512) ppc >>= 1;
+#endif
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3((HW + ppc - 1) / ppc, B), dim3(threads), 0,
                        as_stream(stream), (const a16_t *)x, (const float2 *)ab, (a16_t *)y, HW, C, CC, PL, x_cs,
                        x_co, y_cs, y_co, silu, ppc);

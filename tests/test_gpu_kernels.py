@@ -941,6 +941,32 @@ def test_conv_upsample_phases(B, H, W, Cin, C, epi):
         K.PROFILE = None
 
 
+def test_conv_upsample_phases_store_bf16_in_the_f16_build():
+    """onedc_conv_params.out_bf16 on the upsample phases (round 5: the VAE's last up block may run in bf16 inside an f16 model, and
+    its input is this kernel's output): the f16 library's launch with out_bf16 must store exactly round-to-nearest-even bf16 of
+    the values its f16 launch rounds to f16 -- both are roundings of the same f32 sums -- and leave the same statistics."""
+    from onedc_amd import pack
+    if K.act() != "f16":
+        pytest.skip("the flag only means something in the IEEE-half build")
+    B, H, W, Cin, C = 2, 16, 32, 128, 256
+    x, w, b = rnd(B, Cin, H, W, seed=187), rnd(C, Cin, 3, 3, seed=188, scale=(9 * Cin) ** -0.5), rnd(C, seed=189)
+    xv, wp = from_nchw(x.to(DEV)), pack.pack_matrix(pack.upsample_phase_matrix(w), DEV)
+    y16 = new_view(B, 2 * H, 2 * W, C, DEV, stats=True)
+    K.conv_gemm(xv, wp, b.to(DEV), y16, KH=3, up=2, Cin=Cin, Cout=C, stats=True)
+    ybf = new_view(B, 2 * H, 2 * W, C, DEV, torch.bfloat16, stats=True)
+    K.conv_gemm(xv, wp, b.to(DEV), ybf, KH=3, up=2, Cin=Cin, Cout=C, stats=True, out_bf16=True)
+    n = B * 4 * H * W * C
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    got = ybf.t[:n].float().view(B, 2 * H, 2 * W, C).permute(0, 3, 1, 2).cpu()
+    close(got, ref, rms=6e-3, mx=5e-2, what="upsample phases, bf16 stored by the f16 build")
+    # bf16(f32 sum) against bf16(f16(f32 sum)): equal except where the double rounding crosses a bf16 tie
+    twice = y16.t[:n].float().to(torch.bfloat16)
+    assert float((twice != ybf.t[:n]).float().mean()) < 2e-3
+    assert torch.equal(y16.stats.t, ybf.stats.t)                       # statistics come from the f32 values
+    with pytest.raises(K.KernelError):                                 # the 8-wave phase kernel stores the build's format only
+        K.conv_gemm(xv, wp, b.to(DEV), ybf, KH=3, up=2, Cin=Cin, Cout=C, out_bf16=True, tile=130)
+
+
 def test_conv_upsample_phases_race_screen_and_batch_invariance():
     from onedc_amd import pack
     x, w = rnd(4, 256, 32, 32, seed=191), rnd(128, 256, 3, 3, seed=192, scale=1 / 48)
@@ -1127,7 +1153,8 @@ def test_conv_splitk_dispatch_is_by_shape():
         assert name == "splitk_256" and need == 5 * B * 144 * 1280 * 4
     name, need = kid(16, 12, 768, 768, 3)                                      # the codec's 768-channel layers: four ranges
     assert name == "splitk_256" and need == 4 * 16 * 144 * 768 * 4
-    assert kid(16, 12, 1280, 1280, 3, ws=False)[0] != "splitk_256"            # no scratch: the unsplit kernels
+    with pytest.raises(K.KernelError, match="-15"):                            # no scratch: refused since ABI 5, never run unsplit
+        kid(16, 12, 1280, 1280, 3, ws=False)
     assert kid(16, 12, 1280, 1280, 1)[1] == 0 and kid(16, 24, 1280, 1280, 3)[1] == 0 and kid(16, 12, 320, 1280, 3)[1] == 0
 
 
