@@ -18,6 +18,7 @@ FAMILIES = (
     ("flash_attn64", lambda s: "flash_attn64" in s),
     ("flash_attn80", lambda s: "flash_attn80" in s),
     ("4-wave 16-bit GEMMs", lambda s: ("conv_gemm_kernel" in s and "false, false>" in s) or "conv_lin_kernel" in s),
+    ("  of it the 128x256 ring tile (gated layers)", lambda s: "conv_lin_kernel" in s and "Tile<128, 256" in s),
     ("prior GEMMs (split-half operands)", lambda s: "conv_gemm_kernel" in s and "true, true>" in s),
     ("exact f32 GEMMs", lambda s: "conv_gemm_kernel" in s and "true, false>" in s),
     ("256x256 incl. split-K", lambda s: "conv_gemm256_kernel" in s or "splitk_reduce" in s),
@@ -45,7 +46,7 @@ def main():
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     plain = {"bench_line.json", "bench_line_bf16.json", "bench_line_sequential.json", "bench_line_zonly.json", "bench_line_encdec.json",
              "bench_line_under_profiler.json", "pmc_traffic.json", "pmc_mfma.json", "mfma_rate.txt", "unet_layers.txt",
-             "vae_layers.txt", "ab_round4.txt", "bench_1x1.txt"}
+             "vae_layers.txt", "ab_round4.txt", "bench_1x1.txt", "mfma_power.txt", "stage_times.txt", "bench_gn.txt", "bench_attn.txt"}
     for name in sorted(plain):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):

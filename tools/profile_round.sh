@@ -7,13 +7,13 @@ out=${1:-gpurun_out/round}
 mkdir -p "$out"
 root=$(pwd)
 export TMPDIR=/tmp
-run() { name=$1; shift; timeout 600 "$@" > "$out/$name.json" 2> "$out/$name.err" < /dev/null; echo "$name rc=$?"; }
+run() { name=$1; shift; timeout 1000 "$@" > "$out/$name.json" 2> "$out/$name.err" < /dev/null; echo "$name rc=$?"; }
 run bench_line python3 bench.py
-run bench_line_bf16 env ONEDC_ACT=bf16 python3 bench.py --no-cpu-baseline
-run bench_line_sequential python3 bench.py --sequential --no-cpu-baseline
+run bench_line_bf16 env ONEDC_ACT=bf16 python3 bench.py --no-cpu-baseline --no-side-lines
+run bench_line_sequential python3 bench.py --sequential --no-cpu-baseline --no-side-lines
 run bench_line_zonly python3 bench.py --mode z_only --no-cpu-baseline
 run bench_line_encdec python3 bench.py --mode encode_decode
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r4 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r5 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline --no-side-lines > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$root/$out/pmc_$c" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_$c.err" < /dev/null; echo "pmc $c rc=$?" )
 done
@@ -23,6 +23,7 @@ find "$out" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \; < /
 find "$out/seqprof" -name "*kernel_stats.csv" -exec cp {} "$out/sequential_kernel_stats.csv" \; < /dev/null
 rm -rf "$out/seqprof"
 [ -x tools/micro/mfma_rate ] && timeout 120 tools/micro/mfma_rate > "$out/mfma_rate.txt" 2>&1 < /dev/null
+[ -x tools/micro/mfma_power ] && timeout 120 tools/micro/mfma_power > "$out/mfma_power.txt" 2>&1 < /dev/null
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$root/$out/pmc_mfma" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_mfma.err" < /dev/null; echo "pmc mfma rc=$?" )
 m=$(find "$out/pmc_mfma" -name "*counter_collection.csv" < /dev/null | head -1)
 if [ -n "$m" ]; then ( cd tools && python3 pmc_mfma.py "$root/$m" "$root/$out/pmc_mfma.json" "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, tools/profile_round.sh) over python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential; util = busy cycles of all SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs). Folded by tools/pmc_mfma.py on the box." < /dev/null ); fi
@@ -35,6 +36,8 @@ ls -la "$out" < /dev/null
 # round 4: per-layer tables, the A/B of the round's kernel forms, the tile sweep of the UNet's 1x1 shapes
 timeout 400 python3 tools/unet_layers.py > "$out/unet_layers.txt" 2>&1 < /dev/null
 timeout 400 python3 tools/vae_layers.py > "$out/vae_layers.txt" 2>&1 < /dev/null
-timeout 500 python3 tools/ab_round4.py > "$out/ab_round4.txt" 2>&1 < /dev/null
-timeout 300 python3 tools/bench_1x1.py > "$out/bench_1x1.txt" 2>&1 < /dev/null
+timeout 300 python3 tools/bench_1x1.py 136 > "$out/bench_1x1.txt" 2>&1 < /dev/null
+timeout 200 python3 tools/stage_times.py > "$out/stage_times.txt" 2>&1 < /dev/null
+timeout 200 python3 tools/bench_gn.py > "$out/bench_gn.txt" 2>&1 < /dev/null
+timeout 200 python3 tools/bench_attn.py > "$out/bench_attn.txt" 2>&1 < /dev/null
 ls -la "$out" < /dev/null
