@@ -95,8 +95,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=None, help="picture size of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline's main entry (16 was the fastest of 16/32/64 on the 2x64-core "
-                         "host); a 1-thread entry (the reference's own setting, src/inference.py:29) and an all-core entry "
-                         "are measured beside it on a 256x256 sample")
+                         "host); a 1-thread entry (the reference's own setting, src/inference.py:29) is measured beside it on a "
+                         "256x256 sample")
     ap.add_argument("--free-vae", action="store_true",
                     help="let the VAE stages of the pipeline's streams overlap each other (default: serialised on the device)")
     ap.add_argument("--broadcast-weights", action="store_true",
@@ -137,7 +137,7 @@ def _time_oracle_decode(sample, cores, weights, z_only):
 def cpu_baseline_decode(sample, threads, sds, z_only=False, extras=True):
     """Oracle decode (everything after the entropy decode) of one sample x sample picture on the host; scaled to
     768^2-equivalent images/s by algorithmic FLOPs when sample != 768.  Beside the main entry (`threads` torch threads):
-    ONE thread (the reference harness's own setting, src/inference.py:29) and ALL host threads, each on a 256x256 picture."""
+    ONE thread (the reference harness's own setting, src/inference.py:29) on a 256x256 picture."""
     weights = _oracle_weights(sds)
     ncpu = os.cpu_count() or 1
     what = ("z indices -> hyper decoder + means-only four-part prior + decode_from_latents" if z_only
@@ -155,7 +155,8 @@ def cpu_baseline_decode(sample, threads, sds, z_only=False, extras=True):
     out = entry(sample, threads)
     if extras:
         out["one_thread"] = entry(256, 1)              # torch.set_num_threads(1): src/inference.py:29
-        out["all_threads"] = entry(256, ncpu)
+        # (rounds 3-4 also timed ALL host threads here: slower than 16 on a single picture -- 0.036 images/s -- and, once the
+        # process had run the side lines' models, pathologically so: 200 s for the 256x256 sample.  Dropped: a bounded sample.)
     return out
 
 

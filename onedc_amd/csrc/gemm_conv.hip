@@ -677,9 +677,10 @@ static int conv_choose(const onedc_conv_params &p) {
     // Round 5: the gated Linear layers (GEGLU of the UNet's feed-forward blocks, the codec's ConvFFN3 pairs) on the 128 x 256 tile
     // of the same kernel (wave tile 128 channels x 64 pixels, three 24 KB stages, two workgroups per CU): their life is the L2 ->
     // LDS stream of a wide N against a short K plus an arithmetic epilogue, and this tile moves 25 % fewer bytes per flop than
-    // 128 x 128.  tools/bench_1x1.py 136, B = 16: 320 -> 2560 at 96x96 444 -> 382 us, 640 -> 5120 at 48x48 345 -> 328, 1280 -> 10240
-    // at 24x24 311 -> 286; the plain projections are level or slower on it (to_q|k 320 -> 1024: 174 -> 206 us: they want the third
-    // resident workgroup instead).  Same k order, same bits.  By layer shape and epilogue only.
+    // 128 x 128.  tools/ab_gated.py (interleaved rounds in one process against -DEXP_R5_BASELINE, B = 16): 640 -> 5120 at 48x48
+    // 331 -> 304 us, 1280 -> 10240 at 24x24 308 -> 278, at 12x12 83 -> 77; 320 -> 2560 at 96x96 level (365 / 364: there the
+    // three-stage 128 x 128 ring with its third resident workgroup was as good).  The plain projections are level or slower on
+    // it (tools/bench_1x1.py 136: to_q|k 320 -> 1024 174 -> 206 us).  Same k order, same bits.  By layer shape and epilogue only.
 #ifndef EXP_R5_BASELINE                             // (A/B build: round 5's dispatch and launch changes off, tools/r5_ab_bench.sh)
     if (glu && p.tile == 0 && conv_lin_ok(p) && (p.Cout % 128) == 0 && ktiles < kLongK) return ONEDC_KERNEL_LIN_128X256;
 #endif

@@ -38,6 +38,9 @@ for name, H, Cin, Cout, k, epi, res in SH:
     fl = 2.0 * B * H * H * Cout * k * k * Cin
     out = []
     tiles = (0, 128, 129, 256) + tuple(int(a) for a in sys.argv[1:])        # extra ids: experiment builds (EXP_TILES: 132..135)
+    for _ in range(10):                # (the first column used to be measured cold -- fresh tensors, the clock still ramping: round 5
+        K.conv_gemm(x, w, None, y, KH=k, epi=epi, res=r)                     # read 14 % into a tile that an interleaved A/B puts level)
+    torch.cuda.synchronize()
     for tile in tiles:
         if tile == 256 and Cout % 256:
             out.append("   n/a   ")

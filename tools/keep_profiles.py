@@ -68,7 +68,7 @@ def main():
     pipe = os.path.join(src, "kernel_stats.csv")
     if os.path.exists(pipe):
         line = json.load(open(os.path.join(src, "bench_line_under_profiler.json")))
-        head = (f"# rocprofv3 --kernel-trace --stats of python3 bench.py --no-cpu-baseline (tools/profile_round.sh): the pipelined default bench "
+        head = (f"# rocprofv3 --kernel-trace --stats of python3 bench.py --no-cpu-baseline --no-extras (tools/profile_round.sh): the pipelined default bench "
                 f"({line['value']} images/s under the profiler); launches of different streams overlap, so durations here include the time a kernel "
                 f"shares the GPU\n")
         if remark:

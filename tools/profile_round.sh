@@ -1,6 +1,7 @@
 #!/bin/bash
 # Measurement batch of a round, on the GPU box:  tools/profile_round.sh OUTDIR
-# bench lines of every mode, rocprofv3 kernel stats of the default bench command, PMC traffic passes (FETCH_SIZE and
+# bench lines of every mode, rocprofv3 kernel stats of the default bench command (without the extras: the clock probe's 1.5 s of
+# back-to-back launches of the dominant kernel would sit in the same row of the statistics as the pipelined launches), PMC traffic passes (FETCH_SIZE and
 # WRITE_SIZE separately, kernel trace only -- never with other trace domains).  Every step has its own timeout and
 # no step reads stdin.
 out=${1:-gpurun_out/round}
@@ -13,7 +14,7 @@ run bench_line_bf16 env ONEDC_ACT=bf16 python3 bench.py --no-cpu-baseline --no-s
 run bench_line_sequential python3 bench.py --sequential --no-cpu-baseline --no-side-lines
 run bench_line_zonly python3 bench.py --mode z_only --no-cpu-baseline
 run bench_line_encdec python3 bench.py --mode encode_decode
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r5 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline --no-side-lines > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r5 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline --no-extras > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$root/$out/pmc_$c" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_$c.err" < /dev/null; echo "pmc $c rc=$?" )
 done
