@@ -959,9 +959,14 @@ def test_conv_upsample_phases_store_bf16_in_the_f16_build():
     ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
     got = ybf.t[:n].float().view(B, 2 * H, 2 * W, C).permute(0, 3, 1, 2).cpu()
     close(got, ref, rms=6e-3, mx=5e-2, what="upsample phases, bf16 stored by the f16 build")
-    # bf16(f32 sum) against bf16(f16(f32 sum)): equal except where the double rounding crosses a bf16 tie
+    # bf16(f32 sum) against bf16(f16(f32 sum)): f16 keeps 3 bits more than bf16, so one f16 value in 8 sits exactly on a bf16 tie and
+    # the direct rounding went the other way for half of those: 6.25 % of the elements differ, each by exactly one bf16 ulp
     twice = y16.t[:n].float().to(torch.bfloat16)
-    assert float((twice != ybf.t[:n]).float().mean()) < 2e-3
+    differ = twice != ybf.t[:n]
+    assert 0.03 < float(differ.float().mean()) < 0.09
+    a, b = twice.view(torch.int16).int(), ybf.t[:n].view(torch.int16).int()
+    big = y16.t[:n].float().abs() > 2.0 ** -10          # (below, f16's own precision falls under bf16's: subnormals)
+    assert int((a - b).abs()[big].max()) == 1 and int((a - b).abs().max()) <= 8
     assert torch.equal(y16.stats.t, ybf.stats.t)                       # statistics come from the f32 values
     with pytest.raises(K.KernelError):                                 # the 8-wave phase kernel stores the build's format only
         K.conv_gemm(xv, wp, b.to(DEV), ybf, KH=3, up=2, Cin=Cin, Cout=C, out_bf16=True, tile=130)
