@@ -214,7 +214,11 @@ int onedc_softmax_rows(const float *s, void *p, int64_t rows, int n, int n_pad, 
  * (DQ, DV) in {(64,48), (128,96), (160,160), (32,16)}: head dims 40 / 80 / 160 (decoder UNet) and 8 (the
  * analysis UNet2DModel of the encode side), zero-padded by the packed projection weights.  Head dim 80 is laid out as two
  * half-heads of the d = 40 layout: q / k dims [0..39 | 24 zeros | 40..79 | 24 zeros], v rows [0..39 | 8 zeros | 40..79 |
- * 8 zeros] (onedc_amd/pack.py: head_positions); o has the v layout.  scale multiplies q.k before the softmax. */
+ * 8 zeros] (onedc_amd/pack.py: head_positions); o has the v layout.  scale multiplies q.k before the softmax.
+ * COMPACT heads (round 5): (DQ, DV) = (40, 40) or (80, 80) with Nk >= 64 -- q / k / o rows hold H x d REAL dims back to back, vt
+ * H x d rows; the kernels build the padded LDS images themselves (padding chunks and rows are DMA'd from a page of zeros, like
+ * the constant-1 chunk and the ones row of the softmax trick), so the projections in front and behind compute and move no padded
+ * columns.  Results are bit-identical to the padded layout.  Fewer than 64 keys: -3 (use the padded layout). */
 int onedc_flash_attn(const void *q, const void *k, const void *vt, void *o, int B, int H, int Nq,
                      int Nk, int Nk_pad, int DQ, int DV, float scale, void *stream);
 /* The same with strides: q_rs / k_rs = elements between consecutive query / key rows (q, k as column slices of one wider

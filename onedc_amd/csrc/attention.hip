@@ -296,6 +296,12 @@ __device__ const uint32_t g_ones_page[64] = {
 // bf16 {1, 0, 0, 0, 0, 0, 0, 0}: stands in for chunk 5 (the all-padding dims 40..47) of every K row, so
 // that dim 40 of the S product is a free "+ 1 * q[40]" term: q[40] carries -m_run
 __device__ const uint32_t g_kone_page[4] = {ONEDC_A16_ONE, 0u, 0u, 0u};
+// COMPACT heads (round 5): Q, K, V^T and O hold the d REAL dims of a head back to back in memory (head stride d = 40 / 80 elements
+// instead of the padded 64 / 48 / 128 / 96); the padding only exists in LDS and in registers: the 16-byte chunks of a K row and
+// the V^T rows that are padding are DMA'd from this page of zeros, like the constant-1 chunk and the ones row already are.  The
+// projections then compute and move no padded columns (to_q|k 320 -> 640 instead of -> 1024, to_out K = 320 instead of 384), and
+// the values every MFMA sees are the same as with padded tensors: bit-identical results.
+__device__ const uint32_t g_zero_page[64] = {0u};
 
 constexpr int FA64_K = 64 * 128;                 // K tile bytes
 constexpr int FA64_V = 48 * 128;                 // V^T tile bytes
@@ -318,6 +324,7 @@ __device__ __forceinline__ void fa_glds16(const char *src, char *lds_dst) {
 #define FA64_QT 4
 #define FA64_OCC 2
 #endif
+template <bool COMPACT>
 __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t *__restrict__ Q,
                                                               const a16_t *__restrict__ K,
                                                               const a16_t *__restrict__ VT,
@@ -325,6 +332,7 @@ __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t
                                                               int Nk_pad, float scale_log2e, int d_real, int q_rs, int k_rs,
                                                               int64_t vt_bs) {
     constexpr int DQ = 64, DV = 48, QT = FA64_QT, QW = 64 * QT;      // QW: queries per workgroup
+    constexpr int HQ = COMPACT ? 40 : DQ, HV = COMPACT ? 40 : DV;    // head strides in memory (elements / V^T rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -347,7 +355,8 @@ __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t
         for (int ks = 0; ks < 2; ++ks) {
             union { a16x8 v; uint32_t u[4]; } f;
             f.v = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * q_rs + h * DQ + ks * 32 + g * 8);
+            if (qi < Nq && (!COMPACT || ks * 4 + g < 5))
+                f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * q_rs + h * HQ + ks * 32 + g * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 f.u[e] = pack_a2(a2f((a16_t)(f.u[e] & 0xffff)) * scale_log2e, a2f((a16_t)(f.u[e] >> 16)) * scale_log2e);
@@ -366,26 +375,29 @@ __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t
     // ---- DMA geometry: 14 blocks of 8 LDS rows per tile: K blocks 0..7 (two per wave), V^T blocks 0..5
     // (waves 0, 1: two; waves 2, 3: one).  lane -> (row in block, 16-byte chunk)
     const int lrow = lane >> 3, lch = lane & 7;
-    const char *Kb = (const char *)(K + (int64_t)b * Nk * k_rs + h * DQ);
-    const char *Vb = (const char *)(VT + (int64_t)b * vt_bs + (int64_t)h * DV * Nk_pad);
+    const char *Kb = (const char *)(K + (int64_t)b * Nk * k_rs + h * HQ);
+    const char *Vb = (const char *)(VT + (int64_t)b * vt_bs + (int64_t)h * HV * Nk_pad);
     const int64_t krow_bytes = (int64_t)k_rs * 2;
     const int64_t vrow_bytes = (int64_t)Nk_pad * 2;
     int krow[2], kchunk[2];
+    const char *kfix[2];                              // the constant source of this lane's chunk (nullptr: the K row itself)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         krow[i] = (wave + 4 * i) * 8 + lrow;                                  // key row inside the tile
         kchunk[i] = lch ^ ((krow[i] & 3) | (((krow[i] >> 3) & 1) << 2));
+        kfix[i] = kchunk[i] == 5 ? (const char *)g_kone_page : (COMPACT && kchunk[i] > 5) ? (const char *)g_zero_page : nullptr;
     }
     const int nvb = wave < 2 ? 2 : 1;                                         // V^T blocks of this wave
     int vrow[2];
     const char *vsrc[2];
-    bool vones[2];
+    bool vones[2];                                    // (constant source: the ones row; COMPACT: the padding rows too)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         vrow[i] = (wave + 4 * i) * 8 + lrow;                                  // < 48 for the blocks that exist
         const int ch = lch ^ (vrow[i] & 7);
-        vones[i] = vrow[i] == d_real;
-        vsrc[i] = vones[i] ? (const char *)g_ones_page + ch * 16 : Vb + (int64_t)vrow[i] * vrow_bytes + ch * 16;
+        vones[i] = vrow[i] == d_real || (COMPACT && vrow[i] > d_real);
+        vsrc[i] = vrow[i] == d_real ? (const char *)g_ones_page + ch * 16
+                  : (COMPACT && vrow[i] > d_real) ? (const char *)g_zero_page : Vb + (int64_t)vrow[i] * vrow_bytes + ch * 16;
     }
     auto issue = [&](int tile, char *stage) {
         const int k0 = tile * 64;
@@ -393,8 +405,7 @@ __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t
         for (int i = 0; i < 2; ++i) {
             int key = k0 + krow[i];
             key = key < Nk ? key : Nk - 1;                                    // tail rows: any valid row, masked below
-            fa_glds16(kchunk[i] == 5 ? (const char *)g_kone_page : Kb + (int64_t)key * krow_bytes + kchunk[i] * 16,
-                      stage + (wave + 4 * i) * 1024);
+            fa_glds16(kfix[i] ? kfix[i] : Kb + (int64_t)key * krow_bytes + kchunk[i] * 16, stage + (wave + 4 * i) * 1024);
         }
         fa_glds16(vsrc[0] + (vones[0] ? 0 : (int64_t)k0 * 2), stage + FA64_K + wave * 1024);
         if (nvb == 2) fa_glds16(vsrc[1] + (vones[1] ? 0 : (int64_t)k0 * 2), stage + FA64_K + (wave + 4) * 1024);
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t
         const float inv = 1.f / l;
         const int qi = q0 + t * 16 + r;
         if (qi >= Nq) continue;
-        a16_t *op = O + ((int64_t)b * Nq + qi) * (H * DV) + h * DV + g * 4;
+        a16_t *op = O + ((int64_t)b * Nq + qi) * (H * HV) + h * HV + g * 4;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float v[4];
@@ -629,7 +640,8 @@ __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t
                 v[e] = o[d][t][e] * inv;
                 if (d * 16 + g * 4 + e >= d_real) v[e] = 0.f;
             }
-            *(uint2 *)(op + d * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
+            if (!COMPACT || d * 16 + g * 4 < 40)      // (COMPACT: only the real dims exist in memory; 40 is a multiple of 4)
+                *(uint2 *)(op + d * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         }
     }
 }
@@ -644,6 +656,7 @@ __global__ __launch_bounds__(256, FA64_OCC) void flash_attn64_kernel(const a16_t
 // workgroup per CU: each K / V^T byte is staged once per 256 queries, as in the d = 40 kernel.
 constexpr int FA80_STAGE = 2 * FA64_K + 2 * FA64_V;      // 28 KB
 
+template <bool COMPACT>
 __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__restrict__ Q,
                                                               const a16_t *__restrict__ K,
                                                               const a16_t *__restrict__ VT,
@@ -651,6 +664,8 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
                                                               int Nk_pad, float scale_log2e, int d_real, int q_rs, int k_rs,
                                                               int64_t vt_bs) {
     constexpr int DQ = 128, DV = 96, QT = 2;   // two half-heads of (64, 48): dims 0..39 | pad | 40..79 | pad
+    constexpr int HQ = COMPACT ? 80 : DQ, HV = COMPACT ? 80 : DV;    // head strides in memory; COMPACT: dims 0..79 back to back
+    constexpr int HALF_Q = COMPACT ? 40 : 64, HALF_V = COMPACT ? 40 : 48;   // where the second half-head starts
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -673,7 +688,9 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
         for (int ks = 0; ks < 4; ++ks) {
             union { a16x8 v; uint32_t u[4]; } f;
             f.v = a16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi < Nq) f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * q_rs + h * DQ + ks * 32 + g * 8);
+            // k step ks covers chunks 4 (ks & 1) + g of half-head ks >> 1
+            if (qi < Nq && (!COMPACT || (ks & 1) * 4 + g < 5))
+                f.v = *(const a16x8 *)(Q + ((int64_t)b * Nq + qi) * q_rs + h * HQ + (ks >> 1) * HALF_Q + (ks & 1) * 32 + g * 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 f.u[e] = pack_a2(a2f((a16_t)(f.u[e] & 0xffff)) * scale_log2e, a2f((a16_t)(f.u[e] >> 16)) * scale_log2e);
@@ -692,31 +709,37 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
     // ---- DMA geometry: a stage is [K half 0 | K half 1 | V^T half 0 | V^T half 1] = 28 blocks of 8 LDS rows: wave w moves
     // K rows 8 w .. of both halves, V^T block w and (w < 4) block w + 8 (block vb: half vb / 6, rows 8 (vb % 6) ..)
     const int lrow = lane >> 3, lch = lane & 7;
-    const char *Kb = (const char *)(K + (int64_t)b * Nk * k_rs + h * DQ);
-    const char *Vb = (const char *)(VT + (int64_t)b * vt_bs + (int64_t)h * DV * Nk_pad);
+    const char *Kb = (const char *)(K + (int64_t)b * Nk * k_rs + h * HQ);
+    const char *Vb = (const char *)(VT + (int64_t)b * vt_bs + (int64_t)h * HV * Nk_pad);
     const int64_t krow_bytes = (int64_t)k_rs * 2;
     const int64_t vrow_bytes = (int64_t)Nk_pad * 2;
     const int krow = wave * 8 + lrow;                                         // key row inside the tile
     const int kchunk = lch ^ ((krow & 3) | (((krow >> 3) & 1) << 2));
+    // constant sources of this lane's chunk in the two half tiles (nullptr: the K row itself)
+    const char *const kfix0 = kchunk == 5 ? (const char *)g_kone_page : (COMPACT && kchunk > 5) ? (const char *)g_zero_page : nullptr;
+    const char *const kfix1 = (COMPACT && kchunk >= 5) ? (const char *)g_zero_page : nullptr;
     const int nvb = wave < 4 ? 2 : 1;                                         // V^T blocks of this wave
     int vrow[2];
     const char *vsrc[2];
-    bool vones[2];
+    bool vones[2];                                    // (constant source: the ones row; COMPACT: the padding rows too)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int vb = wave + 8 * i, hf = vb >= 6 ? 1 : 0;                    // (vb < 12 for the blocks that exist)
         vrow[i] = (vb - 6 * hf) * 8 + lrow;                                   // row inside the half: 0 .. 47
         const int ch = lch ^ (vrow[i] & 7);
-        vones[i] = hf == 0 && vrow[i] == d_real;                              // the row that accumulates the denominator
-        vsrc[i] = vones[i] ? (const char *)g_ones_page + ch * 16 : Vb + (int64_t)(hf * 48 + vrow[i]) * vrow_bytes + ch * 16;
+        const bool ones = hf == 0 && vrow[i] == d_real;                       // the row that accumulates the denominator
+        const bool pad = COMPACT && vrow[i] >= 40 && !ones;
+        vones[i] = ones || pad;
+        vsrc[i] = ones ? (const char *)g_ones_page + ch * 16 : pad ? (const char *)g_zero_page
+                       : Vb + (int64_t)(hf * HALF_V + vrow[i]) * vrow_bytes + ch * 16;
     }
     auto issue = [&](int tile, char *stage) {
         const int k0 = tile * 64;
         int key = k0 + krow;
         key = key < Nk ? key : Nk - 1;                                        // tail rows: any valid row, masked below
         const char *ksrc = Kb + (int64_t)key * krow_bytes + kchunk * 16;
-        fa_glds16(kchunk == 5 ? (const char *)g_kone_page : ksrc, stage + wave * 1024);      // half 0: dim 40 reads as 1
-        fa_glds16(ksrc + 128, stage + FA64_K + wave * 1024);                                 // half 1: dims 64 ..
+        fa_glds16(kfix0 ? kfix0 : ksrc, stage + wave * 1024);                                // half 0: dim 40 reads as 1
+        fa_glds16(kfix1 ? kfix1 : ksrc + HALF_Q * 2, stage + FA64_K + wave * 1024);          // half 1: dims 40 .. 79
         fa_glds16(vsrc[0] + (vones[0] ? 0 : (int64_t)k0 * 2), stage + 2 * FA64_K + wave * 1024);
         if (nvb == 2) fa_glds16(vsrc[1] + (vones[1] ? 0 : (int64_t)k0 * 2), stage + 2 * FA64_K + (wave + 8) * 1024);
     };
@@ -934,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
         const float inv = 1.f / l;
         const int qi = q0 + t * 16 + r;
         if (qi >= Nq) continue;
-        a16_t *op = O + ((int64_t)b * Nq + qi) * (H * DV) + h * DV + g * 4;
+        a16_t *op = O + ((int64_t)b * Nq + qi) * (H * HV) + h * HV + g * 4;
 #pragma unroll
         for (int d = 0; d < 6; ++d) {
             float v[4];
@@ -943,7 +966,10 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
                 v[e] = o[d][t][e] * inv;
                 if ((d % 3) * 16 + g * 4 + e >= d_real) v[e] = 0.f;
             }
-            *(uint2 *)(op + d * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
+            // padded: rows 16 d of [half 0: 48 | half 1: 48]; COMPACT: only the 40 real dims of each half exist
+            if (!COMPACT) *(uint2 *)(op + d * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
+            else if ((d % 3) * 16 + g * 4 < 40)
+                *(uint2 *)(op + (d / 3) * 40 + (d % 3) * 16) = make_uint2(pack_a2(v[0], v[1]), pack_a2(v[2], v[3]));
         }
     }
 }
@@ -953,7 +979,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn80_kernel(const a16_t *__res
 // 1 when the kernel onedc_flash_attn picks for (DQ, DV, Nk) reads V^T as bf16 in EITHER build of the library (the d = 40
 // kernel: flash_attn64_kernel), 0 when V^T is in the library's own 16-bit format
 extern "C" int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk) {
-    return ((DQ == 64 && DV == 48) || (DQ == 128 && DV == 96)) && Nk >= 64;
+    return ((DQ == 64 && DV == 48) || (DQ == 128 && DV == 96) || (DQ == 40 && DV == 40) || (DQ == 80 && DV == 80)) && Nk >= 64;
 }
 
 // q_rs / k_rs: elements between consecutive query / key rows (>= H * DQ: q and k may be column slices of one wider
@@ -974,16 +1000,31 @@ extern "C" int onedc_flash_attn_strided(const void *q, const void *k, const void
 #define FA_LAUNCH(dq, dv, ones, pre, dreal)                                                                   \
     hipLaunchKernelGGL((flash_attn_kernel<dq, dv, ones, pre>), grid, block, 0, st, (const a16_t *)q,          \
                        (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c, dreal, q_rs, k_rs, vt_bs)
-    if (DQ == 64 && DV == 48 && Nk >= 64) {
+    // (DQ, DV) = (40, 40) / (80, 80): COMPACT heads (round 5) -- q / k / o rows hold H x d real dims, V^T H x d rows; the padding
+    // is made on the DMA path.  Only the two ring kernels read that layout (64 keys and more): -3 otherwise.
+    if ((DQ == 40 && DV == 40) || (DQ == 80 && DV == 80)) {
+        if (Nk < 64) return -3;
         static OnedcLdsAttrOnce once;
-        once.ensure({{(const void *)flash_attn64_kernel, FA64_NST * FA64_STAGE}});
-        hipLaunchKernelGGL(flash_attn64_kernel, dim3(((Nq + 64 * FA64_QT - 1) / (64 * FA64_QT)) * H * B), block, FA64_NST * FA64_STAGE, st,
+        once.ensure({{(const void *)flash_attn64_kernel<true>, FA64_NST * FA64_STAGE},
+                     {(const void *)flash_attn80_kernel<true>, FA64_NST * FA80_STAGE}});
+        if (DQ == 40)
+            hipLaunchKernelGGL(flash_attn64_kernel<true>, dim3(((Nq + 64 * FA64_QT - 1) / (64 * FA64_QT)) * H * B), block,
+                               FA64_NST * FA64_STAGE, st, (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk,
+                               Nk_pad, c, 40, q_rs, k_rs, vt_bs);
+        else
+            hipLaunchKernelGGL(flash_attn80_kernel<true>, dim3(((Nq + 255) / 256) * H * B), dim3(512), FA64_NST * FA80_STAGE, st,
+                               (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c, 40, q_rs, k_rs,
+                               vt_bs);
+    } else if (DQ == 64 && DV == 48 && Nk >= 64) {
+        static OnedcLdsAttrOnce once;
+        once.ensure({{(const void *)flash_attn64_kernel<false>, FA64_NST * FA64_STAGE}});
+        hipLaunchKernelGGL(flash_attn64_kernel<false>, dim3(((Nq + 64 * FA64_QT - 1) / (64 * FA64_QT)) * H * B), block, FA64_NST * FA64_STAGE, st,
                            (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
                            40, q_rs, k_rs, vt_bs);
     } else if (DQ == 128 && DV == 96 && Nk >= 64) {
         static OnedcLdsAttrOnce once;
-        once.ensure({{(const void *)flash_attn80_kernel, FA64_NST * FA80_STAGE}});
-        hipLaunchKernelGGL(flash_attn80_kernel, dim3(((Nq + 255) / 256) * H * B), dim3(512), FA64_NST * FA80_STAGE, st,
+        once.ensure({{(const void *)flash_attn80_kernel<false>, FA64_NST * FA80_STAGE}});
+        hipLaunchKernelGGL(flash_attn80_kernel<false>, dim3(((Nq + 255) / 256) * H * B), dim3(512), FA64_NST * FA80_STAGE, st,
                            (const a16_t *)q, (const a16_t *)k, (const a16_t *)vt, (a16_t *)o, H, Nq, Nk, Nk_pad, c,
                            40, q_rs, k_rs, vt_bs);
     } else if (DQ == 64 && DV == 48) FA_LAUNCH(64, 48, true, true, 40);

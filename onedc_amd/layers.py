@@ -336,8 +336,17 @@ class ResnetBlock2D:
         return self.c2(h, y, res=res, stats=True, gn=(self.n2, ws, True), alpha=self.stream_scale)
 
 
+# Compact heads (round 5): q / k / V^T / o tensors of the d = 40 and d = 80 attention layers hold the REAL head dims back to back
+# (the flash kernels make the padding on their DMA path: onedc_flash_attn with DQ = DV = d), so the projections compute and move
+# no padded columns -- to_q|k 320 -> 640 instead of -> 1024, to_out with K = 320 instead of 384.  Bit-identical to the padded
+# layout (the MFMAs see the same values).  Only the two ring kernels read it, i.e. 64 keys and more: a layer keeps both packings
+# and decides per call.  ONEDC_COMPACT_HEADS=0: the padded layout everywhere (A/B, tests).
+COMPACT_HEADS = __import__("os").environ.get("ONEDC_COMPACT_HEADS", "1") != "0"
+
+
 class MultiHeadAttention:
-    """diffusers Attention (8 heads) on flash attention; projections zero-pad the head dim.
+    """diffusers Attention (8 heads) on flash attention; the projections zero-pad the head dim, or -- head dims 40 / 80 with 64
+    keys and more -- leave it compact (COMPACT_HEADS above).
 
     Self-attention (`ctx_dim == C`, keys = queries): to_q and to_k are ONE GEMM whose output rows are [q | k]
     (`onedc_flash_attn_strided` reads both as column slices of it).  Cross-attention: K and V^T depend on the context only,
@@ -350,29 +359,44 @@ class MultiHeadAttention:
         self.DQ, self.DV = pack.HEAD_PAD[d]
         self.C, self.ctx_dim = C, ctx_dim
         self.self_attention = (ctx_dim == C) if self_attention is None else self_attention
+        self.compact = COMPACT_HEADS and d in (40, 80)
         wq = pack.pad_heads_rows(sd[f"{p}.to_q.weight"], heads, d, self.DQ)
         self.wk_rows = pack.pad_heads_rows(sd[f"{p}.to_k.weight"], heads, d, self.DQ)      # (kept on the host for ContextKV)
         self.wv_rows = pack.pad_heads_rows(sd[f"{p}.to_v.weight"], heads, d, self.DV)
+        self.wk_rows_c = self.wv_rows_c = None
         if self.self_attention:
             self.qk = Conv(sd, "", device, weight=torch.cat([wq, self.wk_rows], 0), flop_scale=d / self.DQ)
             self.wv = View(pack.pack_matrix(self.wv_rows, device), 1, 1, heads * self.DV, ctx_dim)
             self.wk_rows = self.wv_rows = None
+            if self.compact:
+                self.qk_c = Conv(sd, "", device, weight=torch.cat([sd[f"{p}.to_q.weight"], sd[f"{p}.to_k.weight"]], 0))
+                self.wv_c = View(pack.pack_matrix(sd[f"{p}.to_v.weight"], device), 1, 1, heads * d, ctx_dim)
         else:
             self.q = Conv(sd, "", device, weight=wq, flop_scale=d / self.DQ)
+            if self.compact:
+                self.q_c = Conv(sd, "", device, weight=sd[f"{p}.to_q.weight"])
+                self.wk_rows_c, self.wv_rows_c = sd[f"{p}.to_k.weight"], sd[f"{p}.to_v.weight"]   # (for ContextKV)
         self.o = Conv(sd, "", device, weight=pack.pad_heads_cols(sd[f"{p}.to_out.0.weight"], heads, d, self.DV),
                       bias=sd[f"{p}.to_out.0.bias"], flop_scale=d / self.DV)
+        if self.compact:
+            self.o_c = Conv(sd, "", device, weight=sd[f"{p}.to_out.0.weight"], bias=sd[f"{p}.to_out.0.bias"])
 
     def __call__(self, x, ctx, res, y=None, ws=None, kv=None):
         """x: query tokens View (B, H, W, C); ctx: key/value tokens View; res: residual.
-        kv = (k tensor, k row stride, V^T tensor, V^T image stride) from ContextKV (cross-attention)."""
+        kv = (k tensor, k row stride, V^T tensor, V^T image stride, compact) from ContextKV (cross-attention)."""
         dev = x.t.device
         B, Nq, Nk = x.B, x.H * x.W, ctx.H * ctx.W
         Nk_pad = (Nk + 63) // 64 * 64
-        HDQ, HDV = self.H * self.DQ, self.H * self.DV
+        if self.self_attention or kv is None:
+            compact = self.compact and Nk >= 64
+        else:
+            compact = bool(kv[4])
+        DQ, DV = (self.d, self.d) if compact else (self.DQ, self.DV)
+        HDQ, HDV = self.H * DQ, self.H * DV
         if self.self_attention:
-            qk = self.qk(x)                                          # rows [q (H DQ) | k (H DQ)]
+            qk = (self.qk_c if compact else self.qk)(x)              # rows [q (H DQ) | k (H DQ)]
             q_t, k_t, q_rs, k_rs = qk.t, qk.t[HDQ:], 2 * HDQ, 2 * HDQ
-            vt_dtype = K.flash_vt_dtype(self.DQ, self.DV, Nk)
+            vt_dtype = K.flash_vt_dtype(DQ, DV, Nk)
             n = B * HDV * Nk_pad
             if Nk == Nk_pad:
                 vt = torch.empty(n, dtype=vt_dtype, device=dev)
@@ -380,9 +404,9 @@ class MultiHeadAttention:
                 vt = ws.zeros(f"mha_vt_{B}_{HDV}_{Nk}_{vt_dtype}", n, vt_dtype)
             else:
                 vt = torch.zeros(n, dtype=vt_dtype, device=dev)
-            K.conv_gemm(self.wv, ctx.t, None, View(vt, 1, 1, HDV, Nk, Nk_pad), Cin=self.ctx_dim,
+            K.conv_gemm(self.wv_c if compact else self.wv, ctx.t, None, View(vt, 1, 1, HDV, Nk, Nk_pad), Cin=self.ctx_dim,
                         Cout=Nk, batch=B, x_bs=0, w_bs=Nk * ctx.cs, y_bs=HDV * Nk_pad,
-                        flop_scale=self.d / self.DV, out_bf16=(vt_dtype == torch.bfloat16))
+                        flop_scale=self.d / DV, out_bf16=(vt_dtype == torch.bfloat16))
             vt_bs = 0
         else:
             if kv is None:                       # stand-alone use: this layer's own projections, packed once
@@ -391,77 +415,95 @@ class MultiHeadAttention:
                         raise RuntimeError("this cross-attention layer's to_k / to_v live in a shared ContextKV: pass its `kv`")
                     self._own_kv = ContextKV([self], dev)
                 kv = self._own_kv(ctx, ws)[0]
-            k_t, k_rs, vt, vt_bs = kv
-            q = self.q(x)
+                compact = bool(kv[4])
+                DQ, DV = (self.d, self.d) if compact else (self.DQ, self.DV)
+                HDQ, HDV = self.H * DQ, self.H * DV
+            k_t, k_rs, vt, vt_bs = kv[:4]
+            q = (self.q_c if compact else self.q)(x)
             q_t, q_rs = q.t, HDQ
         o = new_view(x.B, x.H, x.W, HDV, dev)
-        K.flash_attn(q_t, k_t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, self.DQ, self.DV, self.d ** -0.5,
+        K.flash_attn(q_t, k_t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, DQ, DV, self.d ** -0.5,
                      q_rs=q_rs, k_rs=k_rs, vt_bs=vt_bs)
-        return self.o(o, y, res=res)
+        return (self.o_c if compact else self.o)(o, y, res=res)
+
+
+class _ContextKVSet:
+    """One packing of the shared context projections: K of all layers as one GEMM, V^T of all layers as one batched GEMM (two in
+    the IEEE-half build: the d = 40 / 80 kernels read V^T as bf16, the d = 160 kernel as f16)."""
+
+    def __init__(self, layers, order, device, compact):
+        self.compact = compact
+        self.ctx_dim = layers[0].ctx_dim
+        wk, wv, self.k_off, self.v_off = [], [], {}, {}
+        ko = vo = 0
+        real = padded = 0
+        for i in order:
+            l = layers[i]
+            c = compact and l.compact
+            wk.append(l.wk_rows_c if c else l.wk_rows)
+            wv.append(l.wv_rows_c if c else l.wv_rows)
+            self.k_off[i], self.v_off[i] = ko, vo
+            ko += l.H * (l.d if c else l.DQ)
+            vo += l.H * (l.d if c else l.DV)
+            real += l.H * l.d
+            padded += l.H * (l.d if c else l.DQ)
+        self.k_cols, self.v_rows = ko, vo
+        self.v_split = sum(l.H * (l.d if (compact and l.compact) else l.DV) for l in layers if l.d < 160)   # rows [0, v_split): head dims 40 / 80
+        self.k = Conv({}, "", device, weight=torch.cat(wk, 0), flop_scale=real / padded)
+        self.wv = View(pack.pack_matrix(torch.cat(wv, 0), device), 1, 1, vo, self.ctx_dim)
+        self.v_scale = sum(l.H * l.d for l in layers) / vo
 
 
 class ContextKV:
     """to_k / to_v of every cross-attention layer that reads ONE context (the UNet's 16 transformer blocks all attend to
     y_semantic: reference decoder_unet.py:204-293 passes the same `encoder_hidden_states` down): K of all layers is one GEMM
     [tokens][sum H DQ], V^T of all layers one batched GEMM [image][sum H DV][keys] (two in the IEEE-half build when the
-    d = 40 / 80 kernels take their V^T as bf16 and the d = 160 kernel as f16) -- 3 launches per UNet step instead of 32."""
+    d = 40 / 80 kernels take their V^T as bf16 and the d = 160 kernel as f16) -- 3 launches per UNet step instead of 32.
+    Two packings where layers have compact heads (COMPACT_HEADS): the padded one for contexts of fewer than 64 tokens."""
 
     def __init__(self, layers, device):
         # V^T rows: the layers whose kernel may want bf16 V^T first (head dims 40, 80), so that each dtype is one row range
         self.layers = list(layers)
         order = sorted(range(len(self.layers)), key=lambda i: (self.layers[i].d >= 160, i))
         self.ctx_dim = self.layers[0].ctx_dim
-        wk, wv, self.k_off, self.v_off = [], [], {}, {}
-        ko = vo = 0
-        real = padded = 0
-        for i in order:
-            l = self.layers[i]
-            wk.append(l.wk_rows)
-            wv.append(l.wv_rows)
-            self.k_off[i], self.v_off[i] = ko, vo
-            ko += l.H * l.DQ
-            vo += l.H * l.DV
-            real += l.H * l.d
-            padded += l.H * l.DQ
-        self.k_cols, self.v_rows = ko, vo
-        self.v_split = sum(l.H * l.DV for l in self.layers if l.d < 160)           # rows [0, v_split): head dims 40 / 80
-        self.k = Conv({}, "", device, weight=torch.cat(wk, 0), flop_scale=real / padded)
-        self.wv = View(pack.pack_matrix(torch.cat(wv, 0), device), 1, 1, vo, self.ctx_dim)
-        self.v_scale = sum(l.H * l.d for l in self.layers) / vo
+        self.padded = _ContextKVSet(self.layers, order, device, False)
+        self.compact = _ContextKVSet(self.layers, order, device, True) if any(l.compact for l in self.layers) else None
         for l in self.layers:
-            l.wk_rows = l.wv_rows = None                                           # packed: drop the host copies
+            l.wk_rows = l.wv_rows = l.wk_rows_c = l.wv_rows_c = None              # packed: drop the host copies
 
     def __call__(self, ctx, ws=None):
-        """-> per layer (k tensor, k row stride, V^T tensor, V^T image stride), in the order the layers were given."""
+        """-> per layer (k tensor, k row stride, V^T tensor, V^T image stride, compact), in the order the layers were given."""
         dev = ctx.t.device
         B, Nk = ctx.B, ctx.H * ctx.W
         Nk_pad = (Nk + 63) // 64 * 64
-        k = self.k(ctx)                                             # (B, h, w, sum H DQ)
+        S = self.compact if (self.compact is not None and Nk >= 64) else self.padded
+        k = S.k(ctx)                                                # (B, h, w, sum H DQ)
         small = [l for l in self.layers if l.d < 160]
-        bf16_rows = self.v_split if small and K.flash_vt_dtype(small[0].DQ, small[0].DV, Nk) == torch.bfloat16 else 0
+        dqv = (lambda l: (l.d, l.d) if (S.compact and l.compact) else (l.DQ, l.DV))
+        bf16_rows = S.v_split if small and K.flash_vt_dtype(*dqv(small[0]), Nk) == torch.bfloat16 else 0
         if K.a16() == torch.bfloat16:
             bf16_rows = 0                                           # one format anyway
         # ONE buffer of 16-bit words for all layers (bf16 and f16 are both 2 bytes: the row ranges are written as what
         # their readers expect)
-        n = B * self.v_rows * Nk_pad
+        n = B * S.v_rows * Nk_pad
         if Nk == Nk_pad:
             vt = torch.empty(n, dtype=K.a16(), device=dev)
         elif ws is not None:
-            vt = ws.zeros(f"ctx_vt_{B}_{self.v_rows}_{Nk}", n, K.a16())
+            vt = ws.zeros(f"ctx_vt_{B}_{S.v_rows}_{Nk}", n, K.a16())
         else:
             vt = torch.zeros(n, dtype=K.a16(), device=dev)
-        vt_bs = self.v_rows * Nk_pad
-        for r0, r1, as_bf16 in ((0, bf16_rows, True), (bf16_rows, self.v_rows, False)):
+        vt_bs = S.v_rows * Nk_pad
+        for r0, r1, as_bf16 in ((0, bf16_rows, True), (bf16_rows, S.v_rows, False)):
             if r1 > r0:
-                K.conv_gemm(View(self.wv.t.view(-1)[r0 * self.ctx_dim:], 1, 1, r1 - r0, self.ctx_dim), ctx.t, None,
+                K.conv_gemm(View(S.wv.t.view(-1)[r0 * self.ctx_dim:], 1, 1, r1 - r0, self.ctx_dim), ctx.t, None,
                             View(vt[r0 * Nk_pad:], 1, 1, r1 - r0, Nk, Nk_pad), Cin=self.ctx_dim, Cout=Nk, batch=B, x_bs=0,
-                            w_bs=Nk * ctx.cs, y_bs=vt_bs, flop_scale=self.v_scale, out_bf16=as_bf16)
+                            w_bs=Nk * ctx.cs, y_bs=vt_bs, flop_scale=S.v_scale, out_bf16=as_bf16)
         out = []
         for i, l in enumerate(self.layers):
-            vt_l = vt[self.v_off[i] * Nk_pad:]
-            if self.v_off[i] < bf16_rows:
+            vt_l = vt[S.v_off[i] * Nk_pad:]
+            if S.v_off[i] < bf16_rows:
                 vt_l = vt_l.view(torch.bfloat16)                    # same bytes, the dtype its kernel asks for
-            out.append((k.t[self.k_off[i]:], self.k_cols, vt_l, vt_bs))
+            out.append((k.t[S.k_off[i]:], S.k_cols, vt_l, vt_bs, S.compact and l.compact))
         return out
 
 

@@ -303,19 +303,90 @@ def test_context_kv_equals_per_layer_projections():
         Nk = hw[0] * hw[1]
         Nk_pad = (Nk + 63) // 64 * 64
         kvs = ContextKV(layers, DEV)(ctx, ws)
-        for l, sd, (k_t, k_rs, vt, vt_bs) in zip(layers, sds, kvs):
-            k_own = Conv({}, "", DEV, weight=pack.pad_heads_rows(sd["a.to_k.weight"], 8, l.d, l.DQ))(ctx)
-            HDQ, HDV = 8 * l.DQ, 8 * l.DV
+        for l, sd, (k_t, k_rs, vt, vt_bs, compact) in zip(layers, sds, kvs):
+            # 144 keys: the d = 40 / 80 layers get the COMPACT packing (real head dims back to back, round 5), 6 keys: the padded one
+            assert bool(compact) == (l.compact and Nk >= 64)
+            DQ, DV = (l.d, l.d) if compact else (l.DQ, l.DV)
+            rows = (lambda w, dp: w if compact else pack.pad_heads_rows(w, 8, l.d, dp))
+            k_own = Conv({}, "", DEV, weight=rows(sd["a.to_k.weight"], l.DQ))(ctx)
+            HDQ, HDV = 8 * DQ, 8 * DV
             got_k = torch.as_strided(k_t, (2 * Nk, HDQ), (k_rs, 1))
             assert torch.equal(got_k, k_own.t[:2 * Nk * HDQ].view(2 * Nk, HDQ))
-            vdt = K.flash_vt_dtype(l.DQ, l.DV, Nk)
+            vdt = K.flash_vt_dtype(DQ, DV, Nk)
             assert vt.dtype == vdt
             own = torch.zeros(2 * HDV * Nk_pad, dtype=vdt, device=DEV)
-            wv = View(pack.pack_matrix(pack.pad_heads_rows(sd["a.to_v.weight"], 8, l.d, l.DV), DEV), 1, 1, HDV, 768)
+            wv = View(pack.pack_matrix(rows(sd["a.to_v.weight"], l.DV), DEV), 1, 1, HDV, 768)
             K.conv_gemm(wv, ctx.t, None, View(own, 1, 1, HDV, Nk, Nk_pad), Cin=768, Cout=Nk, batch=2, x_bs=0, w_bs=Nk * ctx.cs,
                         y_bs=HDV * Nk_pad, out_bf16=(vdt == torch.bfloat16))
             got_v = torch.as_strided(vt, (2, HDV, Nk_pad), (vt_bs, Nk_pad, 1))
             assert torch.equal(got_v, own.view(2, HDV, Nk_pad))
+
+
+@pytest.mark.parametrize("d,Nq,Nk", [(40, 300, 300), (40, 256, 144), (40, 1024, 1024), (80, 300, 300), (80, 192, 144), (80, 64, 64)])
+def test_flash_attention_compact_heads_are_bit_identical_to_padded(d, Nq, Nk):
+    """Round 5: q / k / V^T / o with the REAL head dims back to back (onedc_flash_attn with DQ = DV = d: the ring kernels make the
+    padding on their DMA path -- zero page, constant-1 chunk, ones row) against the same values in the padded layout: the MFMAs
+    see the same operands, so every output bit is equal.  Ragged key tails, strided q / k (column slices of one [q | k] buffer)."""
+    from onedc_amd import pack
+    B, Hh = 2, 8
+    DQ, DV = pack.HEAD_PAD[d]
+    pos = pack.head_positions(d, DQ).to(DEV)
+    posv = pack.head_positions(d, DV).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(91)
+    Nk_pad = (Nk + 63) // 64 * 64
+    qk_c = (torch.randn(B * max(Nq, Nk), 2 * Hh * d, generator=g, device=DEV)).to(K.a16())        # rows [q | k], compact
+    vt_dt = K.flash_vt_dtype(d, d, Nk)
+    assert vt_dt == K.flash_vt_dtype(DQ, DV, Nk)
+    v_c = torch.zeros(B, Hh * d, Nk_pad, dtype=vt_dt, device=DEV)
+    v_c[:, :, :Nk] = torch.randn(B, Hh * d, Nk, generator=g, device=DEV).to(vt_dt)
+    # the same values, padded
+    qk_p = torch.zeros(B * max(Nq, Nk), 2 * Hh * DQ, dtype=K.a16(), device=DEV)
+    qk_p.view(-1, 2, Hh, DQ)[:, :, :, pos] = qk_c.view(-1, 2, Hh, d)
+    v_p = torch.zeros(B, Hh, DV, Nk_pad, dtype=vt_dt, device=DEV)
+    v_p[:, :, posv] = v_c.view(B, Hh, d, Nk_pad)
+    o_c = torch.full((B * Nq * Hh * d,), 7.0, dtype=K.a16(), device=DEV)
+    o_p = torch.empty(B * Nq * Hh * DV, dtype=K.a16(), device=DEV)
+    # q / k as column slices of the [q | k] rows: q rows are the first Nq (per image B * N rows are laid out image-major)
+    def rows(t, N, w):      # image-major [B][N][w] out of [B * max][w]
+        return t.view(B, max(Nq, Nk), -1)[:, :N].contiguous().view(-1)
+    qc, kc = rows(qk_c[:, :Hh * d], Nq, Hh * d), rows(qk_c[:, Hh * d:], Nk, Hh * d)
+    qp, kp = rows(qk_p[:, :Hh * DQ], Nq, Hh * DQ), rows(qk_p[:, Hh * DQ:], Nk, Hh * DQ)
+    K.flash_attn(qc, kc, v_c.view(-1), o_c, B, Hh, Nq, Nk, Nk_pad, d, d, d ** -0.5)
+    K.flash_attn(qp, kp, v_p.view(-1), o_p, B, Hh, Nq, Nk, Nk_pad, DQ, DV, d ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(o_c.view(B * Nq, Hh, d), o_p.view(B * Nq, Hh, DV)[:, :, posv])
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        qc.float().view(B, Nq, Hh, d).transpose(1, 2), kc.float().view(B, Nk, Hh, d).transpose(1, 2),
+        v_c[:, :, :Nk].float().view(B, Hh, d, Nk).transpose(2, 3))
+    close(o_c.float().view(B, Nq, Hh, d).transpose(1, 2).cpu(), ref.cpu(), rms=8e-3, mx=6e-2, what=f"compact flash attention d={d}")
+    # the layout is only read by the ring kernels: fewer than 64 keys are refused (the layers keep the padded packing for them)
+    with pytest.raises(K.KernelError):
+        K.flash_attn(qc, kc, v_c.view(-1), o_c, B, Hh, Nq, 48, 64, d, d, d ** -0.5)
+
+
+@pytest.mark.parametrize("C,self_attn,hw", [(320, True, (16, 20)), (640, True, (12, 12)), (320, False, (16, 16)), (640, False, (8, 10))])
+def test_attention_layer_with_compact_heads_equals_the_padded_layer(C, self_attn, hw):
+    """layers.MultiHeadAttention built with and without COMPACT_HEADS on the same weights: the same output bits (projection GEMMs
+    with fewer columns compute the same dot products in the same k order; the attention kernel sees the same operands)."""
+    from onedc_amd import layers as L
+    g = torch.Generator().manual_seed(93)
+    ctx_dim = C if self_attn else 768
+    sd = {f"a.{n}.weight": torch.randn(C, ctx_dim if n in ("to_k", "to_v") else C, generator=g) * 0.05 for n in ("to_q", "to_k", "to_v", "to_out.0")}
+    sd["a.to_out.0.bias"] = torch.randn(C, generator=g) * 0.1
+    x = from_nchw(torch.randn(2, C, *hw, generator=g).to(DEV))
+    ctx = x if self_attn else from_nchw(torch.randn(2, 768, 9, 9, generator=g).to(DEV))       # 81 context tokens
+    res = from_nchw(torch.randn(2, C, *hw, generator=g).to(DEV))
+    outs = []
+    for flag in (True, False):
+        before, L.COMPACT_HEADS = L.COMPACT_HEADS, flag
+        try:
+            layer = L.MultiHeadAttention(sd, "a", DEV, C, ctx_dim, self_attention=self_attn)
+        finally:
+            L.COMPACT_HEADS = before
+        assert layer.compact == flag
+        y = layer(x, ctx, res, ws=L.Workspace(DEV))
+        outs.append(y.t[:2 * hw[0] * hw[1] * C].clone())
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_mxfp8_roundtrip_kernel_matches_the_ocp_definition():

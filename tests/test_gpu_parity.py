@@ -692,3 +692,28 @@ def test_softmax_rows_long_rows_match_torch():
     t = tol(2e-3, 1e-2)                                        # output rounding: 11 / 8 significant bits
     assert float((got[:, :n].double() - ref).abs().max()) <= t * float(ref.max())
     assert float((got[:, :n].double().sum(-1) - 1).abs().max()) <= t
+
+
+def test_compact_attention_heads_do_not_change_a_decoded_bit():
+    """Round 5: the UNet's d = 40 / 80 attention layers keep q / k / V^T / o compact (no padded head columns in HBM) wherever their
+    kernel sees 64 keys and more.  A 512x512 picture (64 context tokens; self-attention over 4 096 / 1 024 tokens) decoded by a model
+    built with the switch off and by one built with it on: the same picture, bit for bit -- and both paths were actually taken."""
+    from onedc_amd import layers as L
+    idx = torch.from_numpy(np.random.default_rng(31).integers(0, 16384, (1, 8, 8)).astype(np.int32)).to(DEV)
+    pics = []
+    for flag in (False, True):
+        before, L.COMPACT_HEADS = L.COMPACT_HEADS, flag
+        try:
+            m = SD15_1step_codec_stage1({"vae_attn_patch": 16}).load_synthetic(0, preset="trained_like")
+        finally:
+            L.COMPACT_HEADS = before
+        m.codec_model.update(force=True)
+        t = m.feedforward_model._transformers
+        assert all(x.attn1.compact == flag and x.attn2.compact == flag for x in t if x.attn1.d in (40, 80))
+        assert (m.feedforward_model.ctx_kv.compact is not None) == flag
+        if not pics:
+            blobs, _ = m.codec_model.encode_latents(idx, None, noise_seed=32)
+        pics.append(m.decode(stream=blobs))
+        del m
+        torch.cuda.empty_cache()
+    assert torch.equal(pics[0], pics[1])
