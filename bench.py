@@ -32,7 +32,12 @@ THAT the headline region).
 Extra objects in the line:
   roofline      for the dominant kernel (the implicit-GEMM kernel family with the most device time, as reported by the
                 C dispatcher itself): achieved = algorithmic FLOPs of its launches / their summed duration, measured
-                live with HIP events on the launch stream during the timed region; peak = dense 16-bit MFMA.
+                live with HIP events on the launch stream -- since round 5 over the untimed sequential decode right after
+                the timed region (the kernel with the GPU to itself); the same launches inside the pipelined timed region
+                ride beside it as achieved_in_pipeline / frac_in_pipeline; peak = dense 16-bit MFMA.  traffic and
+                mfma_util_pmc are committed PMC records, named by traffic_from / mfma_util_from.
+  side lines    (default decode run on one GPU) random_init, z_only, batch32, bf16, vae_up3_bf16, encode_decode: the other
+                BASELINE configs and switches, each {value, ms_per_step, steps, how}, after the timed region.
   cpu_baseline  the fp32 oracle (oracle/torch_ref.py, "port") timed on the host cores of this box on a bounded
                 sample, scaled to the metric's unit by algorithmic FLOPs.
 """
