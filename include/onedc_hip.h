@@ -119,6 +119,13 @@ typedef struct onedc_conv_params {
     const void *w2;                     /* packed [rows padded to 128][Cin2] weights of that 1x1 layer, divided by alpha by
                                            the host where alpha != 1 (a power of two there) */
     int32_t Cin2, x2_cs, x2_co;         /* Cin2: multiple of 32 */
+    /* ---- round 5 (appended: a caller that zero-fills the struct keeps the 0.4 behaviour) ---- */
+    int32_t x_bf16;                     /* 1 (IEEE-half build; ignored by the bf16 build): the 3x3 taps multiply bf16 OPERANDS -- x is a
+                                           normalised tensor stored as bf16 (onedc_scale_shift_act_fmt with out_bf16) or, with gn_ab,
+                                           is normalised to bf16 on load; w is packed bf16 -- while y, res, stats, x2 and w2 keep the
+                                           build's format.  The chip holds a higher clock on 8-bit mantissas; an intermediate that only
+                                           this conv reads costs no stored precision.  Only the 4-wave window kernel does it: any other
+                                           layer is refused with -17 (ask onedc_conv_gemm_kernel_id first) */
 } onedc_conv_params;
 /* bytes of scratch (onedc_conv_params.ws) the split-K form of this layer needs; 0: the dispatcher does not split it */
 int64_t onedc_conv_splitk_ws_bytes(const onedc_conv_params *p);
@@ -194,6 +201,9 @@ int onedc_gn_stats(const void *x, const float *gamma, const float *beta, float *
                    int HW, int C, int x_cs, int x_co, float eps, void *stream);
 int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
                           int y_cs, int y_co, int silu, void *stream);
+/* the same; out_bf16 = 1 stores y as bf16 whatever the library's format (the consumer is a conv with onedc_conv_params.x_bf16) */
+int onedc_scale_shift_act_fmt(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
+                              int y_cs, int y_co, int silu, int out_bf16, void *stream);
 /* the statistics step from partial sums left by the producing conv's epilogue (onedc_conv_params.stats):
  * stats [B*HW/64][cs/gran] float2 for the whole buffer (cs channels per pixel), normalised channels
  * [co, co + C); C/32 and co multiples of gran (4 or 2).  Writes ab like onedc_gn_stats. */

@@ -595,7 +595,14 @@ static bool conv_lin_ok(const onedc_conv_params &p) {
            (int64_t)((p.Cout + 127) / 128 * 128) * p.Cin * 2 < 0xfff00000ll && M < 0x7fffffff;
 }
 
+static int conv_choose_any(const onedc_conv_params &p);
+// x_bf16 (bf16 operands under f16 storage, gemm_conv_win4.hip) exists in the 4-wave window kernel only: refused elsewhere
 static int conv_choose(const onedc_conv_params &p) {
+    const int id = conv_choose_any(p);
+    return (p.x_bf16 && id >= 0 && id != ONEDC_KERNEL_WIN3X3_4W) ? -17 : id;
+}
+
+static int conv_choose_any(const onedc_conv_params &p) {
     const bool glu = p.epi == ONEDC_EPI_GLU_LEAKY || p.epi == ONEDC_EPI_GEGLU;
     {
         // a layer whose SHAPE says split-K runs split or not at all: falling back to the unsplit kernel when the caller's

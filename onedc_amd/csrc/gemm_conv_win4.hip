@@ -64,7 +64,12 @@ __device__ __forceinline__ void w4_static_for(F &&f) {
 // K-tile.  The separate shortcut launch, its output tensor and the residual read of it disappear (the VAE's 256 -> 128 block
 // at 768x768: 1.7 ms + 2.4 GB written + 2.4 GB re-read per batch of 16).  A template parameter so that the kernels without a
 // second source are compiled exactly as before.
-template <int MODE, int ST, bool X2 = false>
+// BF (round 5, IEEE-half build only): the 3x3 part multiplies bf16 OPERANDS -- x is a normalised tensor stored as bf16 by the
+// scale/shift pass (MODE 0) or is normalised to bf16 on load (MODE 1), w is packed bf16 -- while everything that is STORED (output,
+// residual, statistics, a second source and its weights) keeps the build's format.  The chip holds a 3 - 6 % higher clock on 8-bit
+// mantissas, and tests/devtools/bf16_operands_sim.py: with f16 storage, bf16 operands in every resnet conv of the VAE and the UNet
+// move the picture by 0.0003 dB of the 0.01 dB budget (the all-bf16 library fails it through its stored streams).
+template <int MODE, int ST, bool X2 = false, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_params p, int tiles_n, int tiles_x, int tiles_y,
                                                            int Ktot, OnedcFastDiv dv_n, OnedcFastDiv dv_pi,
                                                            OnedcFastDiv dv_x, OnedcFastDiv dv_c) {
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
                 v2 = silu_f(v2);
                 v3 = silu_f(v3);
             }
-            o[2 * h] = live ? pack_a2(v0, v1) : 0u;
-            o[2 * h + 1] = live ? pack_a2(v2, v3) : 0u;
+            o[2 * h] = live ? (BF ? pack_bf16_2(v0, v1) : pack_a2(v0, v1)) : 0u;
+            o[2 * h + 1] = live ? (BF ? pack_bf16_2(v2, v3) : pack_a2(v2, v3)) : 0u;
         }
         asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(o) : "memory");
     };
@@ -325,20 +330,32 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     // K-tile (dst != src C), which took 56 more registers and pushed the DMA offsets into scratch.  What the compiler no
     // longer sees: the accumulators are matrix-core results (wait states in front of the epilogue's first VALU read).
 #ifdef ONEDC_ACT_F16
-#define W4_MFMA(c, a, b)                                                                                      \
+#define W4_MFMA_N(c, a, b)                                                                                    \
     do {                                                                                                      \
         f32x4 &c__ = (c);                                                                                     \
         const a16x8 &a__ = (a), &b__ = (b);                                                                   \
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c__) : "v"(a__), "v"(b__));               \
     } while (0)
 #else
-#define W4_MFMA(c, a, b)                                                                                      \
+#define W4_MFMA_N(c, a, b)                                                                                    \
     do {                                                                                                      \
         f32x4 &c__ = (c);                                                                                     \
         const a16x8 &a__ = (a), &b__ = (b);                                                                   \
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c__) : "v"(a__), "v"(b__));              \
     } while (0)
 #endif
+    // the 3x3 part: bf16 operands where the kernel is instantiated for them (BF), the build's format otherwise; the second
+    // source (a stored tensor) always multiplies in the build's format (W4_MFMA_N)
+#define W4_MFMA(c, a, b)                                                                                      \
+    do {                                                                                                      \
+        if constexpr (BF) {                                                                                   \
+            f32x4 &c__ = (c);                                                                                 \
+            const a16x8 &a__ = (a), &b__ = (b);                                                               \
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c__) : "v"(a__), "v"(b__));          \
+        } else {                                                                                              \
+            W4_MFMA_N(c, a, b);                                                                               \
+        }                                                                                                     \
+    } while (0)
 #define W4_WAIT_LGKM4(n, q)                                                                                   \
     do {                                                                                                      \
         a16x8 &q0__ = (q)[0], &q1__ = (q)[1], &q2__ = (q)[2], &q3__ = (q)[3];                                 \
@@ -545,11 +562,11 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) W4_MFMA(acc[i][r], fa[0][i], fbA[r]);
+                for (int r = 0; r < 4; ++r) W4_MFMA_N(acc[i][r], fa[0][i], fbA[r]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) W4_MFMA(acc[i][4 + r], fa[0][i], fbB[r]);
+                for (int r = 0; r < 4; ++r) W4_MFMA_N(acc[i][4 + r], fa[0][i], fbB[r]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -683,6 +700,7 @@ bool onedc_conv_win4_ok(const onedc_conv_params &p) {
                  (int64_t)((p.Cout + 127) / 128 * 128) * p.Cin2 * 2 > 0x7fffffffll ||
                  (int64_t)p.OH * p.OW * p.x2_cs * 2 >= 0xfffff000ll))
         return false;
+    if (p.x_bf16 && (p.up || p.in_f32)) return false;
     return !p.up && conv_epi_fast_ok(p, false) && p.epi == ONEDC_EPI_LINEAR && (p.Cout & 63) == 0 &&
            ((p.y_cs | p.y_co) & 7) == 0 && (!p.res || ((p.r_cs | p.r_co) & 3) == 0) &&
            (!p.gn_ab || W4_LDS + (int64_t)p.Cin * 8 <= 80 * 1024);
@@ -703,9 +721,23 @@ static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
 #else
     const dim3 grid((unsigned)blocks), block(256);
 #endif
+#define W4_LAUNCH_BF(ST_, X2_, BF_)                                                                                  \
+    hipLaunchKernelGGL((conv_win4_kernel<MODE, ST_, X2_, BF_>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, \
+                       dv_pi, dv_x, dv_c)
+#ifdef ONEDC_ACT_F16
 #define W4_LAUNCH(ST_, X2_)                                                                                          \
-    hipLaunchKernelGGL((conv_win4_kernel<MODE, ST_, X2_>), grid, block, lds, st, p, tiles_n, tiles_x, tiles_y, Ktot, dv_n, dv_pi, \
-                       dv_x, dv_c)
+    do {                                                                                                             \
+        if constexpr (!UPS) {                                                                                        \
+            if (p.x_bf16) {                                                                                          \
+                W4_LAUNCH_BF(ST_, X2_, true);                                                                        \
+                break;                                                                                               \
+            }                                                                                                        \
+        }                                                                                                            \
+        W4_LAUNCH_BF(ST_, X2_, false);                                                                               \
+    } while (0)
+#else                                                     // (the bf16 build multiplies bf16 anyway)
+#define W4_LAUNCH(ST_, X2_) W4_LAUNCH_BF(ST_, X2_, false)
+#endif
     if constexpr (!UPS) {
         if (p.x2) {
             if (!p.stats) W4_LAUNCH(0, true);
@@ -719,6 +751,7 @@ static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
     else if (p.stats_gran == 2) W4_LAUNCH(2, false);
     else W4_LAUNCH(4, false);
 #undef W4_LAUNCH
+#undef W4_LAUNCH_BF
     ONEDC_LAUNCH_CHECK();
     return 0;
 }
@@ -737,6 +770,20 @@ static void win4_attrs() {
                  {(const void *)conv_win4_kernel<1, 0, true>, 80 * 1024},
                  {(const void *)conv_win4_kernel<1, 2, true>, 80 * 1024},
                  {(const void *)conv_win4_kernel<1, 4, true>, 80 * 1024},
+#ifdef ONEDC_ACT_F16
+                 {(const void *)conv_win4_kernel<0, 0, false, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 2, false, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 4, false, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<1, 0, false, true>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 2, false, true>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 4, false, true>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<0, 0, true, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 2, true, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<0, 4, true, true>, W4_LDS},
+                 {(const void *)conv_win4_kernel<1, 0, true, true>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 2, true, true>, 80 * 1024},
+                 {(const void *)conv_win4_kernel<1, 4, true, true>, 80 * 1024},
+#endif
                  {(const void *)conv_win4_kernel<2, 0>, W4_LDS},
                  {(const void *)conv_win4_kernel<2, 2>, W4_LDS},
                  {(const void *)conv_win4_kernel<2, 4>, W4_LDS}});

@@ -22,6 +22,9 @@ __device__ __forceinline__ void unpack8(const uint4 &v, float *f) {
 __device__ __forceinline__ uint4 pack8(const float *f) {
     return make_uint4(pack_a2(f[0], f[1]), pack_a2(f[2], f[3]), pack_a2(f[4], f[5]), pack_a2(f[6], f[7]));
 }
+__device__ __forceinline__ uint4 pack8_bf16(const float *f) {      // bf16 whatever the build's format
+    return make_uint4(pack_bf16_2(f[0], f[1]), pack_bf16_2(f[2], f[3]), pack_bf16_2(f[4], f[5]), pack_bf16_2(f[6], f[7]));
+}
 
 // stage 1: block (chunk, b) sums x and x^2 per group over gn_ppc(HW) pixels.
 // threads = CC * PL with CC = C/8 channel chunks and PL pixel lanes.
@@ -191,6 +194,9 @@ __global__ void gn_from_stats_kernel(const float2 *__restrict__ stats, const flo
 // ppc: pixels per block, 256 on the big maps; round 5: fewer on maps that would give less than two blocks per CU -- 24x24 and
 // 12x12 maps of a batch of 16 were 48 / 16 blocks of serial 256-pixel walks: 56 us for 47 MB (0.8 TB/s), 28 us for 12 MB
 constexpr int SSA_PPC = 256;
+// OBF: y is stored as bf16 whatever the build's format (round 5: the consumer is a conv that multiplies bf16 operands,
+// onedc_conv_params.x_bf16; the values before the rounding are the same)
+template <bool OBF>
 __global__ void scale_shift_act_kernel(const a16_t *__restrict__ x, const float2 *__restrict__ ab,
                                        a16_t *__restrict__ y, int HW, int C, int CC, int PL, int x_cs, int x_co,
                                        int y_cs, int y_co, int silu, int ppc) {
@@ -228,7 +234,7 @@ __global__ void scale_shift_act_kernel(const a16_t *__restrict__ x, const float2
                     f[e] = __builtin_fmaf(f[e], a[e], bb[e]);
                     if (SILU) f[e] = silu_f(f[e]);
                 }
-                *(uint4 *)(yp + (int64_t)(p + u * PL) * y_cs) = pack8(f);
+                *(uint4 *)(yp + (int64_t)(p + u * PL) * y_cs) = OBF ? pack8_bf16(f) : pack8(f);
             }
         }
         for (; p < p1; p += PL) {
@@ -239,7 +245,7 @@ __global__ void scale_shift_act_kernel(const a16_t *__restrict__ x, const float2
                 f[e] = __builtin_fmaf(f[e], a[e], bb[e]);
                 if (SILU) f[e] = silu_f(f[e]);
             }
-            *(uint4 *)(yp + (int64_t)p * y_cs) = pack8(f);
+            *(uint4 *)(yp + (int64_t)p * y_cs) = OBF ? pack8_bf16(f) : pack8(f);
         }
     };
     if (silu) run(std::true_type());
@@ -394,8 +400,8 @@ int onedc_gn_from_stats(const float *stats, const float *gamma, const float *bet
     return 0;
 }
 
-int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
-                          int y_cs, int y_co, int silu, void *stream) {
+int onedc_scale_shift_act_fmt(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
+                              int y_cs, int y_co, int silu, int out_bf16, void *stream) {
     if (!x || !ab || !y) return -1;
     if ((C & 7) || (x_cs & 7) || (x_co & 7) || (y_cs & 7) || (y_co & 7)) return -2;
     const int CC = C / 8;
@@ -406,11 +412,21 @@ int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW
 #ifndef EXP_R5_BASELINE
     while (ppc > 8 && ppc > PL && (int64_t)((HW + ppc - 1) / ppc) * B < 512) ppc >>= 1;
 #endif
-    hipLaunchKernelGGL(scale_shift_act_kernel, dim3((HW + ppc - 1) / ppc, B), dim3(threads), 0,
-                       as_stream(stream), (const a16_t *)x, (const float2 *)ab, (a16_t *)y, HW, C, CC, PL, x_cs,
-                       x_co, y_cs, y_co, silu, ppc);
+    if (out_bf16)
+        hipLaunchKernelGGL(scale_shift_act_kernel<true>, dim3((HW + ppc - 1) / ppc, B), dim3(threads), 0,
+                           as_stream(stream), (const a16_t *)x, (const float2 *)ab, (a16_t *)y, HW, C, CC, PL, x_cs,
+                           x_co, y_cs, y_co, silu, ppc);
+    else
+        hipLaunchKernelGGL(scale_shift_act_kernel<false>, dim3((HW + ppc - 1) / ppc, B), dim3(threads), 0,
+                           as_stream(stream), (const a16_t *)x, (const float2 *)ab, (a16_t *)y, HW, C, CC, PL, x_cs,
+                           x_co, y_cs, y_co, silu, ppc);
     ONEDC_LAUNCH_CHECK();
     return 0;
+}
+
+int onedc_scale_shift_act(const void *x, const float *ab, void *y, int B, int HW, int C, int x_cs, int x_co,
+                          int y_cs, int y_co, int silu, void *stream) {
+    return onedc_scale_shift_act_fmt(x, ab, y, B, HW, C, x_cs, x_co, y_cs, y_co, silu, 0, stream);
 }
 
 int onedc_layernorm(const void *x, const float *gamma, const float *beta, void *y, int64_t rows, int C,

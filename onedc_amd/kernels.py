@@ -78,6 +78,7 @@ class ConvParams(C.Structure):
         ("gn_ab", _P), ("gn_silu", C.c_int32), ("out_bf16", C.c_int32),
         ("ws", _P), ("ws_bytes", _L), ("split_k", C.c_int32),
         ("x2", _P), ("w2", _P), ("Cin2", C.c_int32), ("x2_cs", C.c_int32), ("x2_co", C.c_int32),
+        ("x_bf16", C.c_int32),
     ]
 
 
@@ -105,6 +106,7 @@ SIGNATURES = {
     "onedc_gn_chunks": (_I, [_I]),
     "onedc_gn_stats": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_scale_shift_act": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "onedc_scale_shift_act_fmt": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "onedc_gn_from_stats": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "onedc_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "onedc_softmax_rows": (_I, [_P, _P, _L, _I, _I, _P]),
@@ -334,14 +336,18 @@ def conv_kernel_name(p):
 
 def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01, alpha=1.0, res=None,
               pixel_shuffle=0, Cin=None, Cout=None, batch=1, x_bs=0, w_bs=0, y_bs=0, r_bs=0, flop_scale=1.0,
-              tile=0, stats=False, pad=None, gn=None, out_bf16=False, x2=None, w2=None):
+              tile=0, stats=False, pad=None, gn=None, out_bf16=False, x2=None, w2=None, w_bf16=None):
     """x, y, res: View; w: packed bf16 weight tensor; bias: f32 tensor or None.
     x2, w2: a second source on the output grid and its packed 1x1 weights (pre-divided by alpha), accumulated behind the 3x3
     taps: y = alpha * (conv(x) + conv1x1(x2)) + bias + res.  Only the 4-wave window kernel does it; when the dispatcher
     would not, NOTHING is launched and None is returned (the caller runs the two layers separately).
     gn = (gamma, beta, eps, silu, ws): the conv reads GroupNorm(x) (+SiLU).  On the 3x3 window kernel the
     normalisation is applied while the operand is staged (x is read raw, the normalised tensor never exists);
-    any other kernel gets it from the separate scale/shift pass, with identical values."""
+    any other kernel gets it from the separate scale/shift pass, with identical values.
+    w_bf16 (with gn, IEEE-half format only): the same packed weights in bf16 -- the layer then multiplies bf16 OPERANDS (the
+    normalised tensor is an intermediate only this conv reads: it is normalised to bf16 on load, or stored as bf16 by the pass)
+    while y, res and the statistics stay f16 (onedc_conv_params.x_bf16; BF16_OPERANDS).  Only where the 4-wave window kernel
+    takes the layer; silently the f16 operands otherwise."""
     p = ConvParams()
     p.x, p.w, p.bias, p.res, p.y = x.ptr, w.data_ptr(), _ptr(bias), (res.ptr if res is not None else None), y.ptr
     p.zeros = zeros_page(x.t.device).data_ptr()
@@ -378,13 +384,19 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
             return None
     if gn is not None:
         gamma, beta, eps, silu, ws = gn
+        bf = False
+        if BF16_OPERANDS and w_bf16 is not None and act() == "f16" and not x.f32:
+            p.x_bf16, p.w = 1, w_bf16.data_ptr()
+            bf = lib().onedc_conv_gemm_kernel_id(C.byref(p)) == KERNEL_WIN3X3_4W      # (the only kernel that multiplies them)
+            if not bf:
+                p.x_bf16, p.w = 0, w.data_ptr()
         # every 128-channel output tile normalises the window again: only worth it while there is one tile
         if USE_GN_FUSION and x.C == p.Cin and p.Cout <= GN_FUSION_MAX_COUT and lib().onedc_conv_win_takes(C.byref(p)):
             p.gn_ab = group_norm_ab(x, gamma, beta, eps, ws).data_ptr()
             p.gn_silu = int(silu)
         else:
-            xn = new_view(x.B, x.H, x.W, x.C, x.t.device)
-            group_norm(x, gamma, beta, xn, eps, silu, ws)
+            xn = new_view(x.B, x.H, x.W, x.C, x.t.device, torch.bfloat16 if bf else None)
+            group_norm(x, gamma, beta, xn, eps, silu, ws, out_bf16=bf)
             p.x, p.x_cs, p.x_co = xn.ptr, xn.cs, xn.co
     if KH == 3 and p.OH * p.OW <= 256 and SPLIT_K != 1:        # (pre-filter only: the C dispatcher decides)
         need = lib().onedc_conv_splitk_ws_bytes(C.byref(p))
@@ -448,6 +460,10 @@ def gn_chunks(HW):
 USE_EPILOGUE_STATS = True    # False: always run the separate statistics pass (tests, A/B)
 
 
+# bf16 OPERANDS under f16 storage (round 5): convs that read a GroupNorm output take it -- an intermediate -- and their weights in
+# bf16 where the 4-wave window kernel runs them; ONEDC_BF16_OPERANDS=0: f16 operands everywhere (A/B, tests)
+BF16_OPERANDS = __import__("os").environ.get("ONEDC_BF16_OPERANDS", "1") != "0"
+KERNEL_WIN3X3_4W = 10              # ONEDC_KERNEL_WIN3X3_4W of include/onedc_hip.h
 GN_FUSION_MAX_COUT = int(__import__("os").environ.get("ONEDC_GN_FUSION_MAX_COUT", "128"))
 USE_GN_FUSION = True         # False: GroupNorm in front of a conv always runs as its own scale/shift pass (tests, A/B)
 
@@ -469,11 +485,12 @@ def group_norm_ab(x, gamma, beta, eps, ws):
     return ab
 
 
-def group_norm(x, gamma, beta, y, eps, silu, ws):
-    """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors."""
+def group_norm(x, gamma, beta, y, eps, silu, ws, out_bf16=False):
+    """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors.
+    out_bf16: y is stored as bf16 whatever the current format (its reader is a conv with bf16 operands, conv_gemm)."""
     ab = group_norm_ab(x, gamma, beta, eps, ws)
-    _ok(lib().onedc_scale_shift_act(x.ptr, ab.data_ptr(), y.ptr, x.B, x.H * x.W, x.C, x.cs, x.co, y.cs, y.co,
-                                    int(silu), stream()), "onedc_scale_shift_act")
+    _ok(lib().onedc_scale_shift_act_fmt(x.ptr, ab.data_ptr(), y.ptr, x.B, x.H * x.W, x.C, x.cs, x.co, y.cs, y.co,
+                                        int(silu), int(bool(out_bf16)), stream()), "onedc_scale_shift_act")
     return y
 
 

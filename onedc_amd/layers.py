@@ -103,6 +103,17 @@ class Conv:
             self.w_ups = pack.pack_matrix(pack.upsample_phase_matrix(w), device)
         self.mxfp8 = False
         self._mx_src = (m, perm, device) if (not f32 and not glu and not shuffle and self.cin % 32 == 0) else None
+        # the same weights in bf16 for layers that may multiply bf16 operands (kernels.conv_gemm: w_bf16; asked for by the block
+        # that owns the conv -- ResnetBlock2D -- through want_bf16_operands())
+        self.w_bf = None
+        self._bf_src = (m, perm, device) if (not f32 and not glu and not shuffle and self.k == 3) else None
+
+    def want_bf16_operands(self):
+        if self._bf_src is not None and self.w_bf is None and K.act() == "f16" and K.BF16_OPERANDS:
+            m, perm, device = self._bf_src
+            self.w_bf = pack.pack_matrix(m, device, perm, torch.bfloat16)
+        self._bf_src = None
+        return self
 
     def set_mxfp8(self, on=True):
         """MXFP8 experiment: the layer computes on operands quantised to e4m3 with one power-of-two scale per
@@ -162,7 +173,8 @@ class Conv:
             gn = (gn[0].g, gn[0].b, gn[0].eps, gn[2], gn[1])
         return K.conv_gemm(x, self.w, self.b if bias is None else bias, y, KH=self.k, stride=stride, up=up, epi=epi,
                            slope=slope, alpha=alpha, res=res, pixel_shuffle=int(self.shuffle), Cin=self.cin,
-                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad, gn=gn, x2=x2, w2=w2)
+                           Cout=self.cout, flop_scale=self.flop_scale, stats=stats, pad=pad, gn=gn, x2=x2, w2=w2,
+                           w_bf16=self.w_bf if gn is not None else None)
 
 
 _Conv = Conv
@@ -299,9 +311,9 @@ class ResnetBlock2D:
         self.stream_scale = s = float(stream_scale)
         cin = sd[f"{p}.norm1.weight"].shape[0]
         self.n1 = GroupNorm(sd, f"{p}.norm1", device, eps * s * s)
-        self.c1 = Conv(sd, f"{p}.conv1", device)
+        self.c1 = Conv(sd, f"{p}.conv1", device).want_bf16_operands()      # both convs read a GroupNorm output: an intermediate
         self.n2 = GroupNorm(sd, f"{p}.norm2", device, eps)
-        self.c2 = Conv(sd, f"{p}.conv2", device)
+        self.c2 = Conv(sd, f"{p}.conv2", device).want_bf16_operands()
         self.short = Conv(sd, f"{p}.conv_shortcut", device) if f"{p}.conv_shortcut.weight" in sd else None
         if s != 1.0:
             self.c2.b = (self.c2.b * s).contiguous()

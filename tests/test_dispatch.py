@@ -100,6 +100,21 @@ def test_split_k_is_a_function_of_the_layer_shape():
     assert lib.onedc_conv_splitk_ws_bytes(C.byref(params(k=1, H=12, W=12, Cin=5120, Cout=1280, B=16))) == 0  # 1x1
 
 
+def test_bf16_operands_exist_in_the_4wave_window_kernel_only():
+    """onedc_conv_params.x_bf16 (round 5: bf16 operands under f16 storage): the 4-wave window kernel multiplies them, with or
+    without GroupNorm on load and a second source; every other kernel refuses the layer (-17) and the caller keeps f16 operands."""
+    p = params(gn=True)
+    p.x_bf16 = 1
+    assert name(p) == "win3x3_4w"
+    p = params(Cin=256, Cout=256, res=True, stats=4)
+    p.x_bf16 = 1
+    assert name(p) == "win3x3_4w"
+    for q in (params(H=24, W=24, Cin=1280, Cout=1280, B=16), params(k=1, H=96, W=96, Cin=320, Cout=320, B=16), params(epi=K.EPI_SILU),
+              params(up=1)):
+        q.x_bf16, q.split_k = 1, 1
+        assert name(q) == -17, name(q)
+
+
 def test_second_source_question():
     """conv_shortcut as a second source: taken where the layer runs on the 4-wave window kernel, refused elsewhere (the caller
     then launches the shortcut itself)."""

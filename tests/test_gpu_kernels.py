@@ -1087,6 +1087,51 @@ def test_conv_win3x3_groupnorm_on_load(B, H, W, Cin, Cout, silu):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,x2c", [(2, 32, 16, 128, 128, 0), (1, 16, 48, 256, 256, 0), (1, 32, 32, 128, 128, 256), (2, 16, 16, 320, 320, 0)])
+def test_conv_win3x3_bf16_operands_under_f16_storage(B, H, W, Cin, Cout, x2c):
+    """Round 5: conv(silu(GroupNorm(x))) multiplying bf16 OPERANDS (onedc_conv_params.x_bf16: the normalised tensor -- an
+    intermediate only this conv reads -- and the weights in bf16) while y, the residual, the statistics and a second source stay
+    f16.  Against F.conv2d on operands rounded the same way; the fused form (normalised to bf16 on load) and the unfused one (the
+    scale/shift pass stores bf16) give the same bits; with the switch off the launch is the f16 one."""
+    if K.act() != "f16":
+        pytest.skip("operand format of the IEEE-half build")
+    x, w, b = rnd(B, Cin, H, W, seed=211), rnd(Cout, Cin, 3, 3, seed=212, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=213)
+    g, be, r = 1 + 0.2 * rnd(Cin, seed=214), 0.5 * rnd(Cin, seed=215), rnd(B, Cout, H, W, seed=216)
+    xv, rv = from_nchw(x.to(DEV)), from_nchw(r.to(DEV))
+    wp, wbf = packed(w), pack.pack_matrix(pack.conv_matrix(w), DEV, None, torch.bfloat16)
+    x2 = w2 = x2v = w2p = None
+    if x2c:
+        x2, w2 = rnd(B, x2c, H, W, seed=217), rnd(Cout, x2c, 1, 1, seed=218, scale=x2c ** -0.5)
+        x2v, w2p = from_nchw(x2.to(DEV)), packed(w2)
+    outs = {}
+    for name, fuse, bf in (("fused", True, True), ("pass", False, True), ("f16", True, False)):
+        K.USE_GN_FUSION, before = fuse, K.BF16_OPERANDS
+        K.BF16_OPERANDS = bf
+        try:
+            y = new_view(B, H, W, Cout, DEV, stats=True)
+            ws = _WS()
+            assert K.conv_gemm(xv, wp, b.to(DEV), y, KH=3, res=None if x2c else rv, stats=True, gn=(g.to(DEV), be.to(DEV), 1e-6, True, ws),
+                               x2=x2v, w2=w2p, w_bf16=wbf) is not None
+        finally:
+            K.USE_GN_FUSION, K.BF16_OPERANDS = True, before
+        outs[name] = (y.t[:B * H * W * Cout].clone(), y.stats.t.clone(), y)
+    if Cout <= K.GN_FUSION_MAX_COUT:                  # (wider layers take the pass either way)
+        assert torch.equal(outs["fused"][0], outs["pass"][0]) and torch.equal(outs["fused"][1], outs["pass"][1])
+    assert not torch.equal(outs["fused"][0], outs["f16"][0])          # the switch changes the operands
+    xn = F.silu(F.group_norm(x.to(torch.float16).float(), 32, g, be, 1e-6))
+    ref16 = F.conv2d(xn.to(torch.float16).double(), w.to(torch.float16).double(), b.double(), padding=1)
+    refbf = F.conv2d(xn.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), b.double(), padding=1)
+    tail = F.conv2d(x2.to(torch.float16).double(), w2.to(torch.float16).double()) if x2c else r.to(torch.float16).double()
+    # each form against ITS reference far more closely than the two references differ
+    e_bf = float((outs["fused"][2].torch_nchw().double().cpu() - (refbf + tail)).pow(2).mean().sqrt())
+    e_16 = float((outs["f16"][2].torch_nchw().double().cpu() - (ref16 + tail)).pow(2).mean().sqrt())
+    gap = float((refbf - ref16).pow(2).mean().sqrt())
+    scale = float((ref16 + tail).pow(2).mean().sqrt())
+    print(f"[bf16 operands] rms error vs own reference: bf16 {e_bf / scale:.2e}, f16 {e_16 / scale:.2e}; the references differ by {gap / scale:.2e}")
+    assert e_bf <= 0.5 * gap and e_16 <= 0.5 * gap and gap / scale < 5e-3
+    close(outs["fused"][2].torch_nchw(), refbf + tail, rms=1.5e-3, mx=1e-2, what="bf16 operands")
+
+
 def test_conv_win3x3_groupnorm_on_load_race_screen():
     """The fused path mixes register loads, LDS writes and LDS-DMA under hand-counted waits: same bits 40 times,
     on a shape with several chunk transitions and many workgroups."""
