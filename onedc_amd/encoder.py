@@ -62,10 +62,10 @@ class VAEEncoder:
                             exact=bool(wci.abs().max() >= 6.0e4), flop_scale=3 / 32)
         self.down = []
         for i in range(4):
-            blk = {"res": [ResnetBlock2D(sd, f"encoder.down_blocks.{i}.resnets.{j}", device, 1e-6) for j in range(2)]}
+            blk = {"res": [ResnetBlock2D(sd, f"encoder.down_blocks.{i}.resnets.{j}", device, 1e-6, bf16_operands=False) for j in range(2)]}
             blk["down"] = Conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", device) if i < 3 else None
             self.down.append(blk)
-        self.mid_res = [ResnetBlock2D(sd, f"encoder.mid_block.resnets.{j}", device, 1e-6) for j in range(2)]
+        self.mid_res = [ResnetBlock2D(sd, f"encoder.mid_block.resnets.{j}", device, 1e-6, bf16_operands=False) for j in range(2)]
         self.attn_norm = GroupNorm(sd, f"{a}.group_norm", device, 1e-6)
         self.attn = SingleHeadAttention(sd, (f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{a}.to_out.0"), device, 512)
         self.norm_out = GroupNorm(sd, "encoder.conv_norm_out", device, 1e-6)
@@ -174,17 +174,17 @@ class AnalysisUNet:
         self.conv_in_down = Conv(sd, f"{p}.conv_in.3", device)
         self.down = []
         for i, c in enumerate(ch):
-            blk = {"res": [ResnetBlock2D(sd, f"{p}.down_blocks.{i}.resnets.{j}", device, 1e-5) for j in range(2)]}
+            blk = {"res": [ResnetBlock2D(sd, f"{p}.down_blocks.{i}.resnets.{j}", device, 1e-5, bf16_operands=False) for j in range(2)]}
             blk["attn"] = [GroupNormAttention(sd, f"{p}.down_blocks.{i}.attentions.{j}", device, c)
                            for j in range(2)] if i < 2 else None
             blk["down"] = Conv(sd, f"{p}.down_blocks.{i}.downsamplers.0.conv", device) if i < 2 else None
             self.down.append(blk)
-        self.mid_res = [ResnetBlock2D(sd, f"{p}.mid_block.resnets.{j}", device, 1e-5) for j in range(2)]
+        self.mid_res = [ResnetBlock2D(sd, f"{p}.mid_block.resnets.{j}", device, 1e-5, bf16_operands=False) for j in range(2)]
         self.mid_attn = GroupNormAttention(sd, f"{p}.mid_block.attentions.0", device, ch[-1])
         self.up = []
         plan = arch.enc_unet_up_plan()
         for i in range(3):
-            blk = {"res": [ResnetBlock2D(sd, f"{p}.up_blocks.{i}.resnets.{j}", device, 1e-5) for j in range(3)],
+            blk = {"res": [ResnetBlock2D(sd, f"{p}.up_blocks.{i}.resnets.{j}", device, 1e-5, bf16_operands=False) for j in range(3)],
                    "io": [plan[(i, j)] for j in range(3)]}
             blk["attn"] = [GroupNormAttention(sd, f"{p}.up_blocks.{i}.attentions.{j}", device, plan[(i, j)][1])
                            for j in range(3)] if i < 2 else None

@@ -303,17 +303,24 @@ class ResnetBlock2D:
     """diffusers ResnetBlock2D; `temb` (B-independent, timestep is a constant of the codec) is
     folded into conv1's bias by `set_temb`."""
 
-    def __init__(self, sd, p, device, eps, stream_scale=1.0):
-        """stream_scale s (a power of two): the residual stream this block reads and writes is stored times s.
+    def __init__(self, sd, p, device, eps, stream_scale=1.0, bf16_operands=True):
+        """bf16_operands: conv1 / conv2 may multiply bf16 operands where the 4-wave window kernel runs them (kernels.BF16_OPERANDS:
+        their inputs are GroupNorm outputs, intermediates nobody else reads; everything stored stays f16).  The decode path's
+        blocks do (+2.3 % images/s for 0.0003 dB); the ENCODE side's blocks do not: they write the streams, and their arithmetic
+        stays what the parity figures of rounds 2-4 were measured on.
+        stream_scale s (a power of two): the residual stream this block reads and writes is stored times s.
         GroupNorm is scale invariant up to eps (norm1 gets eps * s^2), the branch output and the biases of the linear
         maps of the stream are multiplied by s in the epilogue (alpha) / at load."""
         self.p, self.device = p, device
         self.stream_scale = s = float(stream_scale)
         cin = sd[f"{p}.norm1.weight"].shape[0]
         self.n1 = GroupNorm(sd, f"{p}.norm1", device, eps * s * s)
-        self.c1 = Conv(sd, f"{p}.conv1", device).want_bf16_operands()      # both convs read a GroupNorm output: an intermediate
+        self.c1 = Conv(sd, f"{p}.conv1", device)
         self.n2 = GroupNorm(sd, f"{p}.norm2", device, eps)
-        self.c2 = Conv(sd, f"{p}.conv2", device).want_bf16_operands()
+        self.c2 = Conv(sd, f"{p}.conv2", device)
+        if bf16_operands:                                                   # both convs read a GroupNorm output: an intermediate
+            self.c1.want_bf16_operands()
+            self.c2.want_bf16_operands()
         self.short = Conv(sd, f"{p}.conv_shortcut", device) if f"{p}.conv_shortcut.weight" in sd else None
         if s != 1.0:
             self.c2.b = (self.c2.b * s).contiguous()

@@ -30,6 +30,15 @@ def _round_bf16_(t):
 
 def patched(self, x, y=None, **kw):
     gn = kw.get("gn")
+    if id(self) in ACTIVE and gn is None and not x.f32:       # a conv on a STORED tensor (upsamplers): its operand copy rounded
+        xr = K.View(x.t.clone(), x.B, x.H, x.W, x.C, x.cs, x.co, x.stats)
+        _round_bf16_(xr.t)
+        saved = (self.w, self.w_ups)
+        self.w, self.w_ups = _rounded(self.w), (_rounded(self.w_ups) if self.w_ups is not None else None)
+        try:
+            return _orig_call(self, xr, y, **kw)
+        finally:
+            self.w, self.w_ups = saved
     if id(self) not in ACTIVE or gn is None:
         return _orig_call(self, x, y, **kw)
     xn = gn[0](x, gn[1], gn[2])                    # the separate scale/shift pass (same values as GroupNorm on load)
@@ -47,6 +56,17 @@ def patched(self, x, y=None, **kw):
         return _orig_call(self, xn, y, **kw)
     finally:
         self.w = self._w_f16
+
+
+_cache = {}
+
+
+def _rounded(w):
+    if id(w) not in _cache:
+        c = w.clone()
+        _round_bf16_(c)
+        _cache[id(w)] = (w, c)
+    return _cache[id(w)][1]
 
 
 def delta_psnr(img, ref, level_db, seed):
@@ -80,6 +100,8 @@ def main():
             "all VAE resnets": resnet_convs(vae.mid_res + [r for b in vae.up for r in b["res"]]),
             "all VAE + UNet resnets": resnet_convs(vae.mid_res + [r for b in vae.up for r in b["res"]] + list(unet._all_resnets())),
         }
+        ups = [b["up"] for b in vae.up if b["up"] is not None] + [b["up"] for b in unet.up if b["up"] is not None]
+        sets["... + the upsampler convs (stored inputs)"] = sets["all VAE + UNet resnets"] + ups
         for name, convs in sets.items():
             ACTIVE.clear()
             ACTIVE.update(id(c) for c in convs)

@@ -347,7 +347,9 @@ def test_vae_decoder_windowed(h, w):
     img = vae.decode(lv)
     with torch.no_grad():
         ref = R.vae_decode(sd, lat, 16)
-    check(img.torch_nchw(), ref, tol(4e-3, 3e-2), f"VAE decoder {h}x{w}")
+    # (f16 build: 1.7e-3 ... 3e-3 with f16 operands; since round 5 the decoder's resnet convs multiply bf16 OPERANDS under f16 storage:
+    # 5.2e-3 at the random-init point of this small test -- the budget that counts, |dPSNR| <= 0.01 dB at full size, moved by 0.0003 dB)
+    check(img.torch_nchw(), ref, tol(8e-3, 3e-2), f"VAE decoder {h}x{w}")
 
 
 def test_end_to_end_decode_psnr(full_model, gaussian_tables):
