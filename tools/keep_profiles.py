@@ -5,13 +5,15 @@ The rocprofv3 kernel-stats CSVs get a comment header that says which command the
 batch is made of (sums by kernel family, computed here from the CSV itself)."""
 import csv
 import json
+import re
 import os
 import shutil
 import sys
 
 FAMILIES = (
     ("window kernel", lambda s: "conv_win4_kernel" in s),
-    ("  of it with conv_shortcut as a second source", lambda s: "conv_win4_kernel" in s and "true>" in s),
+    ("  of it with conv_shortcut as a second source", lambda s: re.search(r"conv_win4_kernel<\d, \d, true", s) is not None),
+    ("  of it multiplying bf16 operands (f16 storage)", lambda s: re.search(r"conv_win4_kernel<\d, \d, (?:true|false), true>", s) is not None),
     ("  of it GroupNorm on load", lambda s: "conv_win4_kernel<1" in s),
     ("  of it upsample phases", lambda s: "conv_win4_kernel<2" in s),
     ("8-wave window kernel", lambda s: "conv_win_kernel" in s),

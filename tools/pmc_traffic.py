@@ -20,7 +20,7 @@ def short(name):
         return f"conv_lin_kernel<{m.group(2)}x{m.group(3)}, {m.group(4)} stages>"
     # conv_win4_kernel<MODE, ST, X2>: MODE 2 = the upsample phases, their own row (4/9 of the taps, x4 outputs); MODE 0 / 1 with
     # or without a second source are the family bench.py's roofline object is about
-    m = re.search(r"conv_win4_kernel<(\d), \d(?:, (?:true|false))?>", name)
+    m = re.search(r"conv_win4_kernel<(\d), \d(?:, (?:true|false)){0,2}>", name)      # <MODE, ST[, X2[, BF]]>
     if m:
         return "conv_win4_kernel" + ("<ups>" if m.group(1) == "2" else "")
     m = re.search(r"(conv_win_kernel)<(true|false)(?:, (?:true|false))?>", name)
