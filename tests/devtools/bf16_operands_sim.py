@@ -78,8 +78,22 @@ def resnet_convs(blocks):
     return [c for r in blocks for c in (r.c1, r.c2)]
 
 
+ATTN_QK = [False]
+_orig_flash = K.flash_attn
+
+
+def flash_patched(q, k, vt, o, *a, **kw):
+    """q / k are projection outputs only the attention reads: rounded copies simulate a bf16 S product."""
+    if ATTN_QK[0] and q.dtype == torch.float16:
+        q, k = q.clone(), k.clone()
+        _round_bf16_(q)
+        _round_bf16_(k)
+    return _orig_flash(q, k, vt, o, *a, **kw)
+
+
 def main():
     dev = "cuda:0"
+    K.flash_attn = flash_patched
     torch.set_num_threads(16)
     L.Conv.__call__ = patched
     for preset in ("trained_like", "random_init"):
@@ -102,13 +116,19 @@ def main():
         }
         ups = [b["up"] for b in vae.up if b["up"] is not None] + [b["up"] for b in unet.up if b["up"] is not None]
         sets["... + the upsampler convs (stored inputs)"] = sets["all VAE + UNet resnets"] + ups
+        cm = m.codec_model
+        syn = resnet_convs([cm.semantic_adaptor.r1, cm.semantic_adaptor.r4] + list(cm.dec.res_a) + list(cm.dec.res_b))
+        sets["resnets + the codec synthesis' VQ resnets"] = sets["all VAE + UNet resnets"] + syn
+        sets["resnets + attention q / k (bf16 S product)"] = sets["all VAE + UNet resnets"]
         for name, convs in sets.items():
             ACTIVE.clear()
             ACTIVE.update(id(c) for c in convs)
+            ATTN_QK[0] = "attention q / k" in name
             img = m.decode(stream=blobs, unit_range=True).cpu()
             print(f"[{preset}] bf16 operands in {name:26s} PSNR(product, oracle) {R.psnr(img, ref):6.2f} dB   |dPSNR| at 25 / 27 dB "
                   f"{delta_psnr(img, ref, 25.0, 1000):.4f} / {delta_psnr(img, ref, 27.0, 1000):.4f} dB", flush=True)
         ACTIVE.clear()
+        ATTN_QK[0] = False
         del m
         torch.cuda.empty_cache()
 
