@@ -820,7 +820,10 @@ def main():
                        "weights": "rank 0 builds, one flat RCCL broadcast" if args.broadcast_weights else
                                   "every rank builds the deterministic synthetic weights itself",
                        "setup_s": round(t_setup, 1),
-                       "arithmetic": f"{model.act} storage and MFMA operands (synthesis, UNet, VAE), " +
+                       "arithmetic": (f"{model.act} storage; MFMA operands {model.act}, and bf16 in the resnet convs of the UNet and the VAE on "
+                                      f"the window kernel (their input is a GroupNorm output: an intermediate; kernels.BF16_OPERANDS), "
+                                      if (model.act == "f16" and K.BF16_OPERANDS) else
+                                      f"{model.act} storage and MFMA operands (synthesis, UNet, VAE), ") +
                                      ("16-bit MFMA prior networks (--prior-16bit), exact f32 MFMA (VAE conv_in)" if args.prior_16bit else
                                       "exact f32 MFMA (prior networks, VAE conv_in)" if args.prior_arith in ("mfma", "auto") and args.prior_exact else
                                       "f32 activations and accumulation with split-half operands (22 bits, exact products) on the 16-bit "
