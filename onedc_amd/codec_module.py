@@ -447,9 +447,21 @@ class IntraNoAR:
             self._pinned_bufs[key] = bufs
         return bufs
 
+    def _prior_guard(self):
+        """Everything that evaluates the prior networks holds this while it does: "auto" decoding swaps self.ref_prior and the
+        whole prior stack (hyper_dec, y_prior_fusion, y_spatial_prior*) to another arithmetic while it retries a desynchronised
+        stream, and an encode (or a z-only reconstruction) on another thread must neither pick up the swapped networks -- it
+        would write a stream in the wrong arithmetic -- nor be overtaken by the swap half way.  Re-entrant."""
+        import contextlib
+        return self._auto_lock if self.prior_arith == "auto" else contextlib.nullcontext()
+
+    def recon_with_z(self, indices):
+        with self._prior_guard():
+            return self._recon_with_z(indices)
+
     @K.in_own_format
     @torch.no_grad()
-    def recon_with_z(self, indices):
+    def _recon_with_z(self, indices):
         """z-only model: forward_four_part_prior_recon_with_z (compression_model.py:421-465)."""
         fused, z_semantic = self._params_from_indices(indices)
         common_cat, y_hat = self._prior_setup(fused)
@@ -591,9 +603,13 @@ class IntraNoAR:
         return blobs, indices, y_hat
 
     # ------------------------------------------------------------------ encode side of the prior
+    def encode_latents(self, indices, y=None, noise_seed=0, heights=None, widths=None):
+        with self._prior_guard():
+            return self._encode_latents(indices, y, noise_seed, heights, widths)
+
     @K.in_own_format
     @torch.no_grad()
-    def encode_latents(self, indices, y=None, noise_seed=0, heights=None, widths=None):
+    def _encode_latents(self, indices, y=None, noise_seed=0, heights=None, widths=None):
         """compress_four_part_prior + entropy encode (codec_module.py:372-415 minus the analysis
         transform): indices int32 (B,h,w); y f32 NHWC (B,4h,4w,N) device tensor, or None to draw a
         synthetic latent step by step as means + clamp(scales, .11, 8) * N(0,1).

@@ -599,7 +599,11 @@ static int conv_choose_any(const onedc_conv_params &p);
 // x_bf16 (bf16 operands under f16 storage, gemm_conv_win4.hip) exists in the 4-wave window kernel only: refused elsewhere
 static int conv_choose(const onedc_conv_params &p) {
     const int id = conv_choose_any(p);
+#ifdef ONEDC_ACT_F16
     return (p.x_bf16 && id >= 0 && id != ONEDC_KERNEL_WIN3X3_4W) ? -17 : id;
+#else
+    return id;      // the bf16 build multiplies bf16 operands in every kernel: the flag asks for what it does anyway (header: "ignored")
+#endif
 }
 
 static int conv_choose_any(const onedc_conv_params &p) {

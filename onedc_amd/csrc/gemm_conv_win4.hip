@@ -85,6 +85,16 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
 #define W4_TL(i)
 #define W4_RT(i)
 #endif
+    // slots 10 .. 13 carry the prologue's detail stamps -- or, with -DEXP_W4_EPI_TL (round 6), the epilogue's: 10 staging rows
+    // free (barrier passed), 12 residual rows 0 .. 3 landed (a forced wait: diagnostic only), 11 arithmetic + LDS transpose done,
+    // 3 stores issued, 13 stores drained (tools/timeline_win4.py --epilogue)
+#if defined(EXP_W4_TIMELINE) && defined(EXP_W4_EPI_TL)
+#define W4_PTL(i)
+#define W4_ETL(i) W4_TL(i)
+#else
+#define W4_PTL(i) W4_TL(i)
+#define W4_ETL(i)
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,10 +182,10 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         glds16_buf(w_rsrc, wvoff, so, dst);
         glds16_buf(w_rsrc, wvoff, so + wrow64, dst + 4096);
     };
-    W4_TL(10);                                       // (diagnostic) tile decoded, weight offsets ready
+    W4_PTL(10);                                      // (diagnostic) tile decoded, weight offsets ready
     stage_A(0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    W4_TL(11);                                       // (diagnostic) first weight tile issued
+    W4_PTL(11);                                      // (diagnostic) first weight tile issued
 
     const int64_t img_bytes = (int64_t)p.IH * p.IW * p.x_cs * 2;
     const unsigned x_bytes = img_bytes < 0xfffff000ll ? (unsigned)img_bytes : 0xfffff000u;
@@ -195,14 +205,14 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         sbits |= (unsigned)((wx >> 2) & 1) << k;
         woff[k] = ok ? (unsigned)((iy * p.IW + ix) * p.x_cs + p.x_co) * 2u + sfq * 16 : x_bytes;
     }
-    W4_TL(12);                                       // (diagnostic) window offsets computed
+    W4_PTL(12);                                      // (diagnostic) window offsets computed
     auto stage_W = [&](int k, int c32, int wbuf) {
         glds16_buf(x_rsrc, woff[k], (unsigned)c32 * 64, smem + W4_WOFF + wbuf * W4_W + (wave + 4 * k) * 1024);
     };
 #pragma unroll
     for (int k = 0; k < MAXWB; ++k)
         if (k < nwb) stage_W(k, 0, 0);
-    W4_TL(13);                                       // (diagnostic) first window issued
+    W4_PTL(13);                                      // (diagnostic) first window issued
     stage_A(1, 0, 1);
     stage_A(2, 0, 2);
     stage_A(3, 0, 3);
@@ -227,6 +237,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         (void)abaddr;
         return;
 #endif
+#ifdef EXP_NORM_TILE0_ONLY                           // (ablation, round 6: results of the other channel tiles are garbage) only the FIRST
+        if (n0 != 0) return;                         // channel tile of a window normalises it: the ceiling of a 256-channel tile that
+#endif                                               // normalises once per window and shares the result
         asm volatile("ds_read_b128 %0, %1" : "=v"(raw) : "v"(addr));
 #ifdef EXP_NORM_NOAB                                 // (ablation) (a, b) from registers instead of 4 LDS reads per block
         ab[0] = ab[1] = f32x4{1.f, 0.25f, 1.f, 0.25f};
@@ -602,6 +615,11 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     // every wave is done with the windows and the ring: a wave's 64 x 128 outputs go through 16 KB of them
     W4_WAIT_LGKMCNT(0);
     __builtin_amdgcn_s_barrier();
+    W4_ETL(10);
+#if defined(EXP_W4_TIMELINE) && defined(EXP_W4_EPI_TL)
+    W4_WAIT_VMCNT(0);                                // (diagnostic) residual rows 0 .. 3 are in
+    W4_ETL(12);
+#endif
     typedef __attribute__((address_space(3))) char lds_char;
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -615,23 +633,48 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_lo[b][i] = q_lo[b][i] = s_hi[b][i] = q_hi[b][i] = f32x2_t{0.f, 0.f};
+    // (round 6 experiments, tools/exp_build.sh: -DEXP_W4_EPI_SCALAR does the pair arithmetic as two scalar instructions -- the
+    // PARTNER workgroup's MFMAs share this SIMD's issue port, where packed f32 costs more than the scalar pair,
+    // MI355X_MICROARCH.md "packed f32 VALU"; -DEXP_W4_EPI_OVERLAP issues the two line stores of patch row r - 1 behind the
+    // arithmetic of row r instead of all sixteen behind row 7.  Same values, same order of every sum either way.)
+#ifdef EXP_W4_EPI_SCALAR
+#define W4_FMA2(x, y, z) f32x2_t{__builtin_fmaf((x)[0], (y)[0], (z)[0]), __builtin_fmaf((x)[1], (y)[1], (z)[1])}
+#define W4_ADD2(x, y) f32x2_t{(x)[0] + (y)[0], (x)[1] + (y)[1]}
+#else
+#define W4_FMA2(x, y, z) __builtin_elementwise_fma((x), (y), (z))
+#define W4_ADD2(x, y) ((x) + (y))
+#endif
     if (have) {
         const f32x2_t alpha2 = {p.alpha, p.alpha};
+        const int c = lane & 7;
+        // the two 128-byte line groups (8 pixels x 64 channels each) of patch row r of this wave: back from the wave's own
+        // staging rows -- written and read by this wave only, so no barrier in between -- and out as whole lines
+        auto store_lines = [&](int r) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int px = (2 * r + h) * 8 + (lane >> 3);  // pixel (row 8 wc + (px >> 4), column px & 15) of the patch
+                const u32x4_t o = *(const __attribute__((address_space(3))) u32x4_t *)(my + px * 128 + ((c ^ (px & 7)) << 4));
+                const int py = y0 + 8 * wc + (px >> 4), pxx = x0 + (px & 15);
+                const int64_t pix = UPS ? ((int64_t)img * p.OH + 2 * py + PY) * p.OW + 2 * pxx + PX
+                                        : ((int64_t)img * p.OH + py) * p.OW + pxx;
+                *(u32x4_t *)((a16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
+            }
+        };
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int px = r * 16 + frow;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 a = acc[i][r];
-                f32x2_t lo = __builtin_elementwise_fma(f32x2_t{a[0], a[1]}, alpha2, f32x2_t{bias[i].x, bias[i].y});
-                f32x2_t hi = __builtin_elementwise_fma(f32x2_t{a[2], a[3]}, alpha2, f32x2_t{bias[i].z, bias[i].w});
-                lo += f32x2_t{a2f_lo(res[r][i].x), a2f_hi(res[r][i].x)};
-                hi += f32x2_t{a2f_lo(res[r][i].y), a2f_hi(res[r][i].y)};
+                f32x2_t lo = W4_FMA2((f32x2_t{a[0], a[1]}), alpha2, (f32x2_t{bias[i].x, bias[i].y}));
+                f32x2_t hi = W4_FMA2((f32x2_t{a[2], a[3]}), alpha2, (f32x2_t{bias[i].z, bias[i].w}));
+                lo = W4_ADD2(lo, (f32x2_t{a2f_lo(res[r][i].x), a2f_hi(res[r][i].x)}));
+                hi = W4_ADD2(hi, (f32x2_t{a2f_lo(res[r][i].y), a2f_hi(res[r][i].y)}));
                 if (ST != 0) {
-                    s_lo[r >> 2][i] += lo;
-                    s_hi[r >> 2][i] += hi;
-                    q_lo[r >> 2][i] = __builtin_elementwise_fma(lo, lo, q_lo[r >> 2][i]);
-                    q_hi[r >> 2][i] = __builtin_elementwise_fma(hi, hi, q_hi[r >> 2][i]);
+                    s_lo[r >> 2][i] = W4_ADD2(s_lo[r >> 2][i], lo);
+                    s_hi[r >> 2][i] = W4_ADD2(s_hi[r >> 2][i], hi);
+                    q_lo[r >> 2][i] = W4_FMA2(lo, lo, q_lo[r >> 2][i]);
+                    q_hi[r >> 2][i] = W4_FMA2(hi, hi, q_hi[r >> 2][i]);
                 }
                 const int s8 = i * 4 + fq;
                 // (upsample phases only: onedc_conv_params.out_bf16 stores bf16 whatever the build's format -- round 5: the VAE's
@@ -645,19 +688,27 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
                 load_res_row(r + 3);
                 load_res_row(r + 4);
             }
+#ifdef EXP_W4_EPI_OVERLAP
+            if (r >= 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                store_lines(r - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
-        const int c = lane & 7;
+        W4_ETL(11);
+#ifdef EXP_W4_EPI_OVERLAP
+        store_lines(7);
+#else
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int px = it * 8 + (lane >> 3);           // pixel (row 8 wc + (px >> 4), column px & 15) of the patch
-            const u32x4_t o = *(const __attribute__((address_space(3))) u32x4_t *)(my + px * 128 + ((c ^ (px & 7)) << 4));
-            const int py = y0 + 8 * wc + (px >> 4), pxx = x0 + (px & 15);
-            const int64_t pix = UPS ? ((int64_t)img * p.OH + 2 * py + PY) * p.OW + 2 * pxx + PX
-                                    : ((int64_t)img * p.OH + py) * p.OW + pxx;
-            *(u32x4_t *)((a16_t *)yb + pix * p.y_cs + p.y_co + nw + c * 8) = o;
-        }
+        for (int r = 0; r < 8; ++r) store_lines(r);
+#endif
 #ifdef EXP_W4_TIMELINE
         W4_TL(3);
+#ifdef EXP_W4_EPI_TL
+        W4_WAIT_VMCNT(0);
+        W4_ETL(13);
+#endif
         if (lane == 0) {     // diagnostic build: p.stats is a debug buffer [blocks][4 waves][8] of int64
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
@@ -709,6 +760,9 @@ bool onedc_conv_win4_ok(const onedc_conv_params &p) {
 template <int MODE>
 static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
     constexpr bool UPS = MODE == 2;
+#ifdef EXP_W4_ALONE     // (diagnostic, round 6) ONE workgroup per CU: what a K-tile costs a workgroup that has the matrix pipe to itself
+    lds = 100 * 1024;
+#endif
     const int tiles_n = UPS ? 4 * p.Cout / 128 : (p.Cout + 127) / 128;
     const int tiles_x = (UPS ? p.IW : p.OW) / 16, tiles_y = (UPS ? p.IH : p.OH) / 16;
     const int Ktot = (UPS ? 4 : 9) * p.Cin;
@@ -758,35 +812,40 @@ static int win4_launch(const onedc_conv_params &p, hipStream_t st, int lds) {
 
 static void win4_attrs() {
     static OnedcLdsAttrOnce once;
-    once.ensure({{(const void *)conv_win4_kernel<0, 0>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 2>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 4>, W4_LDS},
-                 {(const void *)conv_win4_kernel<1, 0>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 2>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 4>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<0, 0, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 2, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 4, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<1, 0, true>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 2, true>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 4, true>, 80 * 1024},
-#ifdef ONEDC_ACT_F16
-                 {(const void *)conv_win4_kernel<0, 0, false, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 2, false, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 4, false, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<1, 0, false, true>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 2, false, true>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 4, false, true>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<0, 0, true, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 2, true, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<0, 4, true, true>, W4_LDS},
-                 {(const void *)conv_win4_kernel<1, 0, true, true>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 2, true, true>, 80 * 1024},
-                 {(const void *)conv_win4_kernel<1, 4, true, true>, 80 * 1024},
+#ifdef EXP_W4_ALONE
+#define W4_LDS_ATTR(n) (100 * 1024)
+#else
+#define W4_LDS_ATTR(n) (n)
 #endif
-                 {(const void *)conv_win4_kernel<2, 0>, W4_LDS},
-                 {(const void *)conv_win4_kernel<2, 2>, W4_LDS},
-                 {(const void *)conv_win4_kernel<2, 4>, W4_LDS}});
+    once.ensure({{(const void *)conv_win4_kernel<0, 0>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 2>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 4>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<1, 0>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 2>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 4>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<0, 0, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 2, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 4, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<1, 0, true>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 2, true>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 4, true>, W4_LDS_ATTR(80 * 1024)},
+#ifdef ONEDC_ACT_F16
+                 {(const void *)conv_win4_kernel<0, 0, false, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 2, false, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 4, false, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<1, 0, false, true>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 2, false, true>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 4, false, true>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<0, 0, true, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 2, true, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<0, 4, true, true>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<1, 0, true, true>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 2, true, true>, W4_LDS_ATTR(80 * 1024)},
+                 {(const void *)conv_win4_kernel<1, 4, true, true>, W4_LDS_ATTR(80 * 1024)},
+#endif
+                 {(const void *)conv_win4_kernel<2, 0>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<2, 2>, W4_LDS_ATTR(W4_LDS)},
+                 {(const void *)conv_win4_kernel<2, 4>, W4_LDS_ATTR(W4_LDS)}});
 }
 
 int onedc_conv_win4_launch(const onedc_conv_params &p, hipStream_t st) {

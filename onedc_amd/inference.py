@@ -77,15 +77,27 @@ def rank_world():
 def run_token():
     """What the ranks of ONE launch attempt share and another launch (or a restarted attempt of this one) does not.
     torchrun / accelerate give every rank of every node the same MASTER_ADDR:MASTER_PORT and TORCHELASTIC_RUN_ID, and count
-    restarts in TORCHELASTIC_RESTART_COUNT (a restarted attempt must not accept the failed attempt's marker / done files); the
-    parent's pid -- equal only among the ranks of one node -- is the fallback for launchers that set none of them."""
+    restarts in TORCHELASTIC_RESTART_COUNT (a restarted attempt must not accept the failed attempt's marker / done files).
+    That alone is NOT unique per launch: plain `torchrun --nproc_per_node=N` and `accelerate launch` export the same
+    `127.0.0.1:29500-none-restart0` every time, so a re-run after a failed or killed run would read the dead run's marker and
+    .failed<r> files as its own.  On one node (LOCAL_WORLD_SIZE == WORLD_SIZE) the launcher's pid -- the ranks' common parent --
+    is appended; a launch over several nodes has no such common process and must carry a real run id (`torchrun --rdzv-id`,
+    or ONEDC_RUN_ID: the same on every node, new for every launch).  No launcher variables at all: the parent's pid."""
     env = os.environ
     if env.get("ONEDC_RUN_ID"):
         return env["ONEDC_RUN_ID"]
+    rid = env.get("TORCHELASTIC_RUN_ID", "")
     if env.get("MASTER_ADDR") and env.get("MASTER_PORT"):
-        return (f"{env['MASTER_ADDR']}:{env['MASTER_PORT']}-{env.get('TORCHELASTIC_RUN_ID', '')}"
-                f"-restart{env.get('TORCHELASTIC_RESTART_COUNT', '0')}")
-    return f"{env.get('TORCHELASTIC_RUN_ID', '')}-ppid{os.getppid()}"
+        token = f"{env['MASTER_ADDR']}:{env['MASTER_PORT']}-{rid}-restart{env.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+        world = max(1, int(env.get("WORLD_SIZE", "1") or 1))
+        local_world = int(env.get("LOCAL_WORLD_SIZE", "0") or 0) or world
+        if local_world >= world:
+            return f"{token}-ppid{os.getppid()}"
+        if rid in ("", "none"):
+            raise RuntimeError("a launch over several nodes needs a run id that is new for every launch: torchrun --rdzv-id <id>, "
+                               "or ONEDC_RUN_ID=<id> on every node (MASTER_ADDR:MASTER_PORT repeat from launch to launch)")
+        return token
+    return f"{rid}-ppid{os.getppid()}"
 
 
 class RankFailed(RuntimeError):

@@ -384,19 +384,25 @@ def conv_gemm(x, w, bias, y, *, KH=1, stride=1, up=0, epi=EPI_LINEAR, slope=0.01
             return None
     if gn is not None:
         gamma, beta, eps, silu, ws = gn
+        # every 128-channel output tile normalises the window again: only worth it while there is one tile
+        fused = bool(USE_GN_FUSION and x.C == p.Cin and p.Cout <= GN_FUSION_MAX_COUT and lib().onedc_conv_win_takes(C.byref(p)))
+        ab = group_norm_ab(x, gamma, beta, eps, ws)
+        if fused:
+            p.gn_ab, p.gn_silu = ab.data_ptr(), int(silu)
+        else:                                     # the normalised tensor is a dense buffer of x.C channels
+            p.x_cs, p.x_co = x.C, 0
+        # bf16 operands: asked of the dispatcher with the launch's FINAL parameters (gn_ab set or the pass's geometry: with gn_ab
+        # the 4-wave window kernel has one more condition -- room for the (a, b) pairs, Cin <= 768 -- and a layer it then leaves to
+        # the 8-wave kernel must keep f16 operands instead of being refused with -17)
         bf = False
         if BF16_OPERANDS and w_bf16 is not None and act() == "f16" and not x.f32:
             p.x_bf16, p.w = 1, w_bf16.data_ptr()
             bf = lib().onedc_conv_gemm_kernel_id(C.byref(p)) == KERNEL_WIN3X3_4W      # (the only kernel that multiplies them)
             if not bf:
                 p.x_bf16, p.w = 0, w.data_ptr()
-        # every 128-channel output tile normalises the window again: only worth it while there is one tile
-        if USE_GN_FUSION and x.C == p.Cin and p.Cout <= GN_FUSION_MAX_COUT and lib().onedc_conv_win_takes(C.byref(p)):
-            p.gn_ab = group_norm_ab(x, gamma, beta, eps, ws).data_ptr()
-            p.gn_silu = int(silu)
-        else:
+        if not fused:
             xn = new_view(x.B, x.H, x.W, x.C, x.t.device, torch.bfloat16 if bf else None)
-            group_norm(x, gamma, beta, xn, eps, silu, ws, out_bf16=bf)
+            group_norm(x, gamma, beta, xn, eps, silu, ws, out_bf16=bf, ab=ab)
             p.x, p.x_cs, p.x_co = xn.ptr, xn.cs, xn.co
     if KH == 3 and p.OH * p.OW <= 256 and SPLIT_K != 1:        # (pre-filter only: the C dispatcher decides)
         need = lib().onedc_conv_splitk_ws_bytes(C.byref(p))
@@ -485,10 +491,12 @@ def group_norm_ab(x, gamma, beta, eps, ws):
     return ab
 
 
-def group_norm(x, gamma, beta, y, eps, silu, ws, out_bf16=False):
+def group_norm(x, gamma, beta, y, eps, silu, ws, out_bf16=False, ab=None):
     """ws: Workspace providing .gn_partial (f32) and .gn_ab (f32) scratch tensors.
-    out_bf16: y is stored as bf16 whatever the current format (its reader is a conv with bf16 operands, conv_gemm)."""
-    ab = group_norm_ab(x, gamma, beta, eps, ws)
+    out_bf16: y is stored as bf16 whatever the current format (its reader is a conv with bf16 operands, conv_gemm).
+    ab: the (a, b) pairs when the caller has run group_norm_ab already."""
+    if ab is None:
+        ab = group_norm_ab(x, gamma, beta, eps, ws)
     _ok(lib().onedc_scale_shift_act_fmt(x.ptr, ab.data_ptr(), y.ptr, x.B, x.H * x.W, x.C, x.cs, x.co, y.cs, y.co,
                                         int(silu), int(bool(out_bf16)), stream()), "onedc_scale_shift_act")
     return y

@@ -234,6 +234,7 @@ class SD15_1step_codec_stage1:
             dt = torch.float16 if self.feedforward_model.act == "f16" else torch.bfloat16
             h_detail_hat, ctx = (View(v.t.to(dt), v.B, v.H, v.W, v.C, v.cs, v.co) for v in (h_detail_hat, ctx))
         eps, reduced = self.feedforward_model(h_detail_hat, self.conditioning_timestep, ctx)
+        self._mark("unet")
         x0 = new_view(eps.B, eps.H, eps.W, 4, self.device, torch.float32)
         n = eps.B * eps.H * eps.W * 4
         K.x0_from_noise(reduced.t[:n], eps.t[:n], x0.t[:n], float(self.alphas_cumprod[self.conditioning_timestep].double()))
@@ -280,12 +281,25 @@ class SD15_1step_codec_stage1:
         """Synthesis transform, UNet step, x0, VAE decoder, crop: everything after the rANS hops.
         -> (pictures, non-finite flags int32 [B] on the device)."""
         y_hat, z_semantic, orig_hw, pad_hw, pad_size = entropy_out
+        self._mark("start")
         h_detail_hat, y_semantic = self.codec_model.synthesis(y_hat, z_semantic)
+        self._mark("synthesis")
         image = self.decode_latents(h_detail_hat, y_semantic, vae_gate)["image"]
+        self._mark("vae")
         H, W = orig_hw[0]
         if any(hw != (H, W) for hw in orig_hw):
             H, W = pad_hw                                            # mixed crops: return the padded frame
-        return self._image_out(image, H, W, unit_range, out)
+        res = self._image_out(image, H, W, unit_range, out)
+        self._mark("out")
+        return res
+
+    stage_marks = None       # bench.py / tools: a list here collects (name, HIP event) at the stage boundaries of stage S
+
+    def _mark(self, name):
+        if self.stage_marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.stage_marks.append((name, e))
 
     def _image_out(self, image, H, W, unit_range, out="f32"):
         flags = torch.zeros(image.B, dtype=torch.int32, device=self.device)

@@ -131,6 +131,87 @@ def test_host_core_plan_follows_the_numa_topology():
     assert plan_core_sets(8, list(range(8)), gpu_nodes, node_cpus) is None
 
 
+def _bench(*argv, env=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], cwd=root, env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bare_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment (the shape of the driver's single-GPU command with N = 2): the
+    parent starts two rank processes itself, the ranks meet in a process group (gloo here: --dry-run-ranks is the CPU rehearsal of
+    the protocol, no GPU and no model), run the contract's bracket, reduce MAX, and stdout carries exactly ONE JSON line."""
+    import json
+    r = _bench("--gpus", "2", "--dry-run-ranks", "--steps", "5", "--warmup", "1")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_counted_by_all_reduce"] == 2 and line["launcher"] == "self" and line["dry_run"]
+    assert line["steps"] == 5 and line["scaling"] == "weak"
+    # the stand-in step of rank r takes 2 (r + 1) ms: the job's step time is the SLOWEST rank's (rank 1: >= 4 ms)
+    assert line["ms_per_step"] >= 4.0
+    assert line["value"] == pytest.approx(16 * 2 * 5 / (line["ms_per_step"] * 5e-3), rel=1e-3)
+    assert len(line["repeatability"]["values"]) == 3 and line["value"] == line["repeatability"]["values"][0]
+
+
+def test_bare_bench_launch_fails_when_a_rank_fails():
+    """A rank that dies costs the launch its exit code (the other rank is left waiting in the rendezvous: the parent ends it), and
+    no JSON line is printed."""
+    r = _bench("--gpus", "2", "--dry-run-ranks", "--steps", "2", "--warmup", "1", env={"ONEDC_DRY_RUN_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_dry_run_under_an_external_launcher_environment():
+    """The driver's N > 1 launch line sets RANK / WORLD_SIZE itself: bench.py must then NOT start ranks of its own."""
+    import json
+    port = _free_port()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-ranks", "--steps", "3",
+                                       "--warmup", "1"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    json_lines = [[l for l in o[0].splitlines() if l.startswith("{")] for o in outs]
+    assert len(json_lines[0]) == 1 and len(json_lines[1]) == 0                 # rank 0 prints, rank 1 does not
+    line = json.loads(json_lines[0][0])
+    assert line["n_gpus"] == 2 and line["launcher"] == "external" and line["ranks_counted_by_all_reduce"] == 2
+
+
+@pytest.mark.gpu
+def test_bare_bench_gpus_1_on_the_gpu():
+    """The driver's BENCH command shape (`python bench.py --gpus 1 ...`, no launcher): one process, no process group, one line with
+    the round-6 objects -- the repeatability of the headline, the median-of-passes roofline and its consistency flag, the CPU
+    model.  Runs as a child process before this process has touched the GPU."""
+    import json
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already initialised the GPU: a child launch from here is not allowed on the pool")
+    r = _bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4", "--no-side-lines", "--cpu-sample", "256",
+               env={"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["config"]["launcher"] == "none"
+    rep = line["repeatability"]
+    assert rep["regions"] == 3 and rep["values"][0] == line["value"] and rep["min"] <= line["value_median_of_3"] <= rep["max"]
+    rf = line["roofline"]
+    assert rf["achieved_min"] <= rf["achieved"] <= rf["achieved_max"] and len(rf["achieved_passes"]) == 3
+    assert rf["isolated_inconsistent"] is False, rf["isolated_check"]
+    assert line["cpu_baseline"]["cpu_model"] and line["cpu_baseline"]["cores"] >= 1
+    assert set(line["device"]["stages"]) >= {"codec_synthesis", "unet_step", "vae_decoder"}
+    assert not torch.cuda.is_initialized()
+
+
 @pytest.mark.gpu
 def test_bench_under_torchrun_with_rccl_broadcast_on_one_gpu(tmp_path):
     """The launch line the driver uses for N > 1, with N = 1 (the only size a 1-GPU box allows):
@@ -157,4 +238,5 @@ def test_bench_under_torchrun_with_rccl_broadcast_on_one_gpu(tmp_path):
     assert line["config"]["weights"].startswith("rank 0 builds") and line["config"]["images_per_gpu_per_step"] == 4
     assert line["step_ms"]["n"] >= 1 and line["handoff"]["value"] > 0 and line["device"]["stage_s_ms"] > 0
     assert line["host_rans"]["decode_ns_per_symbol"] > 0
+    assert line["config"]["rccl_ranks"] == 1 and line["config"]["launcher"].startswith("external")
     assert not torch.cuda.is_initialized()

@@ -115,6 +115,23 @@ def test_bf16_operands_exist_in_the_4wave_window_kernel_only():
         assert name(q) == -17, name(q)
 
 
+def test_bf16_operands_are_asked_for_with_the_final_parameters():
+    """with gn_ab the 4-wave window kernel needs room for the image's (a, b) pairs (Cin <= 768); a wider layer
+    normalises on load on the 8-wave kernel, which has no bf16-operand form -- asked with gn_ab SET the dispatcher says so (-17) and
+    kernels.conv_gemm keeps f16 operands; asked before (the round-5 order) it answered for another launch.  The bf16 library
+    multiplies bf16 everywhere and ignores the flag (include/onedc_hip.h)."""
+    wide = params(gn=True, Cin=1024, Cout=128)
+    assert name(wide) == "win3x3"                              # GroupNorm on load, 8 waves
+    wide.x_bf16 = 1
+    assert name(wide) == -17
+    before = params(Cin=1024, Cout=128)                        # the same layer before gn_ab is attached: another answer
+    before.x_bf16 = 1
+    assert name(before) == "win3x3_4w"
+    for q in (wide, params(k=1, H=96, W=96, Cin=320, Cout=320, B=16)):
+        q.x_bf16 = 1
+        assert name(q, "bf16") in ("win3x3", "128x128", "64x128", "lin_128x128")     # never refused for the flag
+
+
 def test_second_source_question():
     """conv_shortcut as a second source: taken where the layer runs on the 4-wave window kernel, refused elsewhere (the caller
     then launches the shortcut itself)."""

@@ -344,12 +344,23 @@ def test_vae_decoder_windowed(h, w):
     vae = VAEDecoder(sd, DEV, attn_patch=16)
     lat = torch.randn(1, 4, h, w, generator=torch.Generator().manual_seed(8)) * 0.18215
     lv = View(lat.permute(0, 2, 3, 1).contiguous().to(DEV).reshape(-1), 1, h, w, 4)
-    img = vae.decode(lv)
     with torch.no_grad():
         ref = R.vae_decode(sd, lat, 16)
-    # (f16 build: 1.7e-3 ... 3e-3 with f16 operands; since round 5 the decoder's resnet convs multiply bf16 OPERANDS under f16 storage:
-    # 5.2e-3 at the random-init point of this small test -- the budget that counts, |dPSNR| <= 0.01 dB at full size, moved by 0.0003 dB)
-    check(img.torch_nchw(), ref, tol(8e-3, 3e-2), f"VAE decoder {h}x{w}")
+    # Two screens: the f16-OPERAND kernels keep their tight bound (f16 build: 1.7e-3 ... 3e-3 measured, bound
+    # 4e-3 as in rounds 2-4); the default since round 5 -- the decoder's resnet convs multiply bf16 OPERANDS under f16 storage -- reads
+    # 5.2e-3 at the random-init point of this small test and gets 8e-3 (the budget that counts, |dPSNR| <= 0.01 dB at full size, moved
+    # by 0.0003 dB: DESIGN.md section 5).  The switch is a run-time one: both weight packings exist in the layers.
+    from onedc_amd import kernels as Kmod
+    keep = Kmod.BF16_OPERANDS
+    try:
+        for on, bound in ((False, 4e-3), (True, 8e-3)):
+            if on and not keep:
+                continue                                    # (ONEDC_BF16_OPERANDS=0 in the environment: no bf16 packing was made)
+            Kmod.BF16_OPERANDS = on
+            img = vae.decode(lv)
+            check(img.torch_nchw(), ref, tol(bound, 3e-2), f"VAE decoder {h}x{w}, {'bf16' if on else 'f16'} operands")
+    finally:
+        Kmod.BF16_OPERANDS = keep
 
 
 def test_end_to_end_decode_psnr(full_model, gaussian_tables):

@@ -103,12 +103,55 @@ def test_run_token_comes_from_the_launchers_rendezvous(monkeypatch):
     monkeypatch.setenv("MASTER_ADDR", "10.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29500")
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job7")
+    monkeypatch.setenv("WORLD_SIZE", "16")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     a = inference.run_token()
     assert "ppid" not in a and "10.0.0.1:29500" in a and "job7" in a           # the same on every node of the launch
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")                           # several nodes and no run id: nothing tells launches apart
+    with pytest.raises(RuntimeError, match="run id"):
+        inference.run_token()
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job7")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")                                # one node: the launcher's pid rides along
+    assert inference.run_token() == a + f"-ppid{os.getppid()}"
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
     assert inference.run_token() != a                                            # a restarted attempt is another run
     monkeypatch.setenv("ONEDC_RUN_ID", "mine")
     assert inference.run_token() == "mine"
+
+
+LAUNCHER = """
+import os, subprocess, sys
+runner, out, src, fail = sys.argv[1:5]
+procs = []
+for rank in (1, 0):
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2")
+    procs.append(subprocess.Popen([sys.executable, runner, out, src] + ([fail] if fail != "-" and rank == 1 else []), env=env))
+sys.exit(max(abs(p.wait()) for p in procs))
+"""
+
+
+def test_a_rerun_with_the_launchers_default_rendezvous_is_not_confused_by_a_failed_run(tmp_path):
+    """plain `torchrun --nproc_per_node=2` / `accelerate launch` export the SAME 127.0.0.1:29500-none-restart0 on every
+    invocation.  Attempt 1 (rank 1 raises at its second picture) leaves .onedc_run and .failed1 behind; attempt 2 -- same
+    variables, another launcher process -- must neither start rank 1 on the dead marker nor stop on the dead .failed1: the token
+    carries the launcher's pid."""
+    src = str(tmp_path / "pictures")
+    make_pictures(src, 6)
+    out = str(tmp_path / "out")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HARNESS_MODE", "ONEDC_RUN_ID")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29500", TORCHELASTIC_RUN_ID="none", TORCHELASTIC_RESTART_COUNT="0")
+    first = subprocess.run([sys.executable, "-c", LAUNCHER, RUNNER, out, src, "1"], env=env, capture_output=True, timeout=300)
+    assert first.returncode != 0
+    assert os.path.exists(os.path.join(out, ".failed1")) and os.path.exists(os.path.join(out, ".onedc_run"))
+    stale = open(os.path.join(out, ".failed1")).read()
+    second = subprocess.run([sys.executable, "-c", LAUNCHER, RUNNER, out, src, "-"], env=env, capture_output=True, timeout=300)
+    assert second.returncode == 0, second.stderr.decode()[-3000:]
+    assert sorted(os.listdir(out)) == ["detail_bpp_caption.xlsx", "recon", "stream", "summary_bpp.xlsx"]
+    import pandas as pd
+    detail = pd.read_csv(os.path.join(out, "detail_bpp_caption.xlsx"), index_col=0)
+    assert list(detail["image_name"]) == [f"pic{i:02d}" for i in range(6)]               # nothing lost, nothing merged twice
+    assert stale.startswith("127.0.0.1:29500-none-restart0-ppid")
 
 
 def make_containers(folder, n):

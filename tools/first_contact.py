@@ -18,6 +18,12 @@ activations fit its range.  This script checks that assumption the day the files
      rms / abs-max of the stage tensors (y_hat, h_detail, eps, reduced, x0, picture), non-finite flags
   4. PSNR between the two pictures, and the recommendation: `act_dtype: f16` (default), or `bf16` when a layer comes within
      a factor 8 of the half range or the f16 picture is not finite
+  5. (round 6) the bf16-OPERAND switch on THIS checkpoint: the f16 model's resnet convs multiply bf16 operands by default since
+     round 5 (kernels.BF16_OPERANDS, + 2.3 % images/s), justified by |dPSNR| 0.0003 dB measured on synthetic weights only.  The same
+     stream is decoded with the switch on and off; PSNR between the two f32 pictures P gives the |dPSNR| it can cost a picture
+     that sits Q dB from its original: 4.34 x 10^((Q - P) / 10) dB when the two errors are uncorrelated (measured on the synthetic
+     points: P = 63.6 dB -> 0.0010 dB at Q = 27), and with --original the measured figure itself.  More than
+     half the 0.01 dB budget at Q = 30 dB -> the report recommends ONEDC_BF16_OPERANDS=0.
 
 Exit status 0 = the files load and both decodes are finite; the JSON report says the rest.
 """
@@ -31,6 +37,40 @@ import torch
 
 HALF_MAX = 65504.0
 HEADROOM_WANTED = 8.0          # recommend bf16 when a stored activation comes within this factor of the half range
+DPSNR_BUDGET = 0.01            # dB (BASELINE.json north_star)
+
+
+def dpsnr_uncorrelated(p_between, q):
+    """|dPSNR| (dB) of a picture Q dB from its original when an independent error P dB below full scale is added to it."""
+    return 4.3429 * 10.0 ** ((q - p_between) / 10.0)
+
+
+def bf16_operand_check(model, blobs, original=None):
+    """Step 5: the same stream through the f16 model with bf16 operands on and off (a run-time switch: both weight packings exist).
+    -> report dict.  original: optional [1,3,H,W] tensor in [0,1]."""
+    from onedc_amd import kernels as K
+    from onedc_amd.quality import psnr
+    pics = {}
+    keep = K.BF16_OPERANDS
+    try:
+        for on in (True, False):
+            K.BF16_OPERANDS = on
+            pics[on] = model.decode(stream=blobs, unit_range=True).float().clamp(0, 1).cpu()
+    finally:
+        K.BF16_OPERANDS = keep
+    p = float(psnr(pics[True], pics[False]))
+    rep = {"psnr_between_db": p, "dpsnr_uncorrelated_db": {str(q): dpsnr_uncorrelated(p, q) for q in (25, 27, 30, 35)},
+           "built_with_bf16_operand_weights": bool(keep)}
+    if original is not None:
+        q_on, q_off = float(psnr(pics[True], original)), float(psnr(pics[False], original))
+        rep["psnr_vs_original_db"] = {"bf16_operands": q_on, "f16_operands": q_off, "abs_delta": abs(q_on - q_off)}
+        cost = abs(q_on - q_off)
+    else:
+        cost = rep["dpsnr_uncorrelated_db"]["30"]
+    rep["recommendation"] = ("ONEDC_BF16_OPERANDS=1 (default)" if cost <= DPSNR_BUDGET / 2 else
+                             f"ONEDC_BF16_OPERANDS=0: the switch costs {cost:.4f} dB on this checkpoint, more than half the "
+                             f"{DPSNR_BUDGET} dB budget")
+    return rep
 
 
 def weight_table(sd, top=8):
@@ -126,6 +166,8 @@ def main(argv=None):
     ap.add_argument("--size", type=int, default=768, help="picture size of the synthetic stream")
     ap.add_argument("--out", default=None, help="write the JSON report here (default: stdout only)")
     ap.add_argument("--cpu-only", action="store_true", help="steps 1 and 2 only")
+    ap.add_argument("--original", default=None, help="the picture --bin was coded from (PNG / JPEG): step 5 then reports the measured "
+                                                     "|dPSNR| of the bf16-operand switch instead of the uncorrelated estimate")
     args = ap.parse_args(argv)
     report, sds = check_files(args.checkpoint_path, args.vae_path)
     ok = report["strict_load"] == "ok"
@@ -159,6 +201,16 @@ def main(argv=None):
                         blobs, _ = model.codec_model.encode_latents(idx, None, noise_seed=1)
                     report["stream"] = {"bytes": len(blobs[0]), "source": args.bin or f"synthetic, {args.size}x{args.size}"}
                 pics[fmt], decodes[fmt] = decode_instrumented(model, blobs)
+                if fmt == "f16":
+                    original = None
+                    if args.original:
+                        from PIL import Image
+                        original = torch.from_numpy(np.asarray(Image.open(args.original).convert("RGB"))).permute(2, 0, 1)[None].float() / 255
+                    model.check_finite = True
+                    try:
+                        report["bf16_operands"] = bf16_operand_check(model, blobs, original)
+                    except Exception as ex:                        # noqa: BLE001 -- (a non-finite f16 decode is reported by step 3 / 4)
+                        report["bf16_operands"] = {"error": f"{type(ex).__name__}: {ex}"}
                 del model
                 torch.cuda.empty_cache()
             report["decode"] = decodes

@@ -2,7 +2,9 @@
 """Diagnostic (EXP_W4_TIMELINE build only): phases of a 4-wave window-kernel workgroup from s_memtime stamps, and the
 shader clock the chip holds inside the K loop (delta s_memtime / delta s_memrealtime x 100 MHz, MI355X_MICROARCH.md
 'DVFS give-back' item 6), after two seconds of back-to-back launches on random data.
-usage: tools/exp_build.sh w4tl -DEXP_W4_TIMELINE; ONEDC_HIP_F16_SO=tools/exp/libonedc_hip_w4tl.so timeline_win4.py B H W Cin Cout"""
+usage: tools/exp_build.sh w4tl -DEXP_W4_TIMELINE; ONEDC_HIP_F16_SO=tools/exp/libonedc_hip_w4tl.so timeline_win4.py B H W Cin Cout
+       [--res] (residual read in the epilogue)  [--gn] (GroupNorm + SiLU on load: MODE 1)  [--bf] (bf16 operands)
+       [--epilogue] (library built with -DEXP_W4_TIMELINE -DEXP_W4_EPI_TL: slots 10 .. 13 are the epilogue's stamps, round 6)"""
 import os
 import sys
 import time
@@ -15,6 +17,7 @@ from onedc_amd import kernels as K
 from onedc_amd import pack
 
 B, H, W, Cin, Cout = map(int, sys.argv[1:6])
+FLAGS = set(sys.argv[6:])
 DEV = "cuda:0"
 g = torch.Generator(device=DEV).manual_seed(0)
 x = K.View(torch.randn((B * H * W + 128) * Cin, generator=g, device=DEV).to(K.a16()), B, H, W, Cin)
@@ -33,11 +36,20 @@ class FakeStats:
 
 
 y.stats = FakeStats()
+res = K.new_view(B, H, W, Cout, DEV) if "--res" in FLAGS else None
+if res is not None:
+    res.t.copy_(torch.randn(res.t.numel(), generator=g, device=DEV).to(K.a16()))
+gn = w_bf = None
+if "--gn" in FLAGS:
+    from onedc_amd.layers import Workspace
+    gn = (torch.ones(Cin, device=DEV), torch.zeros(Cin, device=DEV), 1e-6, True, Workspace(torch.device(DEV)))
+    if "--bf" in FLAGS:
+        w_bf = w.to(torch.bfloat16) if w.dtype != torch.bfloat16 else w
 t_end = time.time() + 2.0
 n = 0
 while time.time() < t_end:
     for _ in range(20):
-        K.conv_gemm(x, w, None, y, KH=3, tile=131, stats=True)
+        K.conv_gemm(x, w, None, y, KH=3, tile=131, stats=True, res=res, gn=gn, w_bf16=w_bf)
     torch.cuda.synchronize()
     n += 20
 d = dbg.view(blocks, 4, 16).cpu().numpy().astype(np.int64)
@@ -46,11 +58,26 @@ clk = (d[:, :, 3] - d[:, :, 2]) / np.maximum(d[:, :, 6] - d[:, :, 5], 1) * 100.0
 print(f"{blocks} workgroups, {n} launches; s_memtime ticks per workgroup (min start .. max end over its 4 waves):")
 print(f"  prologue (entry -> first fragments) {np.mean(t1 - t0):9.0f}")
 pa, pb, pc, pd = (np.mean(d[:, :, i] - d[:, :, 1]) for i in (7, 8, 9, 10))
-q0, q1, q2, q3 = (np.mean(d[:, :, i] - d[:, :, 1]) for i in (11, 12, 13, 14))
-print(f"    of it (per wave, from entry): tile decoded {q0:.0f}, first weights issued {q1:.0f}, window offsets {q2:.0f}, window issued {q3:.0f},")
+if "--epilogue" not in FLAGS:
+    q0, q1, q2, q3 = (np.mean(d[:, :, i] - d[:, :, 1]) for i in (11, 12, 13, 14))
+    print(f"    of it (per wave, from entry): tile decoded {q0:.0f}, first weights issued {q1:.0f}, window offsets {q2:.0f}, window issued {q3:.0f},")
 print(f"      every DMA issued {pa:.0f}, set-up arithmetic done {pb:.0f}, own DMA landed {pc:.0f}, barrier {pd:.0f}")
 print(f"  K loop                              {np.mean(t2 - t1):9.0f}   ({(Cin // 32) * 9} K-tiles: {np.mean(t2 - t1) / ((Cin // 32) * 9):.0f} per K-tile)")
 print(f"  epilogue                            {np.mean(t3 - t2):9.0f}")
+if "--epilogue" in FLAGS:
+    # per WAVE, from the end of its own K loop (tl[2] = column 3): 10 -> col 11, 12 -> col 13, 11 -> col 12, 3 -> col 4, 13 -> col 14
+    e = {name: d[:, :, col] - d[:, :, 3] for name, col in (("barrier", 11), ("res03", 13), ("arith", 12), ("issued", 4), ("drained", 14))}
+    seg = [("K loop end -> bias / residual rows 0-3 issued, lgkmcnt(0), barrier passed (staging rows free)", e["barrier"]),
+           ("  -> residual rows 0 .. 3 landed (forced vmcnt(0); without --res: the bias loads)", e["res03"] - e["barrier"]),
+           ("  -> 128 outputs per lane finished, rows 4 .. 7 of the residual waited for, LDS transpose written", e["arith"] - e["res03"]),
+           ("  -> 16 line stores read back from LDS and issued", e["issued"] - e["arith"]),
+           ("  -> stores drained (vmcnt(0))", e["drained"] - e["issued"])]
+    tot = np.mean(e["drained"])
+    print(f"  epilogue of ONE WAVE, s_memtime ticks from the end of its K loop (mean over all waves; p10 / p90), total {tot:.0f}:")
+    for name, v in seg:
+        print(f"    {np.mean(v):8.0f}  ({np.percentile(v, 10):6.0f} / {np.percentile(v, 90):6.0f})  {100 * np.mean(v) / tot:5.1f} %  {name}")
+    t3 = d[:, :, 14].max(1)                     # the workgroup ends when its stores have drained
+    print(f"  whole workgroup incl. drain         {np.mean(t3 - t0):9.0f}")
 print(f"  whole workgroup                     {np.mean(t3 - t0):9.0f}")
 print(f"  shader clock inside the K loop      median {np.median(clk):7.0f} MHz  (p10 {np.percentile(clk, 10):.0f}, p90 {np.percentile(clk, 90):.0f})")
 
