@@ -240,6 +240,32 @@ int onedc_flash_attn_strided(const void *q, const void *k, const void *vt, void 
  * at least 64 keys: P and V^T of those kernels are bf16, see attention.hip); the producer sets onedc_conv_params.out_bf16 */
 int onedc_flash_attn_vt_is_bf16(int DQ, int DV, int Nk);
 
+/* The cross-attention half of a diffusers BasicTransformerBlock as ONE launch (round 6; reference call site
+ * src/models/sd15_onedc_codec_stage1/decoder_unet.py:204-293, where every transformer block of the UNet attends to the same 144
+ * context tokens):      y = h + to_out( softmax( to_q(LayerNorm(h)) . K^T * scale ) . V ) + to_out.bias
+ * replacing onedc_layernorm + onedc_conv_gemm (to_q) + onedc_flash_attn_strided + onedc_conv_gemm (to_out, residual) and three
+ * passes of the residual stream through HBM: a workgroup keeps 64 pixels resident from the LayerNorm to the residual add
+ * (csrc/xattn_block.hip).  h, y: [B * HW][*_cs] 16-bit rows, channels [*_co, *_co + C) (y must not alias h: a tile's rows are
+ * read again for the residual late in the workgroup).  ln_g / ln_b / bo: f32 [C].  wq, wo: the layers' packed matrices [C rounded up to 128 rows][C], k-contiguous, 16-bit
+ * (onedc_amd/pack.py: pack_matrix; to_q has no bias).  k: [B * Nk][k_rs] 16-bit, head i at columns i * d (COMPACT heads);
+ * vt: [B][heads * d][Nk_pad] with vt_bs elements between pictures, zero beyond Nk, bf16 when vt_bf16 (what
+ * onedc_flash_attn_vt_is_bf16 says the flash kernel of this shape reads: the projection GEMM stores it once for both) else the
+ * library's format.  Shapes: C = 320, heads = 8, d = 40, Nk % 16 == 0 and <= 160, HW % 64 == 0, strides multiples of 8;
+ * onedc_xattn_block_ok answers 1 / 0 for a parameter set without launching, onedc_xattn_block returns -1 for a refused one. */
+typedef struct onedc_xattn_params {
+    const void *h; const float *ln_g; const float *ln_b; const void *wq; const void *k; const void *vt; const void *wo;
+    const float *bo; void *y;
+    int32_t B, HW, C, heads, d, Nk, Nk_pad, k_rs;
+    int32_t h_cs, h_co, y_cs, y_co, vt_bf16;
+    float ln_eps, scale;
+    int64_t vt_bs;
+    const float *bq;                    /* NULL, or a bias of the q projection, f32 [C].  A host may fold the LayerNorm's affine into to_q --
+                                           wq = Wq . diag(gamma), bq = Wq . beta -- and pass ln_g = ln_b = NULL: the kernel then only centres and
+                                           scales the tile (40 fewer loads and 80 fewer multiply-adds per thread in front of the first MFMA) */
+} onedc_xattn_params;
+int onedc_xattn_block_ok(const onedc_xattn_params *p);
+int onedc_xattn_block(const onedc_xattn_params *p, void *stream);
+
 /* ---- elementwise heads ------------------------------------------------------------------- */
 /* FSQ.indices_to_codes, levels [4]*7 (codec_module.py:431): idx int32 [n] -> f32 codes [n][8]
  * (7 used, channel 7 = 0). */

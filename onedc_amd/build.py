@@ -92,7 +92,7 @@ def build_coder(force=False):
 _NO_SLP = ("-fno-slp-vectorize",)
 # ref_arith.hip reproduces torch-CPU's rounding sequence: a multiply followed by an add must stay two roundings (the chains
 # themselves are explicit fmaf calls)
-FILE_FLAGS = {"attention.hip": ("-fno-honor-nans",) + _NO_SLP, "gemm_conv_win.hip": _NO_SLP, "gemm_conv_win4.hip": _NO_SLP, "gemm_conv.hip": _NO_SLP,
+FILE_FLAGS = {"attention.hip": ("-fno-honor-nans",) + _NO_SLP, "xattn_block.hip": ("-fno-honor-nans",) + _NO_SLP, "gemm_conv_win.hip": _NO_SLP, "gemm_conv_win4.hip": _NO_SLP, "gemm_conv.hip": _NO_SLP,
               "gemm_conv256.hip": _NO_SLP, "gemm_conv_ups.hip": _NO_SLP, "ref_arith.hip": ("-ffp-contract=off",)}
 
 

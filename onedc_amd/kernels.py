@@ -92,6 +92,18 @@ class DirectConvParams(C.Structure):
     ]
 
 
+class XAttnParams(C.Structure):
+    """onedc_xattn_params of include/onedc_hip.h."""
+    _fields_ = [
+        ("h", _P), ("ln_g", _P), ("ln_b", _P), ("wq", _P), ("k", _P), ("vt", _P), ("wo", _P), ("bo", _P), ("y", _P),
+        ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32), ("d", C.c_int32), ("Nk", C.c_int32),
+        ("Nk_pad", C.c_int32), ("k_rs", C.c_int32),
+        ("h_cs", C.c_int32), ("h_co", C.c_int32), ("y_cs", C.c_int32), ("y_co", C.c_int32), ("vt_bf16", C.c_int32),
+        ("ln_eps", _F), ("scale", _F),
+        ("vt_bs", _L), ("bq", _P),
+    ]
+
+
 SIGNATURES = {
     "onedc_conv_gemm": (_I, [C.POINTER(ConvParams), _P]),
     "onedc_conv_win_takes": (_I, [C.POINTER(ConvParams)]),
@@ -113,6 +125,8 @@ SIGNATURES = {
     "onedc_flash_attn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "onedc_flash_attn_strided": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _L, _P]),
     "onedc_flash_attn_vt_is_bf16": (_I, [_I, _I, _I]),
+    "onedc_xattn_block_ok": (_I, [C.POINTER(XAttnParams)]),
+    "onedc_xattn_block": (_I, [C.POINTER(XAttnParams), _P]),
     "onedc_fsq_codes": (_I, [_P, _P, _L, _P]),
     "onedc_fsq_quantize": (_I, [_P, _I, _I, _I, _P, _L, _P]),
     "onedc_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -470,7 +484,11 @@ USE_EPILOGUE_STATS = True    # False: always run the separate statistics pass (t
 # bf16 where the 4-wave window kernel runs them; ONEDC_BF16_OPERANDS=0: f16 operands everywhere (A/B, tests)
 BF16_OPERANDS = __import__("os").environ.get("ONEDC_BF16_OPERANDS", "1") != "0"
 KERNEL_WIN3X3_4W = 10              # ONEDC_KERNEL_WIN3X3_4W of include/onedc_hip.h
-GN_FUSION_MAX_COUT = int(__import__("os").environ.get("ONEDC_GN_FUSION_MAX_COUT", "128"))
+# GroupNorm on load up to this many output channels.  128 (one channel tile per window) until round 6; 256 since: where a window has
+# TWO 128-channel tiles each tile's workgroup normalises it again, and that still beats the separate scale / shift pass on both two-tile
+# shapes of the VAE (256 -> 256 at 384 x 384 2.552 -> 2.491 ms, 512 -> 256 4.932 -> 4.658 ms: profiles/r6_tile256_probe.txt); three tiles
+# and more do not (the pass shrinks relative to the conv, the repeated normalisation does not)
+GN_FUSION_MAX_COUT = int(__import__("os").environ.get("ONEDC_GN_FUSION_MAX_COUT", "256"))
 USE_GN_FUSION = True         # False: GroupNorm in front of a conv always runs as its own scale/shift pass (tests, A/B)
 
 
@@ -527,6 +545,33 @@ def flash_attn(q, k, vt, o, B, H, Nq, Nk, Nk_pad, DQ, DV, scale, q_rs=0, k_rs=0,
     _ok(lib().onedc_flash_attn_strided(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, H, Nq, Nk, Nk_pad,
                                        DQ, DV, scale, q_rs, k_rs, vt_bs, stream()), "onedc_flash_attn_strided")
     return o
+
+
+# The cross-attention half of a transformer block as one launch (csrc/xattn_block.hip, round 6) where the kernel takes the shape
+# (the UNet's 96 x 96 level: C = 320, 8 heads of 40, compact heads, a context of 16 .. 160 tokens in whole 16s); ONEDC_XATTN=0: the
+# four separate launches everywhere (A/B, tests)
+USE_XATTN_BLOCK = os.environ.get("ONEDC_XATTN", "1") != "0"
+
+
+def xattn_params(h, ln_g, ln_b, eps, wq, bq, k, k_rs, vt, vt_bs, wo, bo, y, heads, d, Nk, Nk_pad, scale):
+    """ln_g / ln_b None: the LayerNorm's affine is folded into wq / bq (onedc_xattn_params.bq)."""
+    p = XAttnParams()
+    p.h, p.ln_g, p.ln_b, p.wq, p.k, p.vt, p.wo, p.bo, p.y = (h.ptr, _ptr(ln_g), _ptr(ln_b), wq.data_ptr(), k.data_ptr(),
+                                                            vt.data_ptr(), wo.data_ptr(), _ptr(bo), y.ptr)
+    p.bq = _ptr(bq)
+    p.B, p.HW, p.C, p.heads, p.d, p.Nk, p.Nk_pad, p.k_rs = h.B, h.H * h.W, h.C, heads, d, Nk, Nk_pad, k_rs
+    p.h_cs, p.h_co, p.y_cs, p.y_co = h.cs, h.co, y.cs, y.co
+    p.vt_bf16 = int(vt.dtype == torch.bfloat16 and a16() != torch.bfloat16)
+    p.ln_eps, p.scale, p.vt_bs = eps, scale, vt_bs
+    return p
+
+
+def xattn_block_ok(p):
+    return bool(USE_XATTN_BLOCK and lib().onedc_xattn_block_ok(C.byref(p)))
+
+
+def xattn_block(p):
+    _ok(lib().onedc_xattn_block(C.byref(p), stream()), "onedc_xattn_block")
 
 
 def fsq_codes(idx, codes):

@@ -395,6 +395,10 @@ class MultiHeadAttention:
             if self.compact:
                 self.q_c = Conv(sd, "", device, weight=sd[f"{p}.to_q.weight"])
                 self.wk_rows_c, self.wv_rows_c = sd[f"{p}.to_k.weight"], sd[f"{p}.to_v.weight"]   # (for ContextKV)
+            # the fused block (block_fused) takes to_q with the LayerNorm's affine folded in: the f32 matrix is kept on the host
+            # until the first call knows that norm (only where the kernel exists: the UNet's first level)
+            self._wq_host = sd[f"{p}.to_q.weight"].detach().float().cpu() if (self.compact and C == 320 and heads == 8) else None
+            self._xq = self._xbq = self._x_ln = None
         self.o = Conv(sd, "", device, weight=pack.pad_heads_cols(sd[f"{p}.to_out.0.weight"], heads, d, self.DV),
                       bias=sd[f"{p}.to_out.0.bias"], flop_scale=d / self.DV)
         if self.compact:
@@ -444,6 +448,42 @@ class MultiHeadAttention:
         K.flash_attn(q_t, k_t, vt, o.t, B, self.H, Nq, Nk, Nk_pad, DQ, DV, self.d ** -0.5,
                      q_rs=q_rs, k_rs=k_rs, vt_bs=vt_bs)
         return (self.o_c if compact else self.o)(o, y, res=res)
+
+    def prepare_fused(self, ln, device):
+        """Called once by the block that owns this layer and the LayerNorm `ln` in front of it (Transformer2D.__init__; not lazily:
+        the pipeline's stream threads run the same layers side by side).  to_q(LayerNorm(h)) = (Wq . diag(gamma)) . hhat + Wq . beta
+        with hhat = (h - mean) * rstd: the fused kernel centres and scales, the affine rides in the weights (rounded to 16 bits
+        once, like Wq itself) and in a bias of q."""
+        if self._wq_host is None:
+            return self
+        gam, bet = ln.g.detach().float().cpu(), ln.b.detach().float().cpu()
+        self._xq = pack.pack_matrix(self._wq_host * gam[None, :], device)
+        self._xbq = pack.f32(self._wq_host @ bet, device)
+        self._wq_host, self._x_ln = None, ln
+        return self
+
+    def block_fused(self, h, ln, ctx, kv, y=None):
+        """Cross-attention only: y = h + to_out(attention(to_q(LayerNorm(h)), K, V)) as ONE launch (kernels.xattn_block) --
+        `ln` is the block's LayerNorm in front of this layer (the one prepare_fused folded into to_q), kv its slices of the shared
+        context projections.  Returns None, with nothing launched, where the kernel does not take the layer (the caller runs
+        LayerNorm + __call__)."""
+        if self.self_attention or kv is None or not kv[4] or not self.compact or not K.USE_XATTN_BLOCK:
+            return None
+        Nk = ctx.H * ctx.W
+        Nk_pad = (Nk + 63) // 64 * 64
+        k_t, k_rs, vt, vt_bs = kv[:4]
+        if y is None:
+            y = new_view(h.B, h.H, h.W, self.C, h.t.device)
+        if y.t.data_ptr() == h.t.data_ptr():
+            return None                                                # (the kernel re-reads h for the residual: no aliasing)
+        if self._xq is None or ln is not self._x_ln:
+            return None                                                # (prepare_fused was not called for this block's norm)
+        p = K.xattn_params(h, None, None, 1e-5, self._xq, self._xbq, k_t, k_rs, vt, vt_bs, self.o_c.w, self.o_c.b, y, self.H,
+                           self.d, Nk, Nk_pad, self.d ** -0.5)
+        if h.C != self.C or not K.xattn_block_ok(p):
+            return None
+        K.xattn_block(p)
+        return y
 
 
 class _ContextKVSet:
@@ -546,7 +586,7 @@ class Transformer2D:
         self.proj_in = Conv(sd, f"{p}.proj_in", device)
         self.n1, self.n2, self.n3 = (LayerNorm(sd, f"{t}.norm{i}", device) for i in (1, 2, 3))
         self.attn1 = MultiHeadAttention(sd, f"{t}.attn1", device, C, C, self_attention=True)
-        self.attn2 = MultiHeadAttention(sd, f"{t}.attn2", device, C, ctx_dim, self_attention=False)
+        self.attn2 = MultiHeadAttention(sd, f"{t}.attn2", device, C, ctx_dim, self_attention=False).prepare_fused(self.n2, device)
         self.ff1 = Conv(sd, f"{t}.ff.net.0.proj", device, glu=True)
         self.ff2 = Conv(sd, f"{t}.ff.net.2", device)
         self.proj_out = Conv(sd, f"{p}.proj_out", device)
@@ -556,7 +596,9 @@ class Transformer2D:
         h = self.proj_in(self.norm(x, ws, False))
         n = self.n1(h)
         h = self.attn1(n, n, h, ws=ws)
-        h = self.attn2(self.n2(h), ctx, h, ws=ws, kv=kv)
+        # norm2 -> attn2 -> + h: one launch where the fused kernel takes the level (csrc/xattn_block.hip), four otherwise
+        h2 = self.attn2.block_fused(h, self.n2, ctx, kv) if kv is not None else None
+        h = h2 if h2 is not None else self.attn2(self.n2(h), ctx, h, ws=ws, kv=kv)
         f = self.ff1(self.n3(h), epi=EPI_GEGLU)
         h = self.ff2(f, res=h)
         return self.proj_out(h, y, res=x, stats=True)

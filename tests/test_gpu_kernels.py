@@ -389,6 +389,80 @@ def test_attention_layer_with_compact_heads_equals_the_padded_layer(C, self_attn
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("hw,ctx_hw", [((16, 16), (12, 12)), ((24, 16), (8, 8)), ((8, 8), (4, 4))])
+def test_cross_attention_block_as_one_launch(hw, ctx_hw):
+    """csrc/xattn_block.hip (round 6): norm2 -> attn2.to_q -> attention over the context -> attn2.to_out + residual of a diffusers
+    BasicTransformerBlock (reference src/models/sd15_onedc_codec_stage1/decoder_unet.py:204-293) as ONE launch, against (a) a plain
+    torch fp32 reference of the same ops on the same 16-bit inputs and weights and (b) the four separate launches it replaces
+    (LayerNorm, to_q, flash attention, to_out + residual).  C = 320, 8 heads of 40 (the UNet's first level); contexts of 144 (the
+    768 x 768 picture), 64 and 16 tokens.  Tolerances: the layer bound of this file against the reference; 3e-3 rel. RMS between the
+    two device paths (both round q, o and y to 16 bits once; the fused kernel keeps the row maximum where flash_attn64 uses a lazy
+    one, and sums the projections' K loop in another order)."""
+    from onedc_amd import layers as L
+    C, Hh, d, B = 320, 8, 40, 2
+    g = torch.Generator().manual_seed(97)
+    sd = {f"a.{n}.weight": rnd(C, 768 if n in ("to_k", "to_v") else C, seed=101 + i, scale=(768 if n in ("to_k", "to_v") else C) ** -0.5)
+          for i, n in enumerate(("to_q", "to_k", "to_v", "to_out.0"))}
+    sd["a.to_out.0.bias"] = rnd(C, seed=110, scale=0.1)
+    sd["n.weight"], sd["n.bias"] = 1.0 + rnd(C, seed=111, scale=0.2), rnd(C, seed=112, scale=0.2)
+    h_t = rnd(B, C, *hw, seed=113)
+    h_t[:, :40] += 3.0                                           # a mean that is not zero: the LayerNorm has something to subtract
+    h_t = h_t.to(K.a16()).float()
+    ctx_t = rnd(B, 768, *ctx_hw, seed=114)
+    h, ctx = from_nchw(h_t.to(DEV)), from_nchw(ctx_t.to(DEV))
+    Nk = ctx_hw[0] * ctx_hw[1]
+    ln = L.LayerNorm(sd, "n", DEV)
+    layer = L.MultiHeadAttention(sd, "a", DEV, C, 768, self_attention=False).prepare_fused(ln, DEV)
+    ws = L.Workspace(DEV)
+    ckv = L.ContextKV([layer], DEV)
+    kv = ckv(ctx, ws)[0]
+    keep = K.USE_XATTN_BLOCK
+    try:
+        K.USE_XATTN_BLOCK = True
+        fused = layer.block_fused(h, ln, ctx, kv)
+        K.USE_XATTN_BLOCK = False
+        assert layer.block_fused(h, ln, ctx, kv) is None
+        unfused = layer(ln(h), ctx, h, ws=ws, kv=kv)
+    finally:
+        K.USE_XATTN_BLOCK = keep
+    if Nk < 64 or Nk % 16:                                      # compact heads need 64 keys, the kernel whole 16s
+        assert fused is None
+        return
+    assert fused is not None
+    torch.cuda.synchronize()
+    # fp32 reference on the same rounded inputs
+    x = h_t.permute(0, 2, 3, 1).reshape(B, -1, C)
+    n = F.layer_norm(x, (C,), sd["n.weight"], sd["n.bias"], 1e-5)
+    c = ctx_t.permute(0, 2, 3, 1).reshape(B, -1, 768)
+    q = (n @ sd["a.to_q.weight"].T).view(B, -1, Hh, d).transpose(1, 2)
+    k = (c @ sd["a.to_k.weight"].T).view(B, -1, Hh, d).transpose(1, 2)
+    v = (c @ sd["a.to_v.weight"].T).view(B, -1, Hh, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, -1, C)
+    ref = (x + o @ sd["a.to_out.0.weight"].T + sd["a.to_out.0.bias"]).view(B, *hw, C).permute(0, 3, 1, 2)
+    close(fused.torch_nchw(), ref, rms=4e-3, mx=2.5e-2, what=f"fused cross-attention block {hw} x {Nk} keys")
+    close(unfused.torch_nchw(), ref, rms=4e-3, mx=2.5e-2, what="the four launches")
+    close(fused.torch_nchw(), unfused.torch_nchw(), rms=3e-3, mx=2.5e-2, what="fused against unfused")
+    # the kernel's other form: the LayerNorm's affine applied inside (ln_g / ln_b given, to_q's own weights, no q bias) -- what a C
+    # host that does not fold would call
+    k_t, k_rs, vt, vt_bs = kv[:4]
+    y2 = new_view(B, *hw, C, DEV)
+    p2 = K.xattn_params(h, ln.g, ln.b, 1e-5, layer.q_c.w, None, k_t, k_rs, vt, vt_bs, layer.o_c.w, layer.o_c.b, y2, Hh, d, Nk,
+                        (Nk + 63) // 64 * 64, d ** -0.5)
+    assert K.lib().onedc_xattn_block_ok(__import__("ctypes").byref(p2)) == 1
+    K.xattn_block(p2)
+    close(y2.torch_nchw(), ref, rms=4e-3, mx=2.5e-2, what="fused block, affine inside")
+    p2.ln_b = None                                               # gamma without beta: refused, nothing launched
+    assert K.lib().onedc_xattn_block_ok(__import__("ctypes").byref(p2)) == 0
+    # batch invariance (the path's determinism rule): picture 1 alone == picture 1 inside the batch
+    K.USE_XATTN_BLOCK = True
+    try:
+        one = layer.block_fused(h.batch_slice(1, 2), ln, ctx.batch_slice(1, 2), ckv(ctx.batch_slice(1, 2), ws)[0])
+    finally:
+        K.USE_XATTN_BLOCK = keep
+    npx = hw[0] * hw[1] * C
+    assert torch.equal(one.t[:npx], fused.t[npx:2 * npx])
+
+
 def test_mxfp8_roundtrip_kernel_matches_the_ocp_definition():
     """onedc_mxfp8_roundtrip against the definition written with torch's own float8_e4m3fn cast (pack.mxfp8_roundtrip: e4m3,
     round to nearest even, saturating, one power-of-two scale per 32 channels): bit-equal, including blocks of zeros, values

@@ -8,8 +8,8 @@ mkdir -p tools/exp
 objs=""
 for f in onedc_amd/csrc/*.hip; do
   o=tools/exp/$(basename ${f%.hip})_$name.o
-  ff=""; [ "$(basename $f)" = attention.hip ] && ff="-fno-honor-nans"
-  case "$(basename $f)" in attention.hip|gemm_conv*.hip) ff="$ff -fno-slp-vectorize";; esac   # as onedc_amd/build.py
+  ff=""; case "$(basename $f)" in attention.hip|xattn_block.hip) ff="-fno-honor-nans";; esac
+  case "$(basename $f)" in attention.hip|xattn_block.hip|gemm_conv*.hip) ff="$ff -fno-slp-vectorize";; esac   # as onedc_amd/build.py
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wno-unused-result $ff "$@" -o $o $f 2>/dev/null &
   objs="$objs $o"
 done
