@@ -53,7 +53,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-PROFILE_ROUNDS = ("r5", "r4", "r3", "r2", "r1")   # committed measurement records, newest first (profiles/<round>_*)
+PROFILE_ROUNDS = ("r6", "r5", "r4", "r3", "r2", "r1")   # committed measurement records, newest first (profiles/<round>_*)
 PEAK_MFMA16_TFLOPS = 2500.0        # MI355X dense bf16 / f16 MFMA (guide: MI355X_MICROARCH.md)
 GFLOP_PER_IMAGE = {768: 8046.7, 512: 3419.5, 256: 831.4}   # SURVEY.md 8(d), decode, algorithmic, 2*MAC
 MODE_DEFAULTS = {"decode": (768, 16), "z_only": (768, 16), "encode_decode": (512, 8)}

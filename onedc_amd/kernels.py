@@ -484,11 +484,12 @@ USE_EPILOGUE_STATS = True    # False: always run the separate statistics pass (t
 # bf16 where the 4-wave window kernel runs them; ONEDC_BF16_OPERANDS=0: f16 operands everywhere (A/B, tests)
 BF16_OPERANDS = __import__("os").environ.get("ONEDC_BF16_OPERANDS", "1") != "0"
 KERNEL_WIN3X3_4W = 10              # ONEDC_KERNEL_WIN3X3_4W of include/onedc_hip.h
-# GroupNorm on load up to this many output channels.  128 (one channel tile per window) until round 6; 256 since: where a window has
-# TWO 128-channel tiles each tile's workgroup normalises it again, and that still beats the separate scale / shift pass on both two-tile
-# shapes of the VAE (256 -> 256 at 384 x 384 2.552 -> 2.491 ms, 512 -> 256 4.932 -> 4.658 ms: profiles/r6_tile256_probe.txt); three tiles
-# and more do not (the pass shrinks relative to the conv, the repeated normalisation does not)
-GN_FUSION_MAX_COUT = int(__import__("os").environ.get("ONEDC_GN_FUSION_MAX_COUT", "256"))
+# GroupNorm on load up to this many output channels: 128 = one channel tile per window.  Round 6 priced 256 (two tiles: each tile's
+# workgroup normalises the window again) on hardware: per layer it beats the separate scale / shift pass (256 -> 256 at 384 x 384 2.552
+# -> 2.491 ms, 512 -> 256 4.932 -> 4.658 ms: profiles/r6_tile256_probe.txt), in the whole bench it is worth + 0.1 % (noise:
+# profiles/r6_ab_gn_fusion_cout.txt) -- it moves 3 ms of an HBM-bound pass into the MFMA-bound window kernel, whose issue slots are the
+# step's scarce resource.  Not adopted; ONEDC_GN_FUSION_MAX_COUT=256 is the switch.
+GN_FUSION_MAX_COUT = int(__import__("os").environ.get("ONEDC_GN_FUSION_MAX_COUT", "128"))
 USE_GN_FUSION = True         # False: GroupNorm in front of a conv always runs as its own scale/shift pass (tests, A/B)
 
 

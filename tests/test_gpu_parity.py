@@ -598,6 +598,13 @@ def test_cli_harness_encode_decode_and_decoder_only(tmp_path):
     assert rep["decode"]["f16"]["conv_launches"] > 300 and not rep["decode"]["f16"]["nonfinite_pictures"]
     assert rep["decode"]["f16"]["stages"]["x0"]["finite"] and rep["psnr_f16_vs_bf16_db"] > 35.0
     assert rep["recommendation"]["act_dtype"] in ("f16", "bf16") and rep["stream"]["bytes"] == (out / "stream" / "b.bin").stat().st_size
+    # round 6, step 5: the bf16-operand switch measured on THESE weights (same stream, switch on / off), and a recommendation from it
+    bo = rep["bf16_operands"]
+    assert "error" not in bo, bo
+    assert bo["psnr_between_db"] > 45.0 and set(bo["dpsnr_uncorrelated_db"]) == {"25", "27", "30", "35"}
+    assert bo["dpsnr_uncorrelated_db"]["25"] < bo["dpsnr_uncorrelated_db"]["35"]
+    assert bo["recommendation"].startswith("ONEDC_BF16_OPERANDS=")
+    assert fc.dpsnr_uncorrelated(63.57, 27.0) == pytest.approx(0.00095, rel=0.05)           # (63.57 dB -> 0.0010 dB at 27 dB)
     # a file that breaks the contract is reported, not loaded
     bad = dict(codec_full)
     bad.pop("dec.conv_out.weight", None) if "dec.conv_out.weight" in bad else bad.pop(sorted(bad)[0])

@@ -53,5 +53,5 @@ rows = B * HW * HW
 gf = (2 * 2.0 * rows * C * C + 4.0 * rows * (HW // 8) ** 2 * C) / 1e9
 for name in times:
     us = statistics.median(times[name])
-    print(f"{name:8s} {us:8.1f} us   {gf / us * 1e-3:7.1f} TFLOP/s algorithmic   {3 * rows * C * 2 / us / 1e6:6.2f} TB/s of (h read twice + y written)")
+    print(f"{name:8s} {us:8.1f} us   {gf / us * 1e3:7.1f} TFLOP/s algorithmic   {3 * rows * C * 2 / us / 1e6:6.2f} TB/s of (h read twice + y written)")
 print(f"fused / unfused time {statistics.median(times['fused']) / statistics.median(times['unfused']):.3f}")

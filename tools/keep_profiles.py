@@ -48,7 +48,8 @@ def main():
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     plain = {"bench_line.json", "bench_line_bf16.json", "bench_line_sequential.json", "bench_line_zonly.json", "bench_line_encdec.json",
              "bench_line_under_profiler.json", "pmc_traffic.json", "pmc_mfma.json", "mfma_rate.txt", "unet_layers.txt",
-             "vae_layers.txt", "ab_round4.txt", "bench_1x1.txt", "mfma_power.txt", "stage_times.txt", "bench_gn.txt", "bench_attn.txt"}
+             "vae_layers.txt", "ab_round4.txt", "bench_1x1.txt", "mfma_power.txt", "stage_times.txt", "bench_gn.txt", "bench_attn.txt",
+             "bench_xattn.txt"}
     for name in sorted(plain):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
@@ -57,10 +58,11 @@ def main():
     seq = os.path.join(src, "sequential_kernel_stats.csv")
     if os.path.exists(seq):
         line = json.load(open(os.path.join(src, "bench_line_seqprof.json")))
-        decodes = line["steps"] + line["warmup"]
+        # (round 6: the bench times `repeatability.regions` regions of `steps` steps back to back)
+        decodes = line["steps"] * line.get("repeatability", {}).get("regions", 1) + line["warmup"]
         total, parts = family_line(seq, decodes)
         head = (f"# rocprofv3 --kernel-trace --stats of python3 bench.py --sequential --steps {line['steps']} --warmup {line['warmup']} "
-                f"--no-cpu-baseline --no-extras (tools/profile_round.sh):\n# {decodes} decodes of 16 x 768x768 one after the other, nothing "
+                f"--no-cpu-baseline --no-extras (tools/profile_round.sh; {line.get('repeatability', {}).get('regions', 1)} timed region(s)):\n# {decodes} decodes of 16 x 768x768 one after the other, nothing "
                 f"else on the GPU: {total:.1f} ms of kernel time per batch, by family (ms): {parts}.\n")
         if remark:
             head += f"# {remark}\n"

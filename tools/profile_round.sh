@@ -14,7 +14,7 @@ run bench_line_bf16 env ONEDC_ACT=bf16 python3 bench.py --no-cpu-baseline --no-s
 run bench_line_sequential python3 bench.py --sequential --no-cpu-baseline --no-side-lines
 run bench_line_zonly python3 bench.py --mode z_only --no-cpu-baseline
 run bench_line_encdec python3 bench.py --mode encode_decode
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r5 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline --no-extras > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/prof" -o r6 --output-format csv -- python3 "$root/bench.py" --no-cpu-baseline --no-extras > "$root/$out/bench_line_under_profiler.json" 2> "$root/$out/prof.err" < /dev/null; echo "prof rc=$?" )
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$root/$out/pmc_$c" -o pmc --output-format csv -- python3 "$root/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --sequential > /dev/null 2> "$root/$out/pmc_$c.err" < /dev/null; echo "pmc $c rc=$?" )
 done
@@ -41,4 +41,16 @@ timeout 300 python3 tools/bench_1x1.py 136 > "$out/bench_1x1.txt" 2>&1 < /dev/nu
 timeout 200 python3 tools/stage_times.py > "$out/stage_times.txt" 2>&1 < /dev/null
 timeout 200 python3 tools/bench_gn.py > "$out/bench_gn.txt" 2>&1 < /dev/null
 timeout 200 python3 tools/bench_attn.py > "$out/bench_attn.txt" 2>&1 < /dev/null
+ls -la "$out" < /dev/null
+# round 6: the fused cross-attention block against the four launches, the window kernel's instruction mix against LDS reads per MFMA
+timeout 200 python3 tools/bench_xattn.py > "$out/bench_xattn.txt" 2>&1 < /dev/null
+[ -x tools/micro/mfma_lds_mix ] && timeout 200 tools/micro/mfma_lds_mix > "$out/power_mix.txt" 2>&1 < /dev/null
+ls -la "$out" < /dev/null
+# round 6: the bench line once more, now that this batch's own PMC records exist (roofline.traffic / mfma_util_pmc cite them: traffic_from)
+if [ -s "$out/pmc_traffic.json" ] && [ -s "$out/pmc_mfma.json" ]; then
+  tag=$(python3 -c "import bench; print(bench.PROFILE_ROUNDS[0])")
+  cp "$out/pmc_traffic.json" "profiles/${tag}_pmc_traffic.json"; cp "$out/pmc_mfma.json" "profiles/${tag}_pmc_mfma.json"
+  cp "$out/bench_line.json" "$out/bench_line_first.json"
+  run bench_line python3 bench.py
+fi
 ls -la "$out" < /dev/null

@@ -45,7 +45,21 @@ def wrapped(x, w, bias, y, **kw):
     return r
 
 
+xrec = []
+orig_x = K.xattn_block
+
+
+def wrapped_x(p):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    orig_x(p)
+    e1.record()
+    rows = p.B * p.HW
+    xrec.append((e0, e1, 2 * 2.0 * rows * p.C * p.C + 4.0 * rows * p.Nk * p.C, 3.0 * rows * p.C * 2))
+
+
 K.conv_gemm = wrapped
+K.xattn_block = wrapped_x
 import onedc_amd.layers as L
 L.K.conv_gemm = wrapped
 unet(x, 999, ctx)
@@ -60,3 +74,8 @@ tot = sum(v[1] for v in agg.values())
 print(f"conv launches {len(rec)}, {tot:.2f} ms")
 for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
     print(f"k{key[0]} out {key[1]:3d}x{key[1]:<3d} {key[2]:5d}->{key[3]:<5d} epi{key[4]} batch{key[5]:<3d} {key[6]:14s} x{n:3d} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF executed")
+if xrec:
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in xrec)
+    fl, by = sum(r[2] for r in xrec), sum(r[3] for r in xrec)
+    print(f"fused cross-attention block (norm2 + attn2.to_q + attention + attn2.to_out + residual, csrc/xattn_block.hip) x{len(xrec):3d} "
+          f"{ms:7.3f} ms  {ms / len(xrec) * 1e3:6.1f} us each  {fl / ms / 1e9:6.1f} TF algorithmic  {by / ms / 1e9:5.2f} TB/s of (h read twice + y written)")
