@@ -459,6 +459,8 @@ int onedc_xattn_block_ok(const onedc_xattn_params *p) {
     if (p->Nk < 16 || p->Nk > 160 || (p->Nk & 15) || p->Nk_pad < p->Nk || (p->Nk_pad & 7)) return 0;
     if (p->HW <= 0 || (p->HW % XM) || p->B <= 0 || (int64_t)p->B * p->HW / XM > 0x7fffffff) return 0;
     if (((p->h_cs | p->h_co | p->y_cs | p->y_co | p->k_rs) & 7) || p->k_rs < XHEADS * XD) return 0;
+    if (p->h_co < 0 || p->y_co < 0 || p->h_co + XC > p->h_cs || p->y_co + XC > p->y_cs) return 0;      // the channel slices lie inside their rows
+    if (p->vt_bs < (int64_t)XHEADS * XD * p->Nk_pad || p->h == p->y) return 0;
     return 1;
 }
 

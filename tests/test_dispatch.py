@@ -193,3 +193,32 @@ def test_head_layouts():
     lib = K.lib()
     assert lib.onedc_flash_attn_vt_is_bf16(128, 96, 144) == 1 and lib.onedc_flash_attn_vt_is_bf16(128, 96, 16) == 0
     assert lib.onedc_flash_attn_vt_is_bf16(160, 160, 576) == 0
+
+
+def test_fused_cross_attention_block_says_which_shapes_it_takes():
+    """onedc_xattn_block_ok (csrc/xattn_block.hip, round 6) answers on the host, without a launch: the UNet's first level (C = 320, 8
+    heads of 40, a context of 16 .. 160 tokens in whole 16s, pixel counts in whole 64s, channel slices inside their rows, no aliasing,
+    the LayerNorm's affine given whole or folded away) and nothing else -- the caller keeps the four separate launches otherwise."""
+    lib = K.lib()
+    d1, d2 = C.cast(C.create_string_buffer(64), C.c_void_p), C.cast(C.create_string_buffer(64), C.c_void_p)
+
+    def xp(**kw):
+        p = K.XAttnParams()
+        p.h, p.y = d1, d2
+        p.ln_g = p.ln_b = p.wq = p.k = p.vt = p.wo = p.bo = d1
+        p.B, p.HW, p.C, p.heads, p.d, p.Nk, p.Nk_pad, p.k_rs = 16, 96 * 96, 320, 8, 40, 144, 192, 16 * 320
+        p.h_cs, p.h_co, p.y_cs, p.y_co, p.vt_bf16 = 320, 0, 320, 0, 1
+        p.ln_eps, p.scale, p.vt_bs = 1e-5, 40 ** -0.5, 16 * 320 * 192
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+    ok = lambda p: lib.onedc_xattn_block_ok(C.byref(p))          # noqa: E731
+    assert ok(xp()) == 1
+    assert ok(xp(ln_g=None, ln_b=None, bq=d1)) == 1                       # the affine folded into to_q by the host
+    assert ok(xp(Nk=64, Nk_pad=64)) == 1 and ok(xp(Nk=16, Nk_pad=64)) == 1 and ok(xp(Nk=160, Nk_pad=192)) == 1
+    assert ok(xp(HW=64 * 64)) == 1 and ok(xp(h_cs=640, h_co=320, y_cs=960, y_co=640)) == 1
+    for bad in (dict(C=640), dict(heads=4), dict(d=80), dict(Nk=150), dict(Nk=176, Nk_pad=192), dict(Nk=0), dict(Nk_pad=128),
+                dict(HW=12 * 12), dict(h_co=4), dict(y_cs=324), dict(h_cs=320, h_co=8), dict(y_co=-8), dict(k_rs=312),
+                dict(vt_bs=320 * 192 - 8), dict(ln_b=None), dict(y=d1), dict(wq=None), dict(k=None), dict(B=0)):
+        assert ok(xp(**bad)) == 0, bad
+    assert lib.onedc_xattn_block(C.byref(xp(C=640)), None) == -1           # a refused shape is a status, not a launch

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+python -c "from onedc_amd import kernels as K; K.lib(\"f16\")" || { echo "STALE LIBRARY"; exit 9; }
+mkdir -p gpurun_out/r6h
+timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/r6h/pytest_gpu.txt 2>&1
+tail -8 gpurun_out/r6h/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
