@@ -67,7 +67,6 @@ __device__ __forceinline__ int x_addr(int c8, int px) {         // byte address 
 template <bool VT_BF16, int KT_>
 __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_params p, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef __attribute__((address_space(3))) char lds_char;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -254,12 +253,12 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
         const int KT = KT_ ? KT_ : (p.Nk >> 4);               // key tiles of 16 (Nk % 16 == 0, <= 160)
         const a16_t *kb = (const a16_t *)p.k + (int64_t)img * p.Nk * p.k_rs;
         const a16_t *vb = (const a16_t *)p.vt + (int64_t)img * p.vt_bs;
-        uint4 kreg[3], vreg[4];
+        uint4 kreg[4], vreg[4];
         auto load_head = [&](int hd) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int c = tid + 256 * i;                  // chunk c: key c / 5, 16-byte piece c % 5 of the head's 80 B
-                const int key = (c * 13108) >> 16, ch = c - key * 5;
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + 256 * i;                  // chunk c: key c / 5, 16-byte piece c % 5 of the head's 80 B (800 chunks:
+                const int key = (c * 13108) >> 16, ch = c - key * 5;      // 160 rows; rows >= Nk are staged as zeros and masked in the softmax)
                 kreg[i] = key < p.Nk ? *(const uint4 *)(kb + (int64_t)key * p.k_rs + hd * XD + ch * 8) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
@@ -272,10 +271,10 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
         };
         auto store_head = [&]() {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const int c = tid + 256 * i;
                 const int key = (c * 13108) >> 16, ch = c - key * 5;
-                *(uint4 *)(smem + X_KIMG + key * X_KROW + ch * 16) = kreg[i];     // (keys up to 153; rows >= Nk hold zeros)
+                if (key < 160) *(uint4 *)(smem + X_KIMG + key * X_KROW + ch * 16) = kreg[i];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -284,17 +283,10 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
                 if (row < XD) *(uint4 *)(smem + X_VIMG + row * X_VROW + ch * 16) = vreg[i];
             }
         };
-        // keys 154 .. 159 of the K image are never staged (768 chunks cover 153.6 rows): zero them once per head image -- the
-        // tenth key tile is multiplied like the others (no branch in the tile loop) and masked in the softmax
-        auto zero_tail = [&]() {
-            if (tid < 30) *(uint4 *)(smem + X_KIMG + 154 * X_KROW + ((tid * 13108) >> 16) * X_KROW + (tid - ((tid * 13108) >> 16) * 5) * 16) =
-                make_uint4(0, 0, 0, 0);
-        };
         load_head(0);
         __syncthreads();                                      // q is complete in X; the ring is idle
         XA_TL(3);
         store_head();
-        zero_tail();
         const int px = 16 * wave + r16;
         const int sw = ((px >> 2) & 1) << 1;
 #pragma unroll 1
@@ -391,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
                 }
             }
             __syncthreads();                                  // every wave is done with this head's K / V^T images
-            if (hd + 1 < XHEADS) store_head();                // (rows 154 .. 159 keep their zeros: store_head never touches them)
+            if (hd + 1 < XHEADS) store_head();
         }
     }
 
