@@ -117,6 +117,8 @@ def parse():
                     help="CPU rehearsal of the multi-rank protocol (tests/test_dataparallel.py): every rank joins a gloo group, runs the "
                          "same barrier / K steps / barrier bracket around a stand-in step, the MAX reduction and the rank count go "
                          "through the collectives, rank 0 prints one JSON line.  No GPU, no model")
+    ap.add_argument("--cpu-baseline-child", default=None, metavar="SIZE:THREADS:PRESET:ZONLY",
+                    help=argparse.SUPPRESS)      # (internal: the all-threads CPU entry runs in a fresh process that never sees a GPU)
     ap.add_argument("--broadcast-weights", action="store_true",
                     help="rank 0 builds the weights, one flat RCCL broadcast hands them to the other ranks (the path a "
                          "real checkpoint takes); default: every rank builds the synthetic weights itself")
@@ -152,7 +154,7 @@ def _time_oracle_decode(sample, cores, weights, z_only):
         return time.perf_counter() - t0
 
 
-def cpu_baseline_decode(sample, threads, sds, z_only=False, extras=True):
+def cpu_baseline_decode(sample, threads, sds, z_only=False, extras=True, preset="trained_like"):
     """Oracle decode (everything after the entropy decode) of one sample x sample picture on the host; scaled to
     768^2-equivalent images/s by algorithmic FLOPs when sample != 768.  Beside the main entry (`threads` torch threads):
     ONE thread (the reference harness's own setting, src/inference.py:29) on a 256x256 picture."""
@@ -174,9 +176,43 @@ def cpu_baseline_decode(sample, threads, sds, z_only=False, extras=True):
     out = entry(sample, threads)
     if extras:
         out["one_thread"] = entry(256, 1)              # torch.set_num_threads(1): src/inference.py:29
-        # (rounds 3-4 also timed ALL host threads here: slower than 16 on a single picture -- 0.036 images/s -- and, once the
-        # process had run the side lines' models, pathologically so: 200 s for the 256x256 sample.  Dropped: a bounded sample.)
+        # SURVEY 8(d) also asks for ALL host threads.  Rounds 3-4 timed them in this process: slower than 16 on a single picture and,
+        # once the process had run the side lines' models, pathologically so (200 s for the 256x256 sample).  Round 6: a FRESH child
+        # process that never sees a GPU (its own weights, its own torch thread pool), bounded by a timeout.
+        out["all_threads"] = cpu_entry_in_child(256, ncpu, preset, z_only)
     return out
+
+
+def cpu_child(spec):
+    """--cpu-baseline-child SIZE:THREADS:PRESET:ZONLY: one oracle decode on the host, nothing else; prints one JSON object."""
+    from onedc_amd import synth
+    size, threads, preset, z_only = spec.split(":")
+    size, threads, z_only = int(size), int(threads), z_only == "1"
+    bias = -0.2 if preset == "trained_like" else None
+    sds = [synth.unet_state_dict(0, preset=preset), synth.codec_state_dict(0, scale_bias=bias, preset=preset),
+           synth.vae_state_dict(0, preset=preset)]
+    weights = _oracle_weights(sds)
+    _time_oracle_decode(size, threads, weights, z_only)                      # (warm-up: thread pool, allocator)
+    dt = _time_oracle_decode(size, threads, weights, z_only)
+    print(json.dumps({"seconds": dt, "threads": torch.get_num_threads()}), flush=True)
+
+
+def cpu_entry_in_child(size, threads, preset, z_only, timeout=240):
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""            # the child is a CPU program
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f"{size}:{threads}:{preset}:{int(z_only)}"],
+                           env=env, capture_output=True, text=True, timeout=timeout)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        scale = GFLOP_PER_IMAGE[size] / GFLOP_PER_IMAGE[768]
+        return {"value": round(scale / d["seconds"], 5), "unit": "images/s", "cores": d["threads"], "kind": "port", "cpu_model": cpu_model(),
+                "host_threads": ncpu,
+                "sample": f"oracle/torch_ref.py fp32, one {size}x{size} picture in {d['seconds']:.2f} s (second of two decodes) on "
+                          f"{d['threads']} of {ncpu} host threads in a fresh CPU-only child process, scaled to 768x768 by algorithmic GFLOP"}
+    except Exception as ex:                                # noqa: BLE001 -- a baseline entry must not cost the bench line
+        return {"value": None, "cores": threads, "kind": "port", "sample": f"not measured ({type(ex).__name__})"}
 
 
 def host_rans_timing(model, blob):
@@ -650,6 +686,8 @@ def dry_run_rank(args, rank, world):
 
 def main():
     args = parse()
+    if args.cpu_baseline_child:
+        return cpu_child(args.cpu_baseline_child)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)                     # (never returns; before anything here has asked the runtime about a GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1119,7 +1157,7 @@ def main():
                     model, images[:1], noise[:1], args.cpu_threads, sds, enc_sds, model.encode(images[:1], noise=noise[:1])[0])
             else:
                 line["cpu_baseline"] = cpu_baseline_decode(args.cpu_sample, args.cpu_threads, sds, z_only=(mode == "z_only"),
-                                                           extras=not args.no_extras)
+                                                           extras=not args.no_extras, preset=args.weights)
         print(json.dumps(line), flush=True)
     if pipe is not None and not pipe_closed:
         pipe.close()

@@ -11,7 +11,8 @@
 //       the host may fold the norm's affine into to_q -- Wq . diag(gamma), bias Wq . beta -- and pass ln_g = NULL: the tile is then only
 //       centred and scaled), normalised tile -> LDS image X in the MFMA B-operand layout of the window kernel (64 B per pixel and
 //       32-channel chunk, granule g at g ^ 2 * ((px >> 2) & 1)); the first two K-steps of Wq are already on their way (LDS-DMA)
-//   P1  q = Wq . X: 10 K-steps of 32 channels; the weights of a K-step (320 rows x 64 B) ride a ring of two LDS slots filled by LDS-DMA
+//   P1  q = Wq . X: 10 K-steps of 32 channels; the weights of a K-step (320 rows x 64 B) ride a ring of two LDS slots filled by LDS-DMA,
+//       each wave staging exactly the 80 rows its own fragments read -- the ring is wave-private, the K loop has NO barrier --
 //       (buffer_load ... lds, granule == lane on both sides: conflict-free fragment reads) and the fragments are double-buffered in
 //       registers (those of K-step t + 1 are read while K-step t multiplies, the slot they leave is restaged for t + 3); wave w owns
 //       channels 80 w .. 80 w + 79 of all 64 pixels (20 accumulator tiles, 9 fragment reads per 20 MFMAs)
@@ -82,17 +83,19 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
 
     // ---- the two projections: acc[i][pt] = channels 80 wave + 16 i .. + 15 (rows) x pixels 16 pt .. + 15 (columns) ------------------
     f32x4 acc[5][4];
-    const unsigned w_voff = (unsigned)(((wave * 16 + r16) * XC + g * 8) * 2);     // DMA lane: row (l & 15) of a 16-row block, granule l >> 4
+    // DMA lane: row (l & 15) of a 16-row block, granule l >> 4.  A wave stages exactly the five row blocks ITS fragments read (rows 80 w ..):
+    // the weight ring is private to the wave, its K loop needs no barrier -- only its own counted vmcnt and lgkmcnt
+    const unsigned w_voff = (unsigned)(((wave * 80 + r16) * XC + g * 8) * 2);
     const int a_rd = X_RING + wave * 5 * 1024 + lane * 16;                        // fragment lane == DMA lane
     int b_rd[4];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) b_rd[pt] = (16 * pt + r16) * 64 + ((g ^ ((((16 * pt + r16) >> 2) & 1) << 1)) << 4);
     __amdgpu_buffer_rsrc_t w_rsrc;
-    // weights of K-step ks into ring slot `slot`: row blocks wave, wave + 4, ... (five per wave)
+    // weights of K-step ks into ring slot `slot`: this wave's row blocks 5 wave .. 5 wave + 4
     auto stage = [&](int ks, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int jj = 0; jj < 5; ++jj)
-            glds16_buf(w_rsrc, w_voff, (unsigned)(jj * 64 * XC * 2 + ks * 64), smem + X_RING + slot * X_WT + (wave + 4 * jj) * 1024);
+            glds16_buf(w_rsrc, w_voff, (unsigned)(jj * 16 * XC * 2 + ks * 64), smem + X_RING + slot * X_WT + (5 * wave + jj) * 1024);
     };
     auto gemm_issue = [&](const void *wbase) __attribute__((always_inline)) {       // the first two K-steps on their way (the ring must be idle)
         w_rsrc = make_rsrc(wbase, (unsigned)(384 * XC * 2));
@@ -117,10 +120,9 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
         constexpr int cur = decltype(CUR)::value, nxt = cur ^ 1;
         constexpr int NKS = XC / 32;
         if (ks + 1 < NKS) {
-            // this wave's pieces of K-step ks + 1 have landed (the five of ks + 2 may fly on) -- then everybody's
+            // this wave's pieces of K-step ks + 1 have landed (the five of ks + 2 may fly on): nobody else writes or reads them
             if (ks + 2 < NKS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             read_frags(ks + 1, std::integral_constant<int, nxt>());
             __builtin_amdgcn_sched_barrier(0);
@@ -131,9 +133,7 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
             for (int pt = 0; pt < 4; ++pt) acc[i][pt] = ONEDC_MFMA16(fa[cur][i], fb[cur][pt], acc[i][pt]);
         __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < NKS) {
-            XA_WAIT_FRAGS(nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();                     // every wave holds the fragments of ks + 1: their slot may be restaged
+            XA_WAIT_FRAGS(nxt);                               // the fragments of ks + 1 are in registers: their slot may be restaged
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 3 < NKS) stage(ks + 3, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -144,14 +144,11 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
         for (int i = 0; i < 5; ++i)
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) acc[i][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // K-step 0's pieces (the five of K-step 1 may fly on), everybody's; its fragments; slot 0 restaged for K-step 2
+        // K-step 0's pieces (the five of K-step 1 may fly on); its fragments; slot 0 restaged for K-step 2
         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_frags(0, std::integral_constant<int, 0>());
         XA_WAIT_FRAGS(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         stage(2, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -229,9 +226,10 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
     __syncthreads();                                          // the normalised tile is in LDS
     XA_TL(1);
     gemm_run();
+    __syncthreads();                                          // every wave is past its last read of the normalised tile
     XA_TL(2);
 
-    // ---- P2: q -> X (every wave is past its last read of the normalised tile: the second barrier of the last K-step) ------------------
+    // ---- P2: q -> X ------------------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -400,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
     }
     gemm_issue(p.wo);
     gemm_run();
+    __syncthreads();                                          // every wave is past its last read of X and of its ring slots
     XA_TL(5);
 
     // ---- P5: bias, residual, 16-bit, through LDS (pixel rows of 640 B + 16), whole rows out ------------------------------------------
@@ -407,7 +406,6 @@ __global__ __launch_bounds__(256, 2) void xattn_block_kernel(const onedc_xattn_p
         float4 bias[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) bias[i] = p.bo ? *(const float4 *)(p.bo + 80 * wave + 16 * i + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        // (every wave is past its last fragment read of X and of the ring: the second barrier of the last K-step)
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
