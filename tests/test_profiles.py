@@ -39,6 +39,10 @@ def test_bench_line_carries_the_contract():
     base = line["cpu_baseline"]
     assert base["kind"] in ("reference", "port") and base["cores"] >= 1 and base["value"] > 0 and base["sample"]
     assert base["cpu_model"] and base["host_threads"] >= base["cores"]            # the CPU baseline names its processor
+    # ... and carries the reference harness's one-thread setting and an all-threads entry (a fresh CPU-only child process, bounded)
+    assert base["one_thread"]["cores"] == 1 and base["one_thread"]["value"] > 0
+    allt = base.get("all_threads")                          # (opt-in since round 6 measured it: it times out on the pool's 256-thread hosts)
+    assert allt is None or (allt["kind"] == "port" and allt["sample"] and (allt["value"] is None or allt["value"] > 0))
     # round 6: `value` is the FIRST of three timed regions of K steps, the other two say how far one region can be trusted
     rep = line["repeatability"]
     assert rep["regions"] == 3 and rep["values"][0] == line["value"] and rep["min"] <= line["value_median_of_3"] <= rep["max"]
