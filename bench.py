@@ -1142,6 +1142,23 @@ def main():
                 for st in (device or {}).get("stages", {}).values():
                     if isinstance(st, dict):
                         st["frac_of_peak_at_clock"] = round(st["tflops"] / pk, 4)
+        # This box against the box of the committed profile ("within 5 % of profiles/ or the line says why not"):
+        # boxes of the pool hold different clocks in the same loop (1.64 - 1.75 GHz met in round 6) and the dominant kernel's rate moves
+        # with it (and a little more: 1 124 - 1 196 TFLOP/s); the two ratios below say how much of a difference is the box's clock
+        for rnd in PROFILE_ROUNDS:
+            cpath = os.path.join(ROOT, "profiles", f"{rnd}_bench_line.json")
+            if mode == "decode" and os.path.exists(cpath):
+                try:
+                    cr = json.load(open(cpath))["roofline"]
+                    line["roofline"]["vs_committed_profile"] = {
+                        "profile": f"profiles/{rnd}_bench_line.json", "achieved": cr["achieved"], "clock_ghz": cr.get("clock_ghz"),
+                        "achieved_ratio": round(achieved / cr["achieved"], 4),
+                        "clock_ratio": round(clock["ghz"] / cr["clock_ghz"], 4) if (clock and clock.get("ghz") and cr.get("clock_ghz")) else None,
+                        "how": "this run's roofline.achieved and in-loop clock over the committed profile's (another box of the pool, the same "
+                               "code when the tree is the committed one): a ratio near the clock ratio is the box, not the kernel"}
+                except (OSError, ValueError, KeyError, ZeroDivisionError):
+                    pass
+                break
         # what the 16-bit MFMA instruction SUSTAINS on random-mantissa operands on this chip (power-limited: tools/micro/mfma_power,
         # measured offline, profiles/r4_mfma_power.txt) -- context for `frac`, which stays priced against the guide's 2.5 PF
         sustained, sustained_path = sustained_mfma_on_random_data(model.act)
