@@ -631,18 +631,23 @@ def launch_ranks(args):
     t = threading.Thread(target=relay, daemon=True)
     t.start()
     rc, t_fail = 0, None
-    while True:
-        codes = [p.poll() for p in procs]
-        bad = [c for c in codes if c not in (None, 0)]
-        if bad and t_fail is None:
-            rc, t_fail = bad[0], time.monotonic()
-        if all(c is not None for c in codes):
-            break
-        if t_fail is not None and time.monotonic() - t_fail > 5.0:       # a rank died: the others wait in a collective for ever
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()                                         # (exactly the children started here)
-        time.sleep(0.05)
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad and t_fail is None:
+                rc, t_fail = bad[0], time.monotonic()
+            if all(c is not None for c in codes):
+                break
+            if t_fail is not None and time.monotonic() - t_fail > 5.0:   # a rank died: the others wait in a collective for ever
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()                                     # (exactly the children started here)
+            time.sleep(0.05)
+    finally:                                                              # (the parent is interrupted or killed: no rank outlives it)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
     t.join(timeout=5.0)
     bad = [c for c in (p.returncode for p in procs) if c != 0]
     raise SystemExit(rc or (bad[0] if bad else 0))
