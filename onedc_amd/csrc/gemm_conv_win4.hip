@@ -421,7 +421,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) W4_MFMA(ACC[i][r], FA[cur][i], FBA[r]);
+#ifndef EXP_W4_KPRIO                                  // (experiment, round 6: the whole K loop at raised priority, not only its MFMA groups)
             __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             // (c) the weights of K-tile t + 1 (and at tap 8 the whole next window) have landed -- everywhere.
             //     Issue order per K-tile: weights of K-tile t + 4 (two instructions), then the window blocks of the next
@@ -498,7 +500,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) W4_MFMA(ACC[i][4 + r], FA[cur][i], FBB[r]);
+#ifndef EXP_W4_KPRIO
             __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -585,6 +589,9 @@ __global__ __launch_bounds__(256, 2) void conv_win4_kernel(const onedc_conv_para
         }
     }
 
+#ifdef EXP_W4_KPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     W4_TL(2);
     W4_RT(5);
     // ---- epilogue --------------------------------------------------------------------------------------------------------
