@@ -714,7 +714,11 @@ def main():
         return dry_run_rank(args, rank, world)
     torch.cuda.set_device(local_rank)          # before anything else asks the runtime about devices: a rank only ever touches its GPU
     device = torch.device("cuda", local_rank)
-    pinned = pin_host_threads(local_rank, world)
+    try:
+        pinned = pin_host_threads(local_rank, world)
+    except Exception as ex:                    # noqa: BLE001 -- an unreadable topology or a refused affinity call must not cost the run
+        print(f"bench.py: rank {rank}: host threads not pinned ({type(ex).__name__}: {ex})", file=sys.stderr)
+        pinned = None
     if world > 1 or args.broadcast_weights:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
